@@ -1,0 +1,148 @@
+"""Pins the CPU oracle (oracle/huf_oracle.c) against the reference.
+
+1. every known-answer vector of the reference's own tests for the path
+   (test/encode_test.c:35, test/decode_test.c:32-74, huffmanfile_test.py:8-34);
+2. streams captured from the unmodified reference (tests/golden/vectors.json);
+3. live differential runs against oracle/_ref/libhuffman_ref.so on seeded inputs.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from libhuffman_amd import datagen
+from oracle.oracle import RELAXED_TREE, STRICT_TREE
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def test_reference_known_answers(oracle):
+    # test/encode_test.c:35 - "1" with blocksize 256 encodes to exactly 21 bytes
+    assert oracle.encode(b"1", 256).size == 21
+    # test/tree_test.c:25-31 - single-symbol tree: root 256, left leaf, right absent
+    out = oracle.encode(b"\x03\x03\x03\x03", 0)
+    tree = np.frombuffer(out[10:20].tobytes(), dtype="<i2")
+    assert tree.tolist() == [256, 3, -1, -1, -1]
+    # huffmanfile_test.py:8-12 - b"a"*1000 at the Python default blocksize -> 145 bytes
+    c = oracle.encode(b"a" * 1000, 131072)
+    assert c.size == 145 and sha(c).startswith("c4270ae06ed145d8")
+    # README.md:37-56 / SURVEY Appendix C
+    assert oracle.encode(b"0123456789", 65536).tobytes().hex().endswith("ffffffffffff10326b1ee540")
+
+
+def test_encode_small_goldens(oracle, golden):
+    for vec in golden["encode_small"]:
+        data = bytes.fromhex(vec["input_hex"])
+        out = oracle.encode(data, vec["blocksize"])
+        assert out.tobytes().hex() == vec["output_hex"], vec["name"]
+        # decode parity incl. the k = 256 rejection (decoder.c:237-239)
+        err, back, used = oracle.decode(out, len(data) + 8, STRICT_TREE)
+        assert err == vec["ref_decode_err"], vec["name"]
+        if vec["ref_roundtrip"]:
+            assert back.tobytes() == data and used == out.size
+        err, back, _ = oracle.decode(out, len(data) + 8, RELAXED_TREE)
+        assert err == 0 and back.tobytes() == data, vec["name"]
+
+
+def test_encode_large_goldens(oracle, golden):
+    for vec in golden["encode_large"]:
+        data = datagen.GENERATORS[vec["generator"]](vec["n"])
+        assert sha(data) == vec["input_sha256"]
+        out, offs = oracle.encode(data, vec["blocksize"], with_offsets=True)
+        assert out.size == vec["output_len"] and sha(out) == vec["output_sha256"], vec
+        assert offs[0] == 0 and offs[-1] == out.size and np.all(np.diff(offs.astype(np.int64)) > 0)
+        err, back, _ = oracle.decode(out, vec["n"], STRICT_TREE)
+        assert err == vec["ref_decode_err"]
+        err, back, _ = oracle.decode(out, vec["n"], RELAXED_TREE)
+        assert err == 0 and np.array_equal(back, data)
+
+
+def test_decode_error_goldens(oracle, golden):
+    for vec in golden["decode_errors"] + golden["decode_ok"]:
+        stream = bytes.fromhex(vec["stream_hex"])
+        err, out, _ = oracle.decode(stream, 4096, STRICT_TREE, length=vec.get("length"))
+        assert err == vec["err"], vec["name"]
+        assert out.tobytes().hex() == vec["output_hex"], vec["name"]
+
+
+def test_null_root_is_an_error_not_a_crash(oracle):
+    # tree_len == 0 with block_len > 0: the reference dereferences NULL;
+    # the decision is BTREE_CORRUPTED.
+    stream = np.array([4, 0, 0, 0, 0], dtype="<i2").tobytes() + b"\x00"
+    err, out, _ = oracle.decode(stream, 16)
+    assert err == 6 and out.size == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_differential_vs_reference(oracle, reference, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 40000))
+    k = int(rng.integers(1, 256))           # k <= 255 keeps the reference's decoder usable
+    alphabet = rng.choice(256, size=k, replace=False)
+    p = rng.dirichlet(np.full(k, 0.3))
+    data = alphabet[rng.choice(k, size=n, p=p)].astype(np.uint8)
+    bs = int(rng.choice([0, 1, 7, 256, 4096, 65536]))
+    if bs == 1:
+        data = data[:300]
+    ref_out = reference.encode(data, bs)
+    ora_out = oracle.encode(data, bs)
+    assert np.array_equal(ref_out, ora_out)
+    rerr, rback = reference.decode(ref_out, raw_hint=data.size + 64)
+    oerr, oback, _ = oracle.decode(ora_out, data.size + 8)
+    assert rerr == oerr == 0 and np.array_equal(rback, oback) and np.array_equal(oback, data)
+
+
+def _reference_decode_in_child(reference, stream):
+    """Run the reference decoder in a forked child: on some corrupt inputs (NULL root, SURVEY
+    Appendix D) it dereferences NULL, which must not take pytest down with it."""
+    import os
+    import pickle
+    rfd, wfd = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            err, out = reference.decode(stream, raw_hint=1 << 17)
+            os.write(wfd, pickle.dumps((int(err), out.tobytes())))
+        finally:
+            os._exit(0)
+    os.close(wfd)
+    chunks = []
+    while True:
+        b = os.read(rfd, 1 << 16)
+        if not b:
+            break
+        chunks.append(b)
+    os.close(rfd)
+    _, status = os.waitpid(pid, 0)
+    if os.WIFSIGNALED(status) or not chunks:
+        return None
+    return pickle.loads(b"".join(chunks))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_differential_decode_of_garbage(oracle, reference, seed):
+    """Random bit flips in a valid stream must fail (or succeed) identically."""
+    rng = np.random.default_rng(100 + seed)
+    data = rng.integers(0, 40, size=3000, dtype=np.uint8)
+    good = reference.encode(data, 1024)
+    compared = 0
+    for _ in range(60):
+        bad = good.copy()
+        pos = int(rng.integers(0, bad.size))
+        bad[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        oerr, oout, _ = oracle.decode(bad, 1 << 16)
+        if oerr == 1:   # output larger than the test cap (mutated block_len) - not comparable
+            continue
+        res = _reference_decode_in_child(reference, bad)
+        if res is None:
+            # the reference crashed: only the NULL-root case may do that, and the decision
+            # for it is BTREE_CORRUPTED
+            assert oerr == 6
+            continue
+        rerr, rout = res
+        assert rerr == oerr
+        assert rout == oout.tobytes()
+        compared += 1
+    assert compared > 30

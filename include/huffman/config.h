@@ -1,0 +1,3 @@
+/* Compatibility forwarder: the reference splits its API over include/huffman/config.h;
+ * here every declaration lives in include/huffman.h. */
+#include "../huffman.h"

@@ -1,0 +1,124 @@
+/*
+ * huffman_gpu.h - device-resident entry points of the MI355X Huffman block codec.
+ *
+ * The reference has one boundary for the hot path: huf_encode()/huf_decode() over callback
+ * streams (include/huffman/encoder.h:25-26, decoder.h:25-26).  Those are served by this
+ * library too (include/huffman.h).  The functions below are the same per-block hot path with
+ * the callback streams peeled off: plain pointers into HBM and sizes, no host copies.  They
+ * are what huf_encode()/huf_decode() call internally after staging a batch, what the Python
+ * layer calls when the data already lives on the GPU, and what bench.py times.
+ *
+ * C ABI only: no C++ or torch types; `stream` arguments are a hipStream_t passed as void*
+ * (NULL = the context's own stream).  All functions return a huf_error_t value
+ * (include/huffman.h); HIP failures map to HUF_ERROR_FATAL and hufgpu_last_error() carries
+ * the text.  Nothing here falls back to the CPU.
+ *
+ * Replaces, per block (reference file:line):
+ *   hufgpu_histogram      src/histogram.c:73-103   huf_histogram_populate (iota = 1)
+ *   hufgpu_encode         src/encoder.c:288-374    block loop: histogram, tree.c:292-427 tree,
+ *                                                   encoder.c:40-81 codes, tree.c:233-289
+ *                                                   serialize, encoder.c:85-131 bit-pack
+ *   hufgpu_decode         src/decoder.c:218-276    header parse, tree.c:138-227 deserialize,
+ *                                                   decoder.c:34-96 tree walk
+ */
+#ifndef INCLUDE_huffman_gpu_h__
+#define INCLUDE_huffman_gpu_h__
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hufgpu_ctx hufgpu_ctx_t;   /* per-device workspace + stream; not thread-safe */
+
+/* Decode flags. */
+#define HUFGPU_STRICT_TREE  0u  /* tree_len > 1024 -> HUF_ERROR_BTREE_OVERFLOW (reference parity,
+                                   src/decoder.c:237-239) */
+#define HUFGPU_RELAXED_TREE 1u  /* accept the 1025-entry tree the encoder itself emits for blocks
+                                   with all 256 byte values */
+
+/* Largest block the kernels take (bytes).  Larger blocks -> HUF_ERROR_INVALID_ARGUMENT. */
+#define HUFGPU_MAX_BLOCK ((uint64_t)1 << 30)
+
+/* Number of usable gfx950 devices; 0 when HIP is unusable (never an error by itself). */
+int hufgpu_device_count(void);
+
+/* Create/destroy a context bound to `device`. HUF_ERROR_FATAL when there is no such GPU. */
+int hufgpu_ctx_create(hufgpu_ctx_t **ctx, int device);
+int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx);
+
+/* Text of the last failure on this context (or of the last global failure if ctx == NULL). */
+const char *hufgpu_last_error(const hufgpu_ctx_t *ctx);
+
+/* Number of blocks huf_encode produces for n input bytes (src/encoder.c:288-293). */
+uint64_t hufgpu_block_count(uint64_t n, uint64_t blocksize);
+
+/* Capacity (bytes) that always holds the encoded stream of n bytes. */
+uint64_t hufgpu_encode_bound(uint64_t n, uint64_t blocksize);
+
+/* 256-bin byte histogram of each block: d_hist[block * 256 + byte] (uint32). */
+int hufgpu_histogram(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                     uint32_t *d_hist, void *stream);
+
+/*
+ * Encode n bytes at d_in into the libhuffman block stream at d_out (both in HBM).
+ *   d_block_offsets : optional, nblocks+1 uint64 in HBM; receives the byte offset of every
+ *                     block header in d_out, the last entry being the stream length.  This is
+ *                     the in-process block index (the wire format itself stores no payload
+ *                     length - SURVEY §0 fact 1).
+ *   out_len         : optional host pointer; when given the call synchronises and stores the
+ *                     stream length.  When NULL the call only enqueues work on the stream.
+ */
+int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                  void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
+                  uint64_t *out_len, void *stream);
+
+/*
+ * Decode a block stream whose block index is known (d_block_offsets from hufgpu_encode).
+ *   raw_len  : optional host pointer; when given the call synchronises, stores the number of
+ *              bytes written to d_out and returns the first error in stream order
+ *              (HUF_ERROR_BTREE_OVERFLOW / _CORRUPTED / _READ_WRITE like src/decoder.c).
+ *              When NULL the call only enqueues; fetch the result with hufgpu_decode_result().
+ */
+int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                  const uint64_t *d_block_offsets, uint64_t nblocks,
+                  void *d_out, uint64_t out_cap, uint32_t flags,
+                  uint64_t *raw_len, void *stream);
+
+/* Synchronise and report the outcome of the last enqueued hufgpu_decode(). */
+int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
+
+/*
+ * Decode a raw stream (no index): `avail` bytes are readable at d_stream, `length` compressed
+ * bytes drive the block loop exactly like config->length in src/decoder.c:218.  Block
+ * boundaries are discovered on the device.  Synchronous.
+ */
+int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
+                         void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
+                         uint64_t *consumed, void *stream);
+
+/* Deterministic synthetic inputs of SURVEY §8d, generated in HBM (kind: 0 const41,
+ * 1 uniform256, 2 uniform255, 3 zipf255). `first` = index of the first byte of this shard in
+ * the global sequence, so shards of one logical input can be produced on different GPUs. */
+int hufgpu_fill(hufgpu_ctx_t *ctx, void *d_out, uint64_t n, int kind, uint64_t seed,
+                uint64_t first, void *stream);
+
+/* Plain device memory helpers so that C callers need not link HIP themselves. */
+int hufgpu_malloc(hufgpu_ctx_t *ctx, void **d_ptr, uint64_t bytes);
+int hufgpu_free(hufgpu_ctx_t *ctx, void *d_ptr);
+int hufgpu_memcpy_h2d(hufgpu_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int hufgpu_synchronize(hufgpu_ctx_t *ctx);
+
+/* Per-stage timing of the last synchronous-style run: enables HIP events around each kernel
+ * of subsequent calls (0 = off). Results in milliseconds, in launch order:
+ * encode: [hist, tree, scan, pack]; decode: [prepare, scan, decode]. */
+int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled);
+int hufgpu_get_stage_ms(hufgpu_ctx_t *ctx, float *ms, int max_stages, int *n_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDE_huffman_gpu_h__ */

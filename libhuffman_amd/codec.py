@@ -1,0 +1,134 @@
+"""Device-resident codec object over the hufgpu_* C ABI (include/huffman_gpu.h).
+
+``GpuCodec`` works on torch uint8 tensors that already live in HBM: torch is used for device
+memory and streams only, every byte of codec work happens in the HIP kernels of
+``csrc/hufgpu_kernels.hip`` through the C ABI.  There is no eager/CPU path: constructing a
+codec without a usable MI355X raises ``HuffmanGpuError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native
+
+FILL_KINDS = {"const41": 0, "uniform256": 1, "uniform255": 2, "zipf255": 3}
+FILL_SEEDS = {"const41": 0, "uniform256": 1, "uniform255": 2, "zipf255": 3}
+
+
+class HuffmanGpuError(RuntimeError):
+    def __init__(self, err: int, context: str, detail: str = ""):
+        self.err = err
+        msg = f"{_native.error_string(err)}. {context}"
+        if detail:
+            msg += f" ({detail})"
+        super().__init__(msg)
+
+
+class GpuCodec:
+    """One codec context per device. Not thread-safe (like the reference's objects)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _native.load()
+        self.device = device
+        self._ctx = C.c_void_p()
+        err = self.lib.hufgpu_ctx_create(C.byref(self._ctx), device)
+        if err:
+            raise HuffmanGpuError(err, "Failed to create the GPU codec context",
+                                  self.lib.hufgpu_last_error(None).decode())
+        self.tdev = torch.device("cuda", device)
+
+    def close(self):
+        if self._ctx:
+            self.lib.hufgpu_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _check(self, err: int, what: str):
+        if err:
+            raise HuffmanGpuError(err, what, self.lib.hufgpu_last_error(self._ctx).decode())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def block_count(self, n: int, blocksize: int) -> int:
+        return int(self.lib.hufgpu_block_count(n, blocksize))
+
+    def encode_bound(self, n: int, blocksize: int) -> int:
+        return int(self.lib.hufgpu_encode_bound(n, blocksize))
+
+    # -- hot path ---------------------------------------------------------------------------
+    def histogram(self, data: torch.Tensor, blocksize: int) -> torch.Tensor:
+        n = data.numel()
+        nb = self.block_count(n, blocksize)
+        hist = torch.empty((nb, 256), dtype=torch.int32, device=self.tdev)
+        self._check(self.lib.hufgpu_histogram(self._ctx, data.data_ptr(), n, blocksize,
+                                              hist.data_ptr(), self._stream()), "histogram failed")
+        return hist
+
+    def encode(self, data: torch.Tensor, blocksize: int, out: torch.Tensor | None = None,
+               offsets: torch.Tensor | None = None, sync: bool = True):
+        """Returns (stream tensor view, offsets tensor[nblocks+1], length or None)."""
+        assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
+        n = data.numel()
+        nb = self.block_count(n, blocksize)
+        if out is None:
+            out = torch.empty(self.encode_bound(n, blocksize), dtype=torch.uint8, device=self.tdev)
+        if offsets is None:
+            offsets = torch.empty(nb + 1, dtype=torch.int64, device=self.tdev)
+        out_len = C.c_uint64(0)
+        err = self.lib.hufgpu_encode(self._ctx, data.data_ptr(), n, blocksize, out.data_ptr(),
+                                     out.numel(), offsets.data_ptr(),
+                                     C.byref(out_len) if sync else None, self._stream())
+        self._check(err, "Failed to encode the data")
+        if sync:
+            return out[: out_len.value], offsets, int(out_len.value)
+        return out, offsets, None
+
+    def decode(self, stream: torch.Tensor, stream_len: int, offsets: torch.Tensor, nblocks: int,
+               out: torch.Tensor, relaxed: bool = False, sync: bool = True):
+        """Indexed decode. Returns bytes written (sync) or None (enqueued only)."""
+        raw = C.c_uint64(0)
+        err = self.lib.hufgpu_decode(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
+                                     nblocks, out.data_ptr(), out.numel(),
+                                     _native.RELAXED_TREE if relaxed else _native.STRICT_TREE,
+                                     C.byref(raw) if sync else None, self._stream())
+        self._check(err, "Failed to decode the data")
+        return int(raw.value) if sync else None
+
+    def decode_result(self) -> int:
+        raw = C.c_uint64(0)
+        self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data")
+        return int(raw.value)
+
+    def decode_stream(self, stream: torch.Tensor, avail: int, length: int, out: torch.Tensor,
+                      relaxed: bool = False):
+        """Raw-stream decode (no index). Returns (err, bytes written, bytes consumed)."""
+        raw, used = C.c_uint64(0), C.c_uint64(0)
+        err = self.lib.hufgpu_decode_stream(self._ctx, stream.data_ptr() if stream.numel() else None,
+                                            avail, length, out.data_ptr(), out.numel(),
+                                            _native.RELAXED_TREE if relaxed else _native.STRICT_TREE,
+                                            C.byref(raw), C.byref(used), self._stream())
+        return int(err), int(raw.value), int(used.value)
+
+    def fill(self, out: torch.Tensor, kind: str, first: int = 0, seed: int | None = None):
+        seed = FILL_SEEDS[kind] if seed is None else seed
+        self._check(self.lib.hufgpu_fill(self._ctx, out.data_ptr(), out.numel(), FILL_KINDS[kind],
+                                         seed, first, self._stream()), "fill failed")
+        return out
+
+    def set_profiling(self, on: bool):
+        self.lib.hufgpu_set_profiling(self._ctx, 1 if on else 0)
+
+    def stage_ms(self):
+        ms = (C.c_float * 8)()
+        n = C.c_int(0)
+        self._check(self.lib.hufgpu_get_stage_ms(self._ctx, ms, 8, C.byref(n)), "stage timing failed")
+        return [float(ms[i]) for i in range(n.value)]

@@ -1,0 +1,909 @@
+/*
+ * huf_host.cpp - host half of the drop-in libhuffman API (include/huffman.h).
+ *
+ *  - stream backends, buffered byte I/O, error strings, config/alloc helpers: host plumbing
+ *    with the reference's observable behaviour (src/io.c, src/bufio.c, src/errors.c,
+ *    src/config.c, src/malloc.c) minus the defects listed in SURVEY Appendix D;
+ *  - host-callable building blocks the reference also exports (histogram, symbol map, pointer
+ *    tree): small re-implementations so that programs linking those symbols keep working;
+ *  - huf_encode()/huf_decode(): read a batch through the caller's reader, run the block
+ *    codec ON THE GPU (hufgpu_encode / hufgpu_decode_stream), hand the result to the writer.
+ *    There is no CPU codec behind them: no GPU => HUF_ERROR_FATAL.
+ *
+ * Environment (huf_config_t's 48-byte layout is ABI, so switches live outside it):
+ *   HUF_GPU_DEVICE        device ordinal (default 0)
+ *   HUF_GPU_BATCH_MB      input bytes staged per GPU round in huf_encode (default 256)
+ *   HUF_GPU_RELAXED_TREE  1 = accept 1025-entry trees on decode
+ */
+#include <errno.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/huffman.h"
+#include "../../include/huffman_gpu.h"
+
+#define GUARD(ptr)                                   \
+    do {                                             \
+        if (!(ptr)) return HUF_ERROR_INVALID_ARGUMENT; \
+    } while (0)
+#define TRY(expr)                                    \
+    do {                                             \
+        huf_error_t e__ = (huf_error_t)(expr);       \
+        if (e__ != HUF_ERROR_SUCCESS) return e__;    \
+    } while (0)
+
+extern "C" {
+
+/* ------------------------------------------------------------------ errors / alloc / config */
+const char *huf_error_string(huf_error_t error)   /* src/errors.c:5-33 */
+{
+    switch ((int)error) {
+    case HUF_ERROR_SUCCESS: return "Success";
+    case HUF_ERROR_MEMORY_ALLOCATION: return "Failed to allocate the requested memory block";
+    case HUF_ERROR_INVALID_ARGUMENT: return "An invalid argument was specified to the function";
+    case HUF_ERROR_READ_WRITE: return "Failed on read/write operation";
+    case HUF_ERROR_FATAL: return "Fatal error";
+    case HUF_ERROR_BTREE_OVERFLOW: return "Block is corrupted, Huffman tree has impossible size";
+    case HUF_ERROR_BTREE_CORRUPTED: return "Huffman tree is corrupted and cannot be used to decode the block";
+    default: return "Unknown error";
+    }
+}
+
+huf_error_t huf_malloc(void **ptr, size_t size, size_t num)   /* src/malloc.c:7-19 */
+{
+    GUARD(ptr);
+    *ptr = calloc(num, size);
+    return *ptr ? HUF_ERROR_SUCCESS : HUF_ERROR_MEMORY_ALLOCATION;
+}
+
+huf_error_t huf_config_init(huf_config_t **self)   /* src/config.c:7-19 */
+{
+    GUARD(self);
+    return huf_malloc((void **)self, sizeof(huf_config_t), 1);
+}
+
+huf_error_t huf_config_free(huf_config_t **self)   /* src/config.c:22-33 */
+{
+    GUARD(self);
+    free(*self);
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ memory stream (src/io.c:66-226) */
+typedef struct {
+    void **buf;     /* caller-owned pointer, replaced on growth */
+    size_t off;     /* read cursor */
+    size_t len;
+    size_t cap;
+} membuf_t;
+
+huf_error_t memwrite(void *stream, const void *buf, size_t count)
+{
+    membuf_t *m = (membuf_t *)stream;
+    if (!m || (!buf && count)) return HUF_ERROR_INVALID_ARGUMENT;
+    if (m->cap - m->len < count) {
+        /* growth policy of src/io.c:79-84 (double, or twice the request), but never smaller
+         * than what is needed - the reference under-allocates here */
+        size_t want = m->cap * 2;
+        if (count > want) want = count * 2;
+        if (want < m->len + count) want = m->len + count;
+        void *grown = calloc(want ? want : 1, 1);
+        if (!grown) return HUF_ERROR_MEMORY_ALLOCATION;
+        if (m->len) memcpy(grown, *m->buf, m->len);
+        free(*m->buf);
+        *m->buf = grown;
+        m->cap = want;
+    }
+    if (count) memcpy((char *)*m->buf + m->len, buf, count);
+    m->len += count;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t memread(void *stream, void *buf, size_t *count)
+{
+    membuf_t *m = (membuf_t *)stream;
+    if (!m || !count) return HUF_ERROR_INVALID_ARGUMENT;
+    size_t left = m->len - m->off;
+    size_t take = *count < left ? *count : left;     /* short reads are not an error here */
+    if (take) memcpy(buf, (char *)*m->buf + m->off, take);
+    m->off += take;
+    *count = take;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_memopen(huf_read_writer_t **self, void **buf, size_t capacity)
+{
+    GUARD(self);
+    GUARD(buf);
+    huf_read_writer_t *rw = (huf_read_writer_t *)calloc(1, sizeof(*rw));
+    membuf_t *m = (membuf_t *)calloc(1, sizeof(*m));
+    void *mem = calloc(capacity ? capacity : 1, 1);
+    if (!rw || !m || !mem) {
+        free(rw); free(m); free(mem);
+        return HUF_ERROR_MEMORY_ALLOCATION;
+    }
+    *buf = mem;
+    m->buf = buf;
+    m->cap = capacity;
+    rw->stream = m;
+    rw->write = memwrite;
+    rw->read = memread;
+    *self = rw;
+    return HUF_ERROR_SUCCESS;
+}
+
+static membuf_t *as_mem(const huf_read_writer_t *rw) { return rw ? (membuf_t *)rw->stream : NULL; }
+
+huf_error_t huf_memlen(const huf_read_writer_t *self, size_t *len)
+{
+    GUARD(self); GUARD(len);
+    *len = as_mem(self)->len;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_memcap(const huf_read_writer_t *self, size_t *cap)
+{
+    GUARD(self); GUARD(cap);
+    *cap = as_mem(self)->cap;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_memrewind(huf_read_writer_t *self)   /* truncate, src/io.c:160-170 */
+{
+    GUARD(self);
+    as_mem(self)->len = 0;
+    as_mem(self)->off = 0;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_memclose(huf_read_writer_t **self)   /* leaves *buf to the caller, src/io.c:213-226 */
+{
+    GUARD(self);
+    if (*self) {
+        free((*self)->stream);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ fd stream (src/io.c:9-63) */
+huf_error_t fdwrite(void *stream, const void *buf, size_t count)
+{
+    if (!stream) return HUF_ERROR_INVALID_ARGUMENT;
+    const int fd = *(int *)stream;
+    const char *p = (const char *)buf;
+    while (count) {                      /* partial writes and EINTR are retried */
+        ssize_t w = write(fd, p, count);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return HUF_ERROR_READ_WRITE;
+        }
+        p += w;
+        count -= (size_t)w;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t fdread(void *stream, void *buf, size_t *count)
+{
+    if (!stream || !count) return HUF_ERROR_INVALID_ARGUMENT;
+    const int fd = *(int *)stream;
+    size_t got = 0;
+    while (got < *count) {               /* fill the request unless EOF comes first */
+        ssize_t r = read(fd, (char *)buf + got, *count - got);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            *count = got;
+            return HUF_ERROR_READ_WRITE;
+        }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    *count = got;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_fdopen(huf_read_writer_t **self, int fd)
+{
+    GUARD(self);
+    huf_read_writer_t *rw = (huf_read_writer_t *)calloc(1, sizeof(*rw));
+    int *slot = (int *)malloc(sizeof(int));   /* the reference keeps the address of its own
+                                                  parameter (src/io.c:45); a heap copy here */
+    if (!rw || !slot) { free(rw); free(slot); return HUF_ERROR_MEMORY_ALLOCATION; }
+    *slot = fd;
+    rw->stream = slot;
+    rw->read = fdread;
+    rw->write = fdwrite;
+    *self = rw;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_fdclose(huf_read_writer_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        free((*self)->stream);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ bit writer (src/bufio.c:18-32) */
+void huf_bit_write(huf_bit_read_writer_t *self, uint8_t bit)
+{
+    if (self->offset) self->offset--;
+    self->bits |= (uint8_t)((bit & 1u) << self->offset);
+}
+
+void huf_bit_read_writer_reset(huf_bit_read_writer_t *self)
+{
+    self->bits = 0;
+    self->offset = 8;
+}
+
+/* ------------------------------------------------------------------ buffered byte I/O (src/bufio.c:37-320) */
+huf_error_t huf_bufio_read_writer_init(huf_bufio_read_writer_t **self, huf_read_writer_t *read_writer, size_t size)
+{
+    GUARD(self); GUARD(read_writer);
+    huf_bufio_read_writer_t *b = (huf_bufio_read_writer_t *)calloc(1, sizeof(*b));
+    if (!b) return HUF_ERROR_MEMORY_ALLOCATION;
+    if (size) {                          /* 0 => pass-through (src/bufio.c:58-68) */
+        b->bytes = (uint8_t *)calloc(size, 1);
+        if (!b->bytes) { free(b); return HUF_ERROR_MEMORY_ALLOCATION; }
+    }
+    b->capacity = size;
+    b->read_writer = read_writer;
+    *self = b;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_bufio_read_writer_free(huf_bufio_read_writer_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        free((*self)->bytes);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_bufio_read_writer_flush(huf_bufio_read_writer_t *self)
+{
+    GUARD(self);
+    if (!self->length) return HUF_ERROR_SUCCESS;
+    TRY(self->read_writer->write(self->read_writer->stream, self->bytes, self->length));
+    self->length = 0;                    /* bytes were counted when they were accepted */
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_bufio_write(huf_bufio_read_writer_t *self, const void *buf, size_t size)
+{
+    GUARD(self); GUARD(buf);
+    if (self->capacity && self->length >= self->capacity) TRY(huf_bufio_read_writer_flush(self));
+    if (self->capacity && size <= self->capacity - self->length) {
+        memcpy(self->bytes + self->length, buf, size);
+        self->length += size;
+        self->have_been_processed += size;
+        return HUF_ERROR_SUCCESS;
+    }
+    if (size) {                          /* too big for the buffer: drain, then write through */
+        TRY(huf_bufio_read_writer_flush(self));
+        TRY(self->read_writer->write(self->read_writer->stream, buf, size));
+        self->have_been_processed += size;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_bufio_read(huf_bufio_read_writer_t *self, void *buf, size_t size)
+{
+    GUARD(self); GUARD(buf);
+    uint8_t *dst = (uint8_t *)buf;
+    size_t want = size;
+    size_t have = self->length - self->offset;
+    if (have && want) {
+        size_t take = have < want ? have : want;
+        memcpy(dst, self->bytes + self->offset, take);
+        self->offset += take;
+        dst += take;
+        want -= take;
+    }
+    if (want) {
+        if (want >= self->capacity) {    /* straight into the destination (src/bufio.c:239-257) */
+            size_t got = want;
+            TRY(self->read_writer->read(self->read_writer->stream, dst, &got));
+            self->length = self->offset = 0;
+            if (got < want) return HUF_ERROR_READ_WRITE;
+        } else {                         /* refill, then copy (src/bufio.c:259-277) */
+            size_t got = self->capacity;
+            TRY(self->read_writer->read(self->read_writer->stream, self->bytes, &got));
+            self->length = got;
+            self->offset = 0;
+            if (got < want) return HUF_ERROR_READ_WRITE;
+            memcpy(dst, self->bytes, want);
+            self->offset = want;
+        }
+    }
+    self->have_been_processed += size;   /* only successful requests are counted */
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_bufio_read_uint8(huf_bufio_read_writer_t *self, uint8_t *byte)
+{
+    GUARD(self); GUARD(byte);
+    return huf_bufio_read(self, byte, 1);
+}
+
+huf_error_t huf_bufio_write_uint8(huf_bufio_read_writer_t *self, uint8_t byte)
+{
+    GUARD(self);
+    return huf_bufio_write(self, &byte, 1);
+}
+
+/* ------------------------------------------------------------------ histogram (src/histogram.c) */
+huf_error_t huf_histogram_init(huf_histogram_t **self, size_t iota, size_t length)
+{
+    GUARD(self);
+    if (!iota || !length) return HUF_ERROR_INVALID_ARGUMENT;
+    huf_histogram_t *h = (huf_histogram_t *)calloc(1, sizeof(*h));
+    if (!h) return HUF_ERROR_MEMORY_ALLOCATION;
+    h->frequencies = (uint64_t *)calloc(length, sizeof(uint64_t));
+    if (!h->frequencies) { free(h); return HUF_ERROR_MEMORY_ALLOCATION; }
+    h->iota = iota;
+    h->length = length;
+    h->start = (size_t)-1;
+    *self = h;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_histogram_free(huf_histogram_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        free((*self)->frequencies);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_histogram_reset(huf_histogram_t *self)
+{
+    GUARD(self);
+    memset(self->frequencies, 0, self->length * sizeof(uint64_t));
+    self->start = (size_t)-1;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* Generic element width (1..8 bytes, little-endian), whole elements only. The GPU kernel
+ * hist256_kernel is the iota == 1 case the codec uses; this host version exists because the
+ * reference exports it with a host-pointer signature. */
+huf_error_t huf_histogram_populate(huf_histogram_t *self, void *buf, size_t len)
+{
+    GUARD(self); GUARD(buf);
+    if (self->iota > 8) return HUF_ERROR_INVALID_ARGUMENT;
+    const uint8_t *p = (const uint8_t *)buf;
+    for (size_t at = 0; at + self->iota <= len; at += self->iota) {
+        uint64_t el = 0;
+        memcpy(&el, p + at, self->iota);
+        if (el >= self->length) return HUF_ERROR_INVALID_ARGUMENT;   /* the reference writes out of bounds */
+        self->frequencies[el]++;
+        if (self->start == (size_t)-1 || el < self->start) self->start = (size_t)el;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ symbol map (src/symbol.c) */
+huf_error_t huf_symbol_mapping_element_init(huf_symbol_mapping_element_t **self, const uint8_t *coding, size_t length)
+{
+    GUARD(self); GUARD(coding);
+    huf_symbol_mapping_element_t *e = (huf_symbol_mapping_element_t *)calloc(1, sizeof(*e));
+    if (!e) return HUF_ERROR_MEMORY_ALLOCATION;
+    e->coding = (uint8_t *)calloc(length + 1, 1);
+    if (!e->coding) { free(e); return HUF_ERROR_MEMORY_ALLOCATION; }
+    memcpy(e->coding, coding, length);
+    e->length = length;
+    *self = e;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_element_free(huf_symbol_mapping_element_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        free((*self)->coding);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_init(huf_symbol_mapping_t **self, size_t length)
+{
+    GUARD(self);
+    huf_symbol_mapping_t *m = (huf_symbol_mapping_t *)calloc(1, sizeof(*m));
+    if (!m) return HUF_ERROR_MEMORY_ALLOCATION;
+    m->symbols = (huf_symbol_mapping_element_t **)calloc(length ? length : 1, sizeof(*m->symbols));
+    if (!m->symbols) { free(m); return HUF_ERROR_MEMORY_ALLOCATION; }
+    m->length = length;
+    *self = m;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_reset(huf_symbol_mapping_t *self)
+{
+    GUARD(self);
+    for (size_t i = 0; i < self->length; i++)
+        if (self->symbols[i]) huf_symbol_mapping_element_free(&self->symbols[i]);
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_free(huf_symbol_mapping_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        huf_symbol_mapping_reset(*self);
+        free((*self)->symbols);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_insert(huf_symbol_mapping_t *self, size_t position, huf_symbol_mapping_element_t *element)
+{
+    GUARD(self); GUARD(element);
+    if (position >= self->length) return HUF_ERROR_INVALID_ARGUMENT;
+    if (self->symbols[position]) huf_symbol_mapping_element_free(&self->symbols[position]);
+    self->symbols[position] = element;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_symbol_mapping_get(huf_symbol_mapping_t *self, size_t position, huf_symbol_mapping_element_t **element)
+{
+    GUARD(self); GUARD(element);
+    if (position >= self->length) return HUF_ERROR_INVALID_ARGUMENT;
+    *element = self->symbols[position];
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ pointer tree (src/tree.c) */
+huf_error_t huf_node_to_string(const huf_node_t *self, uint8_t *buf, size_t *len)
+{
+    GUARD(buf); GUARD(len);
+    size_t n = 0;
+    for (const huf_node_t *cur = self; cur && cur->parent && n < *len; cur = cur->parent)
+        buf[n++] = (cur->parent->left == cur) ? '0' : '1';    /* leaf -> root, src/tree.c:23-41 */
+    *len = n;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_tree_init(huf_tree_t **self)
+{
+    GUARD(self);
+    huf_tree_t *t = (huf_tree_t *)calloc(1, sizeof(*t));
+    if (!t) return HUF_ERROR_MEMORY_ALLOCATION;
+    t->leaves = (huf_node_t **)calloc(HUF_HISTOGRAM_LEN, sizeof(huf_node_t *));
+    if (!t->leaves) { free(t); return HUF_ERROR_MEMORY_ALLOCATION; }
+    *self = t;
+    return HUF_ERROR_SUCCESS;
+}
+
+static void free_nodes(huf_node_t *root)   /* iterative: foreign trees may be 1025 deep */
+{
+    huf_node_t *cur = root;
+    while (cur) {
+        if (cur->left) { huf_node_t *c = cur->left; cur->left = NULL; c->parent = cur; cur = c; }
+        else if (cur->right) { huf_node_t *c = cur->right; cur->right = NULL; c->parent = cur; cur = c; }
+        else {
+            huf_node_t *up = (cur == root) ? NULL : cur->parent;
+            free(cur);
+            cur = up;
+        }
+    }
+}
+
+huf_error_t huf_tree_reset(huf_tree_t *self)
+{
+    GUARD(self);
+    free_nodes(self->root);
+    self->root = NULL;
+    memset(self->leaves, 0, HUF_HISTOGRAM_LEN * sizeof(huf_node_t *));
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_tree_free(huf_tree_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        free_nodes((*self)->root);
+        free((*self)->leaves);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* Same selection rule as the device tree_kernel: smallest (rate, 511 - index) first; the
+ * smaller becomes the left child; a lone survivor gets a left-only root (src/tree.c:292-427).
+ * Consumes the histogram like the reference does. */
+huf_error_t huf_tree_from_histogram(huf_tree_t *self, huf_histogram_t *histogram)
+{
+    GUARD(self); GUARD(histogram);
+    if (histogram->length < HUF_HISTOGRAM_LEN) return HUF_ERROR_INVALID_ARGUMENT;
+    uint64_t *rate = histogram->frequencies;
+    huf_node_t *slot[HUF_HISTOGRAM_LEN] = {0};
+    int next = HUF_ASCII_COUNT;
+    for (;;) {
+        int best = -1, second = -1;
+        for (int i = next - 1; i >= 0; i--) {          /* descending index: ties keep the earlier hit */
+            if (!rate[i]) continue;
+            if (best < 0 || rate[i] < rate[best]) { second = best; best = i; }
+            else if (second < 0 || rate[i] < rate[second]) second = i;
+        }
+        if (best < 0) break;
+        if (next >= HUF_HISTOGRAM_LEN) return HUF_ERROR_FATAL;
+        huf_node_t *parent = (huf_node_t *)calloc(1, sizeof(huf_node_t));
+        if (!parent) return HUF_ERROR_MEMORY_ALLOCATION;
+        parent->index = (int16_t)next;
+        const int pick[2] = {best, second};
+        for (int side = 0; side < 2; side++) {
+            const int i = pick[side];
+            if (i < 0) continue;
+            if (!slot[i]) {
+                slot[i] = (huf_node_t *)calloc(1, sizeof(huf_node_t));
+                if (!slot[i]) { free(parent); return HUF_ERROR_MEMORY_ALLOCATION; }
+                slot[i]->index = (int16_t)i;
+            }
+            slot[i]->parent = parent;
+            if (side == 0) parent->left = slot[i]; else parent->right = slot[i];
+            if (i < HUF_ASCII_COUNT) self->leaves[i] = slot[i];
+        }
+        rate[next] = rate[best] + (second >= 0 ? rate[second] : 0);
+        rate[best] = 0;
+        if (second >= 0) rate[second] = 0;
+        slot[next] = parent;
+        self->root = parent;
+        next++;
+        if (second < 0) break;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_tree_serialize(huf_tree_t *self, int16_t *buf, size_t *len)   /* preorder, -1 = absent */
+{
+    GUARD(self); GUARD(buf); GUARD(len);
+    size_t n = 0;
+    /* explicit stack of "right children still to emit" */
+    const huf_node_t *stack[2 * HUF_HISTOGRAM_LEN + 4];
+    int top = 0;
+    const huf_node_t *cur = self->root;
+    for (;;) {
+        if (cur) {
+            buf[n++] = cur->index;
+            if (top >= (int)(sizeof(stack) / sizeof(stack[0]))) return HUF_ERROR_FATAL;
+            stack[top++] = cur->right;
+            cur = cur->left;
+        } else {
+            buf[n++] = HUF_LEAF_NODE;
+            if (!top) break;
+            cur = stack[--top];
+        }
+    }
+    *len = n;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_tree_deserialize(huf_tree_t *self, const int16_t *buf, size_t len)
+{
+    GUARD(self); GUARD(buf);
+    /* every entry other than -1 is a node, entries past `len` are absent children */
+    huf_node_t **pending = (huf_node_t **)calloc(len + 1, sizeof(huf_node_t *));
+    if (!pending) return HUF_ERROR_MEMORY_ALLOCATION;
+    size_t top = 0, at = 0;
+    huf_node_t **link = &self->root;
+    huf_node_t *owner = NULL;
+    for (;;) {
+        huf_node_t *made = NULL;
+        if (at < len) {
+            const int16_t v = buf[at++];
+            if (v != HUF_LEAF_NODE) {
+                made = (huf_node_t *)calloc(1, sizeof(huf_node_t));
+                if (!made) { free(pending); return HUF_ERROR_MEMORY_ALLOCATION; }
+                made->index = v;
+                made->parent = owner;
+            }
+        }
+        if (made) {
+            *link = made;
+            pending[top++] = made;
+            owner = made;
+            link = &made->left;
+            continue;
+        }
+        if (!top) break;
+        owner = pending[--top];
+        link = &owner->right;
+    }
+    free(pending);
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ GPU session shared by huf_encode/huf_decode */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static hufgpu_ctx_t *g_ctx = NULL;
+static int g_relaxed = -1;
+
+typedef struct {
+    void *h_a, *h_b;           /* pinned staging */
+    size_t h_a_cap, h_b_cap;
+    void *d_a, *d_b;           /* device staging */
+    size_t d_a_cap, d_b_cap;
+} staging_t;
+static staging_t g_stage;
+
+static huf_error_t session_acquire(void)
+{
+    if (g_ctx) return HUF_ERROR_SUCCESS;
+    const char *dev = getenv("HUF_GPU_DEVICE");
+    int rc = hufgpu_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
+    if (rc != HUF_ERROR_SUCCESS) {
+        fprintf(stderr, "libhuffman: the codec needs an MI355X (gfx950) GPU and has no CPU fallback: %s\n",
+                hufgpu_last_error(NULL));
+        g_ctx = NULL;
+        return HUF_ERROR_FATAL;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+static huf_error_t grow_host(void **p, size_t *cap, size_t want)
+{
+    if (*cap >= want) return HUF_ERROR_SUCCESS;
+    if (*p) (void)hipHostFree(*p);
+    *p = NULL; *cap = 0;
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return HUF_ERROR_MEMORY_ALLOCATION;
+    }
+    *cap = want;
+    return HUF_ERROR_SUCCESS;
+}
+
+static huf_error_t grow_dev(void **p, size_t *cap, size_t want)
+{
+    if (*cap >= want) return HUF_ERROR_SUCCESS;
+    if (*p) hufgpu_free(g_ctx, *p);
+    *p = NULL; *cap = 0;
+    TRY(hufgpu_malloc(g_ctx, p, want));
+    *cap = want;
+    return HUF_ERROR_SUCCESS;
+}
+
+static int relaxed_tree(void)
+{
+    if (g_relaxed < 0) {
+        const char *e = getenv("HUF_GPU_RELAXED_TREE");
+        g_relaxed = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_relaxed;
+}
+
+/* Exported switch (not part of the reference API): 1 = accept tree_len 1025 on decode. */
+void huf_gpu_set_relaxed_tree(int enabled) { g_relaxed = enabled ? 1 : 0; }
+
+/* ------------------------------------------------------------------ encoder / decoder objects */
+struct __huf_encoder {
+    huf_config_t *config;
+    huf_bufio_read_writer_t *bufio_writer;
+    huf_bufio_read_writer_t *bufio_reader;
+};
+struct __huf_decoder {
+    huf_config_t *config;
+    huf_bufio_read_writer_t *bufio_writer;
+    huf_bufio_read_writer_t *bufio_reader;
+};
+
+static huf_error_t codec_init(huf_config_t **cfg, huf_bufio_read_writer_t **w, huf_bufio_read_writer_t **r,
+                              const huf_config_t *config)
+{
+    GUARD(config);
+    if (!config->reader || !config->writer) return HUF_ERROR_INVALID_ARGUMENT;   /* the reference crashes */
+    TRY(huf_config_init(cfg));
+    memcpy(*cfg, config, sizeof(*config));       /* private copy: the caller's struct is never written */
+    TRY(huf_bufio_read_writer_init(w, (*cfg)->writer, (*cfg)->writer_buffer_size));
+    TRY(huf_bufio_read_writer_init(r, (*cfg)->reader, (*cfg)->reader_buffer_size));
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_encoder_init(huf_encoder_t **self, const huf_config_t *config)
+{
+    GUARD(self); GUARD(config);
+    huf_encoder_t *e = (huf_encoder_t *)calloc(1, sizeof(*e));
+    if (!e) return HUF_ERROR_MEMORY_ALLOCATION;
+    *self = e;
+    huf_error_t err = codec_init(&e->config, &e->bufio_writer, &e->bufio_reader, config);
+    if (err == HUF_ERROR_SUCCESS && !e->config->blocksize) e->config->blocksize = e->config->length;   /* encoder.c:163-165 */
+    if (err != HUF_ERROR_SUCCESS) huf_encoder_free(self);
+    return err;
+}
+
+huf_error_t huf_encoder_free(huf_encoder_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        huf_bufio_read_writer_free(&(*self)->bufio_writer);
+        huf_bufio_read_writer_free(&(*self)->bufio_reader);
+        huf_config_free(&(*self)->config);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t huf_decoder_init(huf_decoder_t **self, const huf_config_t *config)
+{
+    GUARD(self); GUARD(config);
+    huf_decoder_t *d = (huf_decoder_t *)calloc(1, sizeof(*d));
+    if (!d) return HUF_ERROR_MEMORY_ALLOCATION;
+    *self = d;
+    huf_error_t err = codec_init(&d->config, &d->bufio_writer, &d->bufio_reader, config);
+    if (err != HUF_ERROR_SUCCESS) huf_decoder_free(self);
+    return err;
+}
+
+huf_error_t huf_decoder_free(huf_decoder_t **self)
+{
+    GUARD(self);
+    if (*self) {
+        huf_bufio_read_writer_free(&(*self)->bufio_writer);
+        huf_bufio_read_writer_free(&(*self)->bufio_reader);
+        huf_config_free(&(*self)->config);
+        free(*self);
+    }
+    *self = NULL;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ huf_encode (src/encoder.c:261-388) */
+static huf_error_t encode_locked(huf_encoder_t *enc)
+{
+    const uint64_t length = enc->config->length;
+    const uint64_t blocksize = enc->config->blocksize;
+    if (blocksize > HUFGPU_MAX_BLOCK) {
+        fprintf(stderr, "libhuffman: blocksize %llu exceeds the GPU kernel limit (%llu)\n",
+                (unsigned long long)blocksize, (unsigned long long)HUFGPU_MAX_BLOCK);
+        return HUF_ERROR_INVALID_ARGUMENT;
+    }
+    TRY(session_acquire());
+
+    const char *env = getenv("HUF_GPU_BATCH_MB");
+    uint64_t batch = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : 256) << 20;
+    if (batch < blocksize) batch = blocksize;
+    batch -= batch % blocksize;                   /* whole blocks per round */
+    if (batch > length) batch = length;
+
+    const uint64_t bound = hufgpu_encode_bound(batch, blocksize);
+    TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, batch));
+    TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, bound));
+    TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, batch));
+    TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound));
+
+    for (uint64_t done = 0; done < length;) {
+        const uint64_t take = (length - done < batch) ? length - done : batch;
+        /* one large read per round; a short read is an error exactly like the reference's
+         * block read (src/encoder.c:296, src/bufio.c:251-253) */
+        TRY(huf_bufio_read(enc->bufio_reader, g_stage.h_a, take));
+        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take));
+        uint64_t out_len = 0;
+        int rc = hufgpu_encode(g_ctx, g_stage.d_a, take, blocksize, g_stage.d_b, g_stage.d_b_cap, NULL, &out_len, NULL);
+        if (rc != HUF_ERROR_SUCCESS) return (huf_error_t)rc;
+        TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, out_len));
+        TRY(huf_bufio_write(enc->bufio_writer, g_stage.h_b, out_len));
+        done += take;
+    }
+    return huf_bufio_read_writer_flush(enc->bufio_writer);   /* encoder.c:377 */
+}
+
+huf_error_t huf_encode(const huf_config_t *config)
+{
+    GUARD(config);
+    huf_encoder_t *enc = NULL;
+    TRY(huf_encoder_init(&enc, config));
+    huf_error_t err = HUF_ERROR_SUCCESS;
+    if (enc->config->length) {                    /* length 0: nothing is read or written */
+        pthread_mutex_lock(&g_lock);
+        err = encode_locked(enc);
+        pthread_mutex_unlock(&g_lock);
+    }
+    huf_encoder_free(&enc);
+    return err;
+}
+
+/* ------------------------------------------------------------------ huf_decode (src/decoder.c:201-287) */
+static huf_error_t read_upto(huf_read_writer_t *rw, uint8_t *dst, size_t want, size_t *got)
+{
+    size_t total = 0;
+    while (total < want) {
+        size_t n = want - total;
+        TRY(rw->read(rw->stream, dst + total, &n));
+        if (!n) break;
+        total += n;
+    }
+    *got = total;
+    return HUF_ERROR_SUCCESS;
+}
+
+static huf_error_t decode_locked(huf_decoder_t *dec)
+{
+    const uint64_t length = dec->config->length;
+    TRY(session_acquire());
+    const uint32_t flags = relaxed_tree() ? HUFGPU_RELAXED_TREE : HUFGPU_STRICT_TREE;
+
+    /* The reference pulls bytes on demand and may run past `length` to finish the last block
+     * (src/decoder.c:218); here: take `length` bytes, and if the device reports that a block
+     * needs more input, ask the reader for more and decode again. */
+    size_t cap_in = (size_t)length + 4096;
+    TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, cap_in));
+    size_t avail = 0;
+    TRY(read_upto(dec->config->reader, (uint8_t *)g_stage.h_a, (size_t)length, &avail));
+
+    uint64_t out_cap = (uint64_t)avail * 8 + (1u << 20);
+    for (;;) {
+        TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, avail + 16));
+        TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, out_cap));
+        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, avail));
+        uint64_t raw = 0, used = 0;
+        int rc = hufgpu_decode_stream(g_ctx, g_stage.d_a, avail, length, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
+        if (rc == HUF_ERROR_MEMORY_ALLOCATION && out_cap < ((uint64_t)1 << 40)) {   /* output did not fit: enlarge */
+            out_cap *= 4;
+            continue;
+        }
+        if (rc == HUF_ERROR_READ_WRITE) {          /* maybe the reader has more than `length` */
+            size_t more_want = avail < 65536 ? 65536 : avail;
+            if (g_stage.h_a_cap < avail + more_want) {
+                void *bigger = NULL; size_t bigger_cap = 0;
+                TRY(grow_host(&bigger, &bigger_cap, avail + more_want));
+                memcpy(bigger, g_stage.h_a, avail);
+                (void)hipHostFree(g_stage.h_a);
+                g_stage.h_a = bigger; g_stage.h_a_cap = bigger_cap;
+            }
+            size_t more = 0;
+            TRY(read_upto(dec->config->reader, (uint8_t *)g_stage.h_a + avail, more_want, &more));
+            if (more) { avail += more; continue; }
+        }
+        /* bytes of the blocks that decoded completely are delivered even when a later block
+         * fails, as the reference's unbuffered writer would have done */
+        if (raw) {
+            TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, raw));
+            TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, raw));
+            TRY(huf_bufio_write(dec->bufio_writer, g_stage.h_b, raw));
+        }
+        if (rc != HUF_ERROR_SUCCESS) return (huf_error_t)rc;   /* no flush on the error path (decoder.c:278-286) */
+        return huf_bufio_read_writer_flush(dec->bufio_writer);
+    }
+}
+
+huf_error_t huf_decode(const huf_config_t *config)
+{
+    GUARD(config);
+    huf_decoder_t *dec = NULL;
+    TRY(huf_decoder_init(&dec, config));
+    huf_error_t err = HUF_ERROR_SUCCESS;
+    if (dec->config->length) {                    /* test/decode_test.c:32-36: empty input is fine */
+        pthread_mutex_lock(&g_lock);
+        err = decode_locked(dec);
+        pthread_mutex_unlock(&g_lock);
+    }
+    huf_decoder_free(&dec);
+    return err;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,478 @@
+/*
+ * hufgpu_api.hip - host side of the device-resident C ABI (include/huffman_gpu.h).
+ *
+ * Owns the per-device context (stream, workspace in HBM, pinned result words) and launches the
+ * kernels of hufgpu_kernels.hip.  No CPU implementation of the codec lives here: if HIP or a
+ * gfx950 device is unavailable every entry point fails with HUF_ERROR_FATAL and says why.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/huffman_gpu.h"
+#include "hufgpu_common.h"
+#include "hufgpu_kernels.hip"
+
+using namespace hufgpu;
+
+#define HIST_THREADS 256
+#define PACK_THREADS 256
+#define DEC_THREADS 256
+#define SCAN_THREADS 1024
+#define MAX_STAGES 8
+
+struct hufgpu_ctx {
+    int device;
+    hipStream_t stream;
+    char err[512];
+
+    /* encode workspace, sized for ws_blocks blocks */
+    uint64_t ws_blocks;
+    uint32_t *d_hist;
+    hufcode_t *d_codetab;
+    int16_t *d_treebuf;
+    HufBlockMeta *d_meta;
+    uint64_t *d_offsets;          /* used when the caller passes no index buffer */
+
+    /* decode workspace */
+    uint64_t dws_blocks;
+    HufDecodeMeta *d_dmeta;
+    uint64_t *d_out_offsets;
+    int32_t *d_status;
+
+    uint64_t *d_result;           /* 4 words: err, raw_len, failing block, spare */
+    uint64_t *h_result;           /* pinned mirror */
+    uint64_t *d_zipf;             /* 255 cumulative weights */
+
+    int profiling;
+    int n_stages;
+    hipEvent_t ev[MAX_STAGES + 1];
+    float stage_ms[MAX_STAGES];
+    int decode_pending;
+    hipStream_t last_stream;
+};
+
+static char g_err[512] = "";
+
+static void set_err(hufgpu_ctx *ctx, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof(g_err), "%s", buf);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    fprintf(stderr, "libhuffman(gpu): %s\n", buf);
+}
+
+#define HIP_OK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err((ctx), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                              \
+            return HUFE_FATAL;                                                              \
+        }                                                                                   \
+    } while (0)
+
+extern "C" int hufgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int usable = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    return usable;
+}
+
+extern "C" const char *hufgpu_last_error(const hufgpu_ctx_t *ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" uint64_t hufgpu_block_count(uint64_t n, uint64_t blocksize)
+{
+    if (n == 0) return 0;
+    if (blocksize == 0) blocksize = n;            /* src/encoder.c:163-165 */
+    return (n + blocksize - 1) / blocksize;
+}
+
+extern "C" uint64_t hufgpu_encode_bound(uint64_t n, uint64_t blocksize)
+{
+    /* per block: 10 + 2*1025 header; payload <= 9 bits per byte (an optimal prefix code never
+     * costs more than the 8-bit fixed code, plus the wrap-root bit), +1 byte of padding */
+    const uint64_t nb = hufgpu_block_count(n, blocksize);
+    return nb * (HUF_HEADER_FIXED + 2ull * HUF_TREE_MAX + 1) + (n * 9 + 7) / 8 + 16;
+}
+
+extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
+{
+    if (!out) return HUFE_ARGUMENT;
+    *out = NULL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_err(NULL, "no HIP device available (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return HUFE_FATAL;
+    }
+    if (device < 0 || device >= n) {
+        set_err(NULL, "device %d out of range (have %d)", device, n);
+        return HUFE_ARGUMENT;
+    }
+    hipDeviceProp_t prop;
+    HIP_OK(NULL, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(NULL, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+        return HUFE_FATAL;
+    }
+    hufgpu_ctx *ctx = (hufgpu_ctx *)calloc(1, sizeof(hufgpu_ctx));
+    if (!ctx) return HUFE_MEMORY;
+    ctx->device = device;
+    HIP_OK(NULL, hipSetDevice(device));
+    HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
+    HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i <= MAX_STAGES; i++) HIP_OK(ctx, hipEventCreate(&ctx->ev[i]));
+
+    /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
+    uint64_t cum[255], acc = 0;
+    for (int r = 1; r <= 255; r++) {
+        acc += (1ull << 32) / (uint64_t)r;
+        cum[r - 1] = acc;
+    }
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_zipf, sizeof(cum)));
+    HIP_OK(ctx, hipMemcpy(ctx->d_zipf, cum, sizeof(cum), hipMemcpyHostToDevice));
+    *out = ctx;
+    return HUFE_OK;
+}
+
+static void free_encode_ws(hufgpu_ctx *c)
+{
+    (void)hipFree(c->d_hist);
+    (void)hipFree(c->d_codetab);
+    (void)hipFree(c->d_treebuf);
+    (void)hipFree(c->d_meta);
+    (void)hipFree(c->d_offsets);
+    c->d_hist = NULL; c->d_codetab = NULL; c->d_treebuf = NULL; c->d_meta = NULL; c->d_offsets = NULL;
+    c->ws_blocks = 0;
+}
+
+static void free_decode_ws(hufgpu_ctx *c)
+{
+    (void)hipFree(c->d_dmeta);
+    (void)hipFree(c->d_out_offsets);
+    (void)hipFree(c->d_status);
+    c->d_dmeta = NULL; c->d_out_offsets = NULL; c->d_status = NULL;
+    c->dws_blocks = 0;
+}
+
+extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_encode_ws(ctx);
+    free_decode_ws(ctx);
+    (void)hipFree(ctx->d_result);
+    (void)hipFree(ctx->d_zipf);
+    (void)hipHostFree(ctx->h_result);
+    for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return HUFE_OK;
+}
+
+static int ensure_encode_ws(hufgpu_ctx *c, uint64_t nblocks)
+{
+    if (nblocks <= c->ws_blocks) return HUFE_OK;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    free_encode_ws(c);
+    const uint64_t cap = nblocks + nblocks / 8 + 16;
+    HIP_OK(c, hipMalloc((void **)&c->d_hist, cap * HUF_NSYM * sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_codetab, cap * HUF_NSYM * sizeof(hufcode_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_treebuf, cap * HUF_TREE_STRIDE * sizeof(int16_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_meta, cap * sizeof(HufBlockMeta)));
+    HIP_OK(c, hipMalloc((void **)&c->d_offsets, (cap + 1) * sizeof(uint64_t)));
+    c->ws_blocks = cap;
+    return HUFE_OK;
+}
+
+static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
+{
+    if (nblocks <= c->dws_blocks) return HUFE_OK;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    free_decode_ws(c);
+    const uint64_t cap = nblocks + nblocks / 8 + 16;
+    HIP_OK(c, hipMalloc((void **)&c->d_dmeta, cap * sizeof(HufDecodeMeta)));
+    HIP_OK(c, hipMalloc((void **)&c->d_out_offsets, (cap + 1) * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
+    c->dws_blocks = cap;
+    return HUFE_OK;
+}
+
+static inline hipStream_t pick_stream(hufgpu_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+#define STAGE_BEGIN(c, s)                                                    \
+    do {                                                                     \
+        (c)->n_stages = 0;                                                   \
+        if ((c)->profiling) HIP_OK((c), hipEventRecord((c)->ev[0], (s)));    \
+    } while (0)
+#define STAGE_MARK(c, s)                                                                    \
+    do {                                                                                    \
+        if ((c)->profiling && (c)->n_stages < MAX_STAGES) {                                 \
+            (c)->n_stages++;                                                                \
+            HIP_OK((c), hipEventRecord((c)->ev[(c)->n_stages], (s)));                       \
+        }                                                                                   \
+    } while (0)
+
+extern "C" int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    ctx->profiling = enabled ? 1 : 0;
+    ctx->n_stages = 0;
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_get_stage_ms(hufgpu_ctx_t *ctx, float *ms, int max_stages, int *n_stages)
+{
+    if (!ctx || !ms || !n_stages) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    int n = ctx->n_stages < max_stages ? ctx->n_stages : max_stages;
+    if (ctx->profiling && n > 0) {
+        HIP_OK(ctx, hipEventSynchronize(ctx->ev[ctx->n_stages]));
+        for (int i = 0; i < n; i++) HIP_OK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    } else {
+        n = 0;
+    }
+    *n_stages = n;
+    return HUFE_OK;
+}
+
+static int check_block_args(hufgpu_ctx *c, uint64_t n, uint64_t *blocksize)
+{
+    if (*blocksize == 0) *blocksize = n;
+    if (*blocksize > HUFGPU_MAX_BLOCK) {
+        set_err(c, "blocksize %llu exceeds the kernel limit of %llu bytes", (unsigned long long)*blocksize,
+                (unsigned long long)HUFGPU_MAX_BLOCK);
+        return HUFE_ARGUMENT;
+    }
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_histogram(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                                uint32_t *d_hist, void *stream)
+{
+    if (!ctx || (!d_in && n) || !d_hist) return HUFE_ARGUMENT;
+    if (n == 0) return HUFE_OK;
+    int rc = check_block_args(ctx, n, &blocksize);
+    if (rc) return rc;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t nb = hufgpu_block_count(n, blocksize);
+    hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>((const uint8_t *)d_in, n, blocksize, d_hist);
+    HIP_OK(ctx, hipGetLastError());
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                             void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
+                             uint64_t *out_len, void *stream)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (n == 0) {                                  /* src/encoder.c:288: nothing to do */
+        if (out_len) *out_len = 0;
+        return HUFE_OK;
+    }
+    if (!d_in || !d_out) return HUFE_ARGUMENT;
+    int rc = check_block_args(ctx, n, &blocksize);
+    if (rc) return rc;
+    if (out_cap < hufgpu_encode_bound(n, blocksize)) {
+        set_err(ctx, "output capacity %llu below hufgpu_encode_bound() = %llu", (unsigned long long)out_cap,
+                (unsigned long long)hufgpu_encode_bound(n, blocksize));
+        return HUFE_ARGUMENT;
+    }
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const uint64_t nb = hufgpu_block_count(n, blocksize);
+    if (nb > 0x7fffffffull) {
+        set_err(ctx, "too many blocks (%llu)", (unsigned long long)nb);
+        return HUFE_ARGUMENT;
+    }
+    rc = ensure_encode_ws(ctx, nb);
+    if (rc) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    uint64_t *offs = d_block_offsets ? d_block_offsets : ctx->d_offsets;
+    const uint8_t *in = (const uint8_t *)d_in;
+
+    STAGE_BEGIN(ctx, s);
+    hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
+    STAGE_MARK(ctx, s);
+    if (blocksize < (1ull << 22))
+        tree_kernel<uint32_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+    else
+        tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+    STAGE_MARK(ctx, s);
+    scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
+    STAGE_MARK(ctx, s);
+    pack_kernel<PACK_THREADS><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
+    STAGE_MARK(ctx, s);
+    HIP_OK(ctx, hipGetLastError());
+
+    if (out_len) {
+        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, offs + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipStreamSynchronize(s));
+        *out_len = ctx->h_result[0];
+    }
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->decode_pending) {
+        if (raw_len) *raw_len = 0;
+        return HUFE_OK;
+    }
+    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->last_stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
+    ctx->decode_pending = 0;
+    if (raw_len) *raw_len = ctx->h_result[1];
+    const int err = (int)ctx->h_result[0];
+    if (err == HUFE_ARGUMENT) set_err(ctx, "block %llu is longer than the kernels support", (unsigned long long)ctx->h_result[2]);
+    if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small (block %llu)", (unsigned long long)ctx->h_result[2]);
+    return err;
+}
+
+extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                             const uint64_t *d_block_offsets, uint64_t nblocks, void *d_out,
+                             uint64_t out_cap, uint32_t flags, uint64_t *raw_len, void *stream)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (nblocks == 0 || stream_len == 0) {         /* src/decoder.c:218, test/decode_test.c:32-36 */
+        ctx->decode_pending = 0;
+        if (raw_len) *raw_len = 0;
+        return HUFE_OK;
+    }
+    if (!d_stream || !d_block_offsets || (!d_out && out_cap)) return HUFE_ARGUMENT;
+    if (nblocks > 0x7fffffffull) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_decode_ws(ctx, nblocks);
+    if (rc) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
+    const uint8_t *st = (const uint8_t *)d_stream;
+
+    STAGE_BEGIN(ctx, s);
+    decode_prepare_kernel<<<dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta);
+    STAGE_MARK(ctx, s);
+    scan_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_dmeta, nblocks, ctx->d_out_offsets);
+    STAGE_MARK(ctx, s);
+    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, (uint8_t *)d_out, out_cap, ctx->d_status);
+    STAGE_MARK(ctx, s);
+    decode_status_kernel<256><<<dim3(1), dim3(256), 0, s>>>(ctx->d_status, ctx->d_out_offsets, nblocks, ctx->d_result);
+    HIP_OK(ctx, hipGetLastError());
+    ctx->decode_pending = 1;
+    ctx->last_stream = s;
+    if (raw_len) return hufgpu_decode_result(ctx, raw_len);
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
+                                    void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
+                                    uint64_t *consumed, void *stream)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (raw_len) *raw_len = 0;
+    if (consumed) *consumed = 0;
+    if (length == 0) return HUFE_OK;                  /* src/decoder.c:218 */
+    if ((!d_stream && avail) || (!d_out && out_cap)) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
+    STAGE_BEGIN(ctx, s);
+    decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_stream, avail, length, max_tree,
+                                                                        (uint8_t *)d_out, out_cap, ctx->d_result, NULL, 0);
+    STAGE_MARK(ctx, s);
+    HIP_OK(ctx, hipGetLastError());
+    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipStreamSynchronize(s));
+    if (raw_len) *raw_len = ctx->h_result[1];
+    if (consumed) *consumed = ctx->h_result[2];
+    const int err = (int)ctx->h_result[0];
+    if (err == HUFE_ARGUMENT) set_err(ctx, "a block is longer than the kernels support");
+    if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small");
+    return err;
+}
+
+extern "C" int hufgpu_fill(hufgpu_ctx_t *ctx, void *d_out, uint64_t n, int kind, uint64_t seed,
+                           uint64_t first, void *stream)
+{
+    if (!ctx || (!d_out && n) || kind < 0 || kind > 3) return HUFE_ARGUMENT;
+    if (n == 0) return HUFE_OK;
+    if (kind == 1 && (first & 7)) {
+        set_err(ctx, "uniform256 shards must start on an 8-byte boundary");
+        return HUFE_ARGUMENT;
+    }
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    fill_kernel<<<dim3(4096), dim3(256), 0, s>>>((uint8_t *)d_out, n, kind, seed, first, ctx->d_zipf);
+    HIP_OK(ctx, hipGetLastError());
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_malloc(hufgpu_ctx_t *ctx, void **d_ptr, uint64_t bytes)
+{
+    if (!ctx || !d_ptr) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_err(ctx, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return HUFE_MEMORY;
+    }
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_free(hufgpu_ctx_t *ctx, void *d_ptr)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipFree(d_ptr));
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_memcpy_h2d(hufgpu_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (!bytes) return HUFE_OK;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (!bytes) return HUFE_OK;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return HUFE_OK;
+}
+
+extern "C" int hufgpu_synchronize(hufgpu_ctx_t *ctx)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return HUFE_OK;
+}

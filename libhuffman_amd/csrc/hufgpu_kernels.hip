@@ -1,0 +1,1074 @@
+/*
+ * hufgpu_kernels.hip - CDNA4 (gfx950) kernels of the Huffman block codec.
+ *
+ * One libhuffman block (config->blocksize input bytes, src/encoder.c:288-293) is the unit of
+ * parallelism everywhere: blocks never exchange data, so every kernel maps blocks to
+ * workgroups and the grid is simply the block count.
+ *
+ *   encode:  hist256_kernel  ->  tree_kernel  ->  scan_sizes_kernel  ->  pack_kernel
+ *   decode:  decode_prepare_kernel -> scan_lens_kernel -> decode_kernel -> decode_status_kernel
+ *            (block index known), or decode_chain_kernel (raw stream, blocks in order)
+ *
+ * Wave size is 64 throughout (hard-coded, gfx950 only).  All arithmetic is integer.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hufgpu_common.h"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * small helpers
+ * ==================================================================================== */
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+template <typename T>
+__device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
+template <typename T>
+__device__ __forceinline__ T dmax(T a, T b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_xor((int)lo, mask);
+    hi = (uint32_t)__shfl_xor((int)hi, mask);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t shfl_xor_key(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask); }
+__device__ __forceinline__ uint64_t shfl_xor_key(uint64_t v, int mask) { return shfl_xor_u64(v, mask); }
+
+/* Exclusive prefix sum over the workgroup (THREADS a multiple of 64). s_part needs THREADS/64
+ * words. Returns this thread's exclusive prefix; `total` is the workgroup sum. */
+template <int THREADS, typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *s_part, T &total)
+{
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t;
+        if constexpr (sizeof(T) == 8) {
+            uint32_t lo = (uint32_t)inc, hi = (uint32_t)((uint64_t)inc >> 32);
+            lo = (uint32_t)__shfl_up((int)lo, o);
+            hi = (uint32_t)__shfl_up((int)hi, o);
+            t = (T)(((uint64_t)hi << 32) | lo);
+        } else {
+            t = (T)__shfl_up((int)inc, o);
+        }
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) {
+        T x = s_part[i];
+        if (i < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+/* ======================================================================================
+ * hist256 - replaces huf_histogram_populate (src/histogram.c:73-103, iota = 1).
+ *
+ * One workgroup per block; every wavefront owns a private 256-bin histogram in LDS so that
+ * LDS atomics of different waves never collide; the wave copies are summed at the end.
+ * Each lane reads 16 contiguous bytes per step (a wave reads 1 KiB, fully coalesced).
+ * Runs of one byte value are folded before touching LDS: a 16-byte chunk of one value costs
+ * one atomic, and a whole wave-step of one value costs one atomic for the wave - that is the
+ * common case on BASELINE config 2 (all 0x41), where per-byte atomics would serialise 64-way.
+ * ==================================================================================== */
+__device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w)
+{
+    atomicAdd(&h[w & 0xffu], 1u);
+    atomicAdd(&h[(w >> 8) & 0xffu], 1u);
+    atomicAdd(&h[(w >> 16) & 0xffu], 1u);
+    atomicAdd(&h[w >> 24], 1u);
+}
+
+__device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v)
+{
+    const uint32_t b = v.x & 0xffu;
+    const uint32_t rep = b * 0x01010101u;
+    const bool uni = (v.x == rep) & (v.y == rep) & (v.z == rep) & (v.w == rep);
+    const unsigned long long act = __ballot(1);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    const unsigned long long same = __ballot(uni && b == b0);
+    if (same == act) {                       /* the whole wave step holds one byte value */
+        if ((unsigned)lane_id() == (unsigned)__builtin_ctzll(act))
+            atomicAdd(&h[b0], 16u * (uint32_t)__popcll(act));
+        return;
+    }
+    if (uni) {
+        atomicAdd(&h[b], 16u);
+        return;
+    }
+    hist_add_bytes(h, v.x);
+    hist_add_bytes(h, v.y);
+    hist_add_bytes(h, v.z);
+    hist_add_bytes(h, v.w);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void hist256_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                          uint64_t blocksize, uint32_t *__restrict__ hist)
+{
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t s_hist[WAVES * HUF_NSYM];
+
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    const int tid = (int)threadIdx.x;
+
+    for (int i = tid; i < WAVES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
+    __syncthreads();
+
+    uint32_t *mine = s_hist + (tid >> 6) * HUF_NSYM;
+    const uint8_t *p = in + base;
+    const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
+    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
+
+    const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
+    const uint64_t nvec = (len - head) >> 4;
+    for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
+
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
+    __syncthreads();
+
+    for (int b = tid; b < HUF_NSYM; b += THREADS) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += s_hist[w * HUF_NSYM + b];
+        hist[blk * HUF_NSYM + b] = s;
+    }
+}
+
+/* ======================================================================================
+ * tree_kernel - replaces huf_tree_from_histogram (src/tree.c:292-427), the code walk
+ * (src/tree.c:12-47 + src/encoder.c:40-81) and huf_tree_serialize (src/tree.c:233-289).
+ *
+ * One wavefront per block.  The 512 rate slots live in registers, 8 per lane (slot = lane +
+ * 64*j).  A slot's sort key is (rate << 9) | (511 - slot): the plain minimum of the keys is
+ * the reference's selection order "rate ascending, index descending" (tree.c:329-352), and
+ * keys are unique.  Each round reduces the two smallest keys across the wave, makes the
+ * smaller one the left child and the other the right child of the new node (tree.c:390-408),
+ * and stops on the round that finds a single survivor, which becomes the left-only wrap root
+ * (tree.c:410-413).  K = uint32_t serves blocks shorter than 2^22 bytes, uint64_t the rest.
+ *
+ * Then, level by level from the root: code bits, depth and the preorder position of every
+ * node (position of a right child = parent + 1 + entries of the left subtree, a subtree with
+ * L leaves holding 4L-1 entries), which gives codes and the serialized tree without recursion.
+ * ==================================================================================== */
+template <typename K>
+__global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ hist, uint64_t n,
+                                                  uint64_t blocksize, hufcode_t *__restrict__ codetab,
+                                                  int16_t *__restrict__ treebuf,
+                                                  HufBlockMeta *__restrict__ meta)
+{
+    __shared__ int16_t s_left[HUF_NSLOT];
+    __shared__ int16_t s_right[HUF_NSLOT];
+    __shared__ uint16_t s_leaves[HUF_NSLOT];  /* leaves below each slot */
+    __shared__ uint16_t s_depth[HUF_NSLOT];   /* 0xffff = not reached */
+    __shared__ uint16_t s_pos[HUF_NSLOT];     /* preorder position */
+    __shared__ uint64_t s_code[HUF_NSLOT];
+    __shared__ int16_t s_tree[HUF_TREE_STRIDE];
+
+    const K KMAX = ~(K)0;
+    const int lane = lane_id();
+    const uint64_t blk = blockIdx.x;
+    const uint32_t *h = hist + blk * HUF_NSYM;
+
+    K key[8];
+    uint32_t rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        rate[j] = h[slot];
+        key[j] = rate[j] ? (((K)rate[j] << 9) | (K)(511 - slot)) : KMAX;
+    }
+#pragma unroll
+    for (int j = 4; j < 8; j++) key[j] = KMAX;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int slot = lane + 64 * j;
+        s_left[slot] = -1;
+        s_right[slot] = -1;
+        s_leaves[slot] = (j < 4 && rate[j & 3]) ? 1 : 0;
+        s_depth[slot] = 0xffffu;
+    }
+    __syncthreads();
+
+    int node = HUF_NSYM;
+    int root = -1;
+    for (;;) {
+        K a = KMAX, b = KMAX;              /* two smallest keys of this lane */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const K k = key[j];
+            const K t = dmax(a, k);
+            a = dmin(a, k);
+            b = dmin(b, t);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {  /* butterfly: disjoint lane groups, unique keys */
+            const K oa = shfl_xor_key(a, o);
+            const K ob = shfl_xor_key(b, o);
+            const K t = dmax(a, oa);
+            a = dmin(a, oa);
+            b = dmin(dmin(b, ob), t);
+        }
+        if (a == KMAX) {                   /* tree.c:355-358 (only for an empty histogram) */
+            root = node - 1;
+            break;
+        }
+        const int i1 = 511 - (int)(a & (K)511);
+        if (b == KMAX) {                   /* tree.c:410-413: single survivor -> left-only root */
+            if (lane == 0) {
+                s_left[node] = (int16_t)i1;
+                s_right[node] = -1;
+                s_leaves[node] = s_leaves[i1];
+            }
+            root = node;
+            node++;
+            break;
+        }
+        const int i2 = 511 - (int)(b & (K)511);
+        const K sum = (a >> 9) + (b >> 9);  /* tree.c:407 */
+        const K nk = (sum << 9) | (K)(511 - node);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int slot = lane + 64 * j;
+            if (slot == i1 || slot == i2) key[j] = KMAX;   /* tree.c:396,403 */
+            if (slot == node) key[j] = nk;
+        }
+        if (lane == 0) {
+            s_left[node] = (int16_t)i1;
+            s_right[node] = (int16_t)i2;
+            s_leaves[node] = (uint16_t)(s_leaves[i1] + s_leaves[i2]);
+        }
+        node++;
+    }
+    __syncthreads();
+
+    const int nodes = node;
+    const int nleaves = (root >= 0) ? (int)s_leaves[root] : 0;
+    const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
+
+    for (int i = lane; i < HUF_TREE_STRIDE; i += 64) s_tree[i] = -1;
+    if (lane == 0 && root >= 0) {
+        s_depth[root] = 0;
+        s_code[root] = 0;
+        s_pos[root] = 0;
+    }
+    __syncthreads();
+
+    for (int d = 0; d < HUF_NSLOT; d++) {
+        bool any = false;
+#pragma unroll
+        for (int j = 4; j < 8; j++) {
+            const int slot = lane + 64 * j;
+            if (slot < nodes && s_depth[slot] == (uint16_t)d) {
+                any = true;
+                const int l = s_left[slot], r = s_right[slot];
+                const uint64_t c = s_code[slot];
+                const int p = s_pos[slot];
+                s_tree[p] = (int16_t)slot;
+                s_depth[l] = (uint16_t)(d + 1);
+                s_code[l] = c << 1;
+                s_pos[l] = (uint16_t)(p + 1);
+                if (l < HUF_NSYM) s_tree[p + 1] = (int16_t)l;
+                if (r >= 0) {
+                    const int pr = p + 1 + 4 * (int)s_leaves[l] - 1;
+                    s_depth[r] = (uint16_t)(d + 1);
+                    s_code[r] = (c << 1) | 1u;
+                    s_pos[r] = (uint16_t)pr;
+                    if (r < HUF_NSYM) s_tree[pr] = (int16_t)r;
+                }
+            }
+        }
+        __syncthreads();
+        if (!__any(any)) break;
+    }
+
+    uint64_t bits = 0;
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        hufcode_t e = 0;
+        if (rate[j]) {
+            const uint32_t len = s_depth[slot];
+            e = (s_code[slot] << 8) | (hufcode_t)len;
+            bits += (uint64_t)rate[j] * len;
+            maxlen = dmax(maxlen, len);
+        }
+        codetab[blk * HUF_NSYM + slot] = e;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        bits += shfl_xor_u64(bits, o);
+        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    }
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
+    if (lane == 0) {
+        HufBlockMeta m;
+        m.tree_len = (uint32_t)tree_len;
+        m.max_len = maxlen;
+        m.payload_bits = bits;
+        meta[blk] = m;
+    }
+    (void)n;
+    (void)blocksize;
+}
+
+/* ======================================================================================
+ * scan_sizes_kernel - byte offset of every block header in the output stream.
+ * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
+ * Single workgroup; offsets[nblocks] = stream length.
+ * ==================================================================================== */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta *__restrict__ meta,
+                                                             uint64_t nblocks, uint64_t *__restrict__ offsets)
+{
+    __shared__ uint64_t s_part[THREADS / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nblocks; base += THREADS) {
+        const uint64_t i = base + threadIdx.x;
+        uint64_t v = 0;
+        if (i < nblocks) {
+            const HufBlockMeta m = meta[i];
+            v = HUF_HEADER_FIXED + 2ull * m.tree_len + ((m.payload_bits + 7) >> 3);
+        }
+        uint64_t total;
+        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(v, s_part, total);
+        if (i < nblocks) offsets[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) offsets[nblocks] = carry;
+}
+
+/* ======================================================================================
+ * pack_kernel - replaces the header emission (src/encoder.c:322-339) and __huf_encode_block
+ * + huf_bit_write (src/encoder.c:85-131, src/bufio.c:18-23).
+ *
+ * One workgroup per block.  The block record [u64 len][i16 tree_len][tree][payload] is built
+ * in an LDS image of big-endian 32-bit words whose word 0 is the 4-byte-aligned global word
+ * that contains the record's first byte, so bit b of the stream (MSB first inside each byte)
+ * is simply bit 31-(b&31) of word b>>5, and a finished word is byte-swapped and stored.
+ *
+ * Payload tiles of THREADS*16 symbols: every lane loads 16 contiguous input bytes, looks the
+ * codes up in the LDS table, the workgroup prefix-sums the per-lane bit counts, and each
+ * lane shifts its codes into a 64-bit accumulator and writes whole words: plain LDS stores
+ * for words it owns entirely, atomic OR for its first and last word, which it may share
+ * with a neighbour.  Finished words are flushed to HBM coalesced; the partial last word is
+ * carried into the next tile.  First/last word of the record are byte-masked because the
+ * neighbouring blocks (other workgroups) own the rest of those words.
+ * ==================================================================================== */
+#define PACK_SYMS_PER_LANE 16
+
+struct PackImage {
+    uint32_t *words;      /* LDS image */
+    uint64_t  win_word;   /* absolute word index (relative to A0) of words[0] */
+};
+
+template <int THREADS>
+__device__ __forceinline__ void pack_flush(uint32_t *s_img, uint32_t nwords, uint64_t win_word,
+                                           uint8_t *__restrict__ g_a0, uint64_t rec_lo, uint64_t rec_hi)
+{
+    /* words [0, nwords) of the image are complete; byte range of the record relative to A0
+     * is [rec_lo, rec_hi): only those bytes may be written. */
+    for (uint32_t i = threadIdx.x; i < nwords; i += THREADS) {
+        const uint64_t byte0 = (win_word + i) << 2;
+        const uint32_t w = s_img[i];
+        if (byte0 >= rec_lo && byte0 + 4 <= rec_hi) {
+            *reinterpret_cast<uint32_t *>(g_a0 + byte0) = __builtin_bswap32(w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t bp = byte0 + k;
+                if (bp >= rec_lo && bp < rec_hi) g_a0[bp] = (uint8_t)(w >> (24 - 8 * k));
+            }
+        }
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                       uint64_t blocksize,
+                                                       const hufcode_t *__restrict__ codetab,
+                                                       const int16_t *__restrict__ treebuf,
+                                                       const HufBlockMeta *__restrict__ meta,
+                                                       const uint64_t *__restrict__ offsets,
+                                                       uint8_t *__restrict__ out)
+{
+    constexpr int TILE = THREADS * PACK_SYMS_PER_LANE;
+    /* worst case per tile: TILE symbols of HUF_CODE_MAXBITS bits, + header tile, + carry */
+    constexpr int IMG_WORDS = TILE * HUF_CODE_MAXBITS / 32 + 8;
+    static_assert(IMG_WORDS * 4 >= HUF_HEADER_FIXED + 2 * HUF_TREE_MAX + 16, "header must fit");
+    __shared__ uint32_t s_img[IMG_WORDS];
+    __shared__ hufcode_t s_code[HUF_NSYM];
+    __shared__ uint32_t s_part[THREADS / 64];
+
+    const int tid = (int)threadIdx.x;
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    const HufBlockMeta m = meta[blk];
+    const uint64_t dst0 = offsets[blk];
+    const uint64_t dst1 = offsets[blk + 1];
+
+    uint8_t *g_a0 = out + (dst0 & ~3ull);
+    const uint64_t rec_lo = dst0 & 3ull;                  /* record bytes relative to A0 */
+    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
+
+    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = codetab[blk * HUF_NSYM + i];
+    for (int i = tid; i < IMG_WORDS; i += THREADS) s_img[i] = 0;
+    __syncthreads();
+
+    /* ---- header (encoder.c:325-339): little-endian fields, placed bytewise ---- */
+    const uint32_t hdr_bytes = HUF_HEADER_FIXED + 2u * m.tree_len;
+    const int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    for (uint32_t j = tid; j < hdr_bytes; j += THREADS) {
+        uint32_t byte;
+        if (j < 8) byte = (uint32_t)(len >> (8 * j)) & 0xffu;
+        else if (j < 10) byte = (m.tree_len >> (8 * (j - 8))) & 0xffu;
+        else {
+            const uint16_t e = (uint16_t)tb[(j - 10) >> 1];
+            byte = (e >> (8 * (j & 1))) & 0xffu;
+        }
+        const uint32_t bp = (uint32_t)rec_lo + j;
+        atomicOr(&s_img[bp >> 2], byte << (24 - 8 * (bp & 3)));
+    }
+    __syncthreads();
+
+    uint64_t bitpos = (rec_lo + hdr_bytes) * 8ull;        /* absolute, relative to A0 bit 0 */
+    uint64_t win_word = 0;
+    {
+        const uint32_t done = (uint32_t)(bitpos >> 5);
+        pack_flush<THREADS>(s_img, done, win_word, g_a0, rec_lo, rec_hi);
+        __syncthreads();
+        const uint32_t carry = s_img[done];
+        __syncthreads();
+        for (uint32_t i = tid; i <= done; i += THREADS) s_img[i] = 0;
+        __syncthreads();
+        if (tid == 0) s_img[0] = carry;
+        win_word = done;
+        __syncthreads();
+    }
+
+    /* ---- payload tiles ---- */
+    const uint8_t *src = in + base;
+    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
+        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SYMS_PER_LANE;
+        uint32_t nsym = 0;
+        uint8_t sym[PACK_SYMS_PER_LANE];
+        if (my0 < len) {
+            nsym = (uint32_t)dmin<uint64_t>(PACK_SYMS_PER_LANE, len - my0);
+            const uint8_t *p = src + my0;
+            if (nsym == PACK_SYMS_PER_LANE && (((uintptr_t)p) & 15u) == 0) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(p);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) sym[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            } else {
+#pragma unroll
+                for (int k = 0; k < PACK_SYMS_PER_LANE; k++) sym[k] = (k < (int)nsym) ? p[k] : 0;
+            }
+        }
+        hufcode_t code[PACK_SYMS_PER_LANE];
+        uint32_t mybits = 0;
+#pragma unroll
+        for (int k = 0; k < PACK_SYMS_PER_LANE; k++) {
+            code[k] = (k < (int)nsym) ? s_code[sym[k]] : 0;
+            mybits += (uint32_t)(code[k] & 0xffu);
+        }
+        uint32_t tile_bits;
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
+
+        /* emit this lane's bits */
+        if (mybits) {
+            const uint64_t rel = bitpos + ex - (win_word << 5);   /* bit index inside the image */
+            uint32_t w = (uint32_t)(rel >> 5);
+            uint32_t nacc = (uint32_t)(rel & 31);                 /* bits already used in word w */
+            uint64_t acc = 0;                                     /* left-aligned pending bits */
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < PACK_SYMS_PER_LANE; k++) {
+                uint32_t l = (uint32_t)(code[k] & 0xffu);
+                uint64_t c = code[k] >> 8;
+                if (l > 32) {                                     /* long code: high part first */
+                    const uint32_t lh = l - 32;
+                    acc |= (c >> 32) << (64 - nacc - lh);
+                    nacc += lh;
+                    if (nacc >= 32) {
+                        const uint32_t word = (uint32_t)(acc >> 32);
+                        if (first) { atomicOr(&s_img[w], word); first = false; }
+                        else s_img[w] = word;
+                        w++; acc <<= 32; nacc -= 32;
+                    }
+                    c &= 0xffffffffull;
+                    l = 32;
+                }
+                if (l) {
+                    acc |= c << (64 - nacc - l);
+                    nacc += l;
+                    if (nacc >= 32) {
+                        const uint32_t word = (uint32_t)(acc >> 32);
+                        if (first) { atomicOr(&s_img[w], word); first = false; }
+                        else s_img[w] = word;
+                        w++; acc <<= 32; nacc -= 32;
+                    }
+                }
+            }
+            if (nacc) atomicOr(&s_img[w], (uint32_t)(acc >> 32));
+        }
+        __syncthreads();
+
+        bitpos += tile_bits;
+        const uint32_t done = (uint32_t)((bitpos >> 5) - win_word);
+        pack_flush<THREADS>(s_img, done, win_word, g_a0, rec_lo, rec_hi);
+        __syncthreads();
+        const uint32_t carry = s_img[done];
+        __syncthreads();
+        for (uint32_t i = tid; i <= done; i += THREADS) s_img[i] = 0;
+        __syncthreads();
+        if (tid == 0) s_img[0] = carry;
+        win_word += done;
+        __syncthreads();
+    }
+
+    /* final partial word: zero-padded tail byte(s) (encoder.c:123-128) */
+    if (bitpos & 31) pack_flush<THREADS>(s_img, 1, win_word, g_a0, rec_lo, rec_hi);
+}
+
+/* ======================================================================================
+ * decode_prepare_kernel - header parse of src/decoder.c:218-252 for every indexed block.
+ * ==================================================================================== */
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
+{
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v |= (uint64_t)p[k] << (8 * k);
+    return v;
+}
+
+__global__ void decode_prepare_kernel(const uint8_t *__restrict__ stream, uint64_t stream_len,
+                                      const uint64_t *__restrict__ offsets, uint64_t nblocks,
+                                      int max_tree_len, HufDecodeMeta *__restrict__ dmeta)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t o0 = offsets[b];
+    const uint64_t o1 = dmin<uint64_t>(offsets[b + 1], stream_len);
+    HufDecodeMeta m;
+    m.block_len = 0;
+    m.tree_len = 0;
+    m.status = HUFE_OK;
+    if (o0 > o1 || o1 - o0 < HUF_HEADER_FIXED) {
+        m.status = HUFE_RW;                                /* decoder.c:220-234 short read */
+    } else {
+        const uint64_t bl = load_u64_unaligned(stream + o0);
+        const int16_t tl = (int16_t)((uint16_t)stream[o0 + 8] | ((uint16_t)stream[o0 + 9] << 8));
+        if (tl < 0 || tl > max_tree_len) m.status = HUFE_OVERFLOW;          /* decoder.c:237-239 */
+        else if (o1 - o0 < HUF_HEADER_FIXED + 2ull * (uint64_t)tl) m.status = HUFE_RW;   /* :248-252 */
+        else if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;              /* beyond kernel limits */
+        else {
+            m.block_len = bl;
+            m.tree_len = tl;
+        }
+    }
+    dmeta[b] = m;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta *__restrict__ dmeta,
+                                                            uint64_t nblocks, uint64_t *__restrict__ out_offsets)
+{
+    __shared__ uint64_t s_part[THREADS / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nblocks; base += THREADS) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = (i < nblocks) ? dmeta[i].block_len : 0;
+        uint64_t total;
+        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(v, s_part, total);
+        if (i < nblocks) out_offsets[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) out_offsets[nblocks] = carry;
+}
+
+/* ======================================================================================
+ * decode_kernel - replaces huf_tree_deserialize (src/tree.c:138-227) and __huf_decode_block
+ * (src/decoder.c:34-96).
+ *
+ * One workgroup per block.
+ *  1. The serialized tree is turned into child arrays in parallel.  With S(i) = number of
+ *     open child slots before entry i (S(0) = 1, +1 after a node entry, -1 after a -1
+ *     marker), entry j+1 is the left child of node j and the first later entry with the same
+ *     S as j is its right child; entries after S reaches 0, or past the buffer, do not exist
+ *     (tree.c:152-160: a missing entry is a NULL child).
+ *  2. A 2^LUT_BITS-entry table in LDS maps the next LUT_BITS stream bits to {leaf, length},
+ *     {inner node to continue the bit walk from} or {walk left the tree}.
+ *  3. The payload is processed in segments of THREADS x SUB_BITS bits staged in LDS as
+ *     big-endian words.  Every lane decodes one SUB_BITS subsequence.  Only the first lane
+ *     knows where its first codeword starts; the others start at their subsequence boundary,
+ *     then repeatedly restart from the end position their left neighbour reported until no
+ *     start changes any more (self-synchronisation; worst case one lane per round, always
+ *     exact).  Symbol counts are prefix-summed, the symbols are decoded once more into an LDS
+ *     byte image aligned with the destination and stored coalesced.  Exactly block_len
+ *     symbols are produced; pad bits are ignored (decoder.c:89-91).
+ * ==================================================================================== */
+#define DEC_LUT_BITS 12
+#define DEC_SUB_BITS 128
+#define DEC_NULL 0xffffu
+#define DEC_EXTRA_WORDS 40            /* > (1025 + LUT_BITS)/32: deepest possible bit walk */
+
+struct DecTree {
+    const uint16_t *left;
+    const uint16_t *right;
+    const int16_t *val;
+    const uint16_t *lut;
+    const uint32_t *pay;              /* staged segment, big-endian words */
+    uint64_t seg_bit0;                /* absolute payload bit of pay[0] bit 31 */
+    uint64_t pay_bits;                /* readable payload bits */
+};
+
+#define DEC_POS_EXHAUSTED (~0ull >> 1)   /* "a codeword ran past the readable payload" */
+
+__device__ __forceinline__ uint32_t dec_window(const DecTree &t, uint64_t pos)
+{
+    const uint32_t rel = (uint32_t)(pos - t.seg_bit0);
+    const uint32_t w = rel >> 5, sh = rel & 31u;
+    const uint32_t hi = t.pay[w], lo = t.pay[w + 1];
+    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
+}
+
+/* Decode the codewords that start in [start, limit).  Returns the position of the first
+ * codeword at or after limit (DEC_POS_EXHAUSTED if a codeword needs bits past the payload:
+ * the reference would fail its next byte read there, src/decoder.c:53-56).
+ *   WRITE = false: count only; a walk that leaves the tree skips one bit (this only ever
+ *           happens on a speculative, not yet synchronised start).
+ *   WRITE = true : store at most omax symbols to s_out[obase..] and stop after them; a walk
+ *           that leaves the tree sets bad and stops (src/decoder.c:69-71). */
+template <bool WRITE>
+__device__ __forceinline__ uint64_t dec_span(const DecTree &t, uint64_t start, uint64_t limit,
+                                             uint32_t &cnt, uint8_t *s_out, uint32_t obase,
+                                             uint32_t omax, bool &bad)
+{
+    uint64_t pos = start;
+    uint32_t c = 0;
+    bad = false;
+    while (pos < limit) {
+        if (WRITE && c >= omax) break;
+        const uint32_t win = dec_window(t, pos);
+        const uint32_t e = t.lut[win >> (32 - DEC_LUT_BITS)];
+        const uint32_t type = e >> 14;
+        uint64_t npos;
+        uint32_t symv;
+        bool ok = true;
+        if (type == 0) {
+            symv = e & 0xffu;
+            npos = pos + ((e >> 8) & 0xfu);
+        } else if (type == 1) {
+            uint32_t node = e & 0x7ffu;
+            uint64_t p = pos + DEC_LUT_BITS;
+            for (;;) {
+                if (p >= t.pay_bits) { p = t.pay_bits + 1; break; }   /* forces "exhausted" below */
+                const uint32_t bit = dec_window(t, p) >> 31;
+                p++;
+                const uint32_t nx = bit ? t.right[node] : t.left[node];
+                if (nx == DEC_NULL) { ok = false; break; }
+                node = nx;
+                if (t.left[node] == DEC_NULL && t.right[node] == DEC_NULL) break;
+            }
+            symv = (uint32_t)(uint8_t)t.val[node];
+            npos = p;
+        } else {
+            ok = false;
+            symv = 0;
+            npos = pos + ((e >> 8) & 0xfu);            /* bits read up to the missing child */
+        }
+        if (!ok) {
+            /* the failing bit must be a real payload bit for the failure to be real; otherwise
+             * the reference would have failed its byte read first (src/decoder.c:53-56) */
+            if (npos > t.pay_bits) { pos = DEC_POS_EXHAUSTED; break; }
+            if (WRITE) { bad = true; break; }
+            pos += 1;
+            continue;
+        }
+        if (npos > t.pay_bits) { pos = DEC_POS_EXHAUSTED; break; }
+        if (WRITE) s_out[obase + c] = (uint8_t)symv;
+        pos = npos;
+        c++;
+    }
+    cnt = c;
+    return pos;
+}
+
+/* big-endian 32-bit word of payload bytes [off, off+4), zero beyond nbytes */
+__device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, uint64_t nbytes)
+{
+    if (off >= nbytes) return 0;
+    const uint64_t remain = nbytes - off;
+    const uintptr_t a = (uintptr_t)(pay + off);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t m = (uint32_t)(a & 3u);
+    uint32_t v = q[0];
+    if (m) {
+        const uint32_t hi = (remain > 4u - m) ? q[1] : 0u;
+        v = (v >> (8 * m)) | (hi << (32 - 8 * m));
+    }
+    v = __builtin_bswap32(v);
+    if (remain < 4) v &= 0xffffffffu << (8 * (4 - (uint32_t)remain));
+    return v;
+}
+
+template <int THREADS>
+struct DecShared {
+    static constexpr int SEG_WORDS = THREADS * DEC_SUB_BITS / 32;
+    static constexpr int ENT = HUF_TREE_STRIDE;
+    static constexpr int OUT_BYTES = THREADS * DEC_SUB_BITS + 32;   /* 1-bit codes: a symbol per bit */
+    int16_t ent[ENT];
+    uint16_t open[ENT];        /* S(i) */
+    uint16_t left[ENT];
+    uint16_t right[ENT];
+    uint16_t lut[1 << DEC_LUT_BITS];
+    uint32_t pay[SEG_WORDS + DEC_EXTRA_WORDS];
+    uint64_t end[THREADS];
+    uint32_t part[THREADS / 64];
+    int efflen;
+    int flag;
+    uint64_t qend;             /* payload bit right after the block's last symbol */
+    __attribute__((aligned(16))) uint8_t out[OUT_BYTES];
+};
+
+/* Decode one block whose header has been parsed.  `tree` points at the tree_len int16 entries,
+ * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
+ * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
+ * symbol (valid on success). */
+template <int THREADS>
+__device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
+                            uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits)
+{
+    constexpr int SEG_WORDS = DecShared<THREADS>::SEG_WORDS;
+    constexpr int ENT = DecShared<THREADS>::ENT;
+    const int tid = (int)threadIdx.x;
+
+    /* ---- 1. tree ---- */
+    __syncthreads();           /* previous user of sh is done */
+    for (int i = tid; i < ENT; i += THREADS) {
+        int16_t v = -1;
+        if (i < tree_len) v = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
+        sh.ent[i] = v;
+        sh.left[i] = DEC_NULL;
+        sh.right[i] = DEC_NULL;
+    }
+    if (tid == 0) { sh.efflen = tree_len; sh.flag = 0; sh.qend = 0; }
+    __syncthreads();
+    {
+        constexpr int PER = (ENT + THREADS - 1) / THREADS;
+        int local[PER];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            local[k] = (i < tree_len) ? ((sh.ent[i] != -1) ? 1 : -1) : 0;
+            sum += local[k];
+        }
+        uint32_t tot;
+        /* signed values scanned in two's complement */
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>((uint32_t)sum, sh.part, tot);
+        int run = 1 + (int)ex;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            if (i < ENT) {
+                sh.open[i] = (uint16_t)(run < 0 ? 0 : run);
+                if (i < tree_len && run <= 0) atomicMin(&sh.efflen, i);
+                run += local[k];
+            }
+        }
+    }
+    __syncthreads();
+    const int eff = sh.efflen;
+    for (int j = tid; j < eff; j += THREADS) {
+        if (sh.ent[j] == -1) continue;
+        const uint16_t sj = sh.open[j];
+        const int c = j + 1;
+        if (c < eff && sh.ent[c] != -1) sh.left[j] = (uint16_t)c;
+        for (int r = j + 2; r < eff; r++) {
+            if (sh.open[r] == sj) {
+                if (sh.ent[r] != -1) sh.right[j] = (uint16_t)r;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    /* tree_len == 0 or a tree that starts with -1 is a NULL root: the reference crashes,
+     * the decision is BTREE_CORRUPTED */
+    if (!(eff > 0 && sh.ent[0] != -1)) return HUFE_CORRUPTED;
+
+    /* ---- 2. lookup table ---- */
+    for (int idx = tid; idx < (1 << DEC_LUT_BITS); idx += THREADS) {
+        uint32_t node = 0, e = 2u << 14;
+        bool done = false;
+#pragma unroll 1
+        for (int b = 0; b < DEC_LUT_BITS; b++) {
+            const uint32_t bit = (idx >> (DEC_LUT_BITS - 1 - b)) & 1u;
+            const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+            if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); done = true; break; }
+            node = nx;
+            if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) {
+                e = ((uint32_t)(b + 1) << 8) | ((uint32_t)(uint8_t)sh.ent[node]);
+                done = true;
+                break;
+            }
+        }
+        if (!done) e = (1u << 14) | node;
+        sh.lut[idx] = (uint16_t)e;
+    }
+    __syncthreads();
+
+    /* ---- 3. payload ---- */
+    const uint8_t *pay = tree + 2 * tree_len;
+    DecTree t;
+    t.left = sh.left;
+    t.right = sh.right;
+    t.val = sh.ent;
+    t.lut = sh.lut;
+    t.pay = sh.pay;
+    t.pay_bits = pay_bytes * 8ull;
+
+    uint64_t true_start = 0;      /* bit where the next undecoded codeword starts */
+    uint64_t produced = 0;        /* symbols written so far */
+    int err = HUFE_OK;
+
+    while (produced < block_len) {
+        if (true_start >= t.pay_bits) { err = HUFE_RW; break; }          /* input exhausted */
+        /* segment origin: the 32-bit word that holds true_start */
+        const uint64_t seg0 = true_start & ~31ull;
+        const uint64_t byte0 = seg0 >> 3;
+        for (int i = tid; i < SEG_WORDS + DEC_EXTRA_WORDS; i += THREADS)
+            sh.pay[i] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
+        __syncthreads();
+        t.seg_bit0 = seg0;
+
+        const uint64_t sub_lo = seg0 + (uint64_t)tid * DEC_SUB_BITS;
+        const uint64_t limit = sub_lo + DEC_SUB_BITS;
+        uint64_t start = (tid == 0) ? true_start : sub_lo;
+        uint32_t cnt = 0;
+        bool bad;
+        uint64_t end = start;
+        if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad);
+        sh.end[tid] = end;
+        __syncthreads();
+        for (;;) {
+            uint64_t ns = (tid == 0) ? true_start : sh.end[tid - 1];
+            const int changed = (ns != start);
+            __syncthreads();                               /* everyone has read sh.end */
+            if (changed) {
+                start = ns;
+                cnt = 0;
+                end = start;
+                if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad);
+                sh.end[tid] = end;
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+
+        /* output positions */
+        uint32_t seg_total;
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(cnt, sh.part, seg_total);
+        const uint64_t remaining = block_len - produced;
+        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
+        const uint32_t shift = (uint32_t)((uintptr_t)(gout + produced) & 15u);
+        const uint32_t omax = (ex < take) ? dmin<uint32_t>(take - ex, cnt) : 0u;
+        if (omax) {
+            uint32_t c2 = 0;
+            bool bad2 = false;
+            const uint64_t qe = dec_span<true>(t, start, limit, c2, sh.out, shift + ex, omax, bad2);
+            if (bad2) atomicExch(&sh.flag, 1);             /* left the tree inside the quota */
+            else if (ex + omax == take && remaining <= seg_total) sh.qend = qe;   /* block's last symbol */
+        }
+        __syncthreads();
+        if (sh.flag) { err = HUFE_CORRUPTED; break; }
+
+        /* copy out[shift, shift+take) -> gout[produced ...), 16-byte units aligned with HBM */
+        {
+            uint8_t *g16 = gout + produced - shift;       /* 16-byte aligned */
+            const uint32_t nunit = (shift + take + 15u) >> 4;
+            for (uint32_t u = tid; u < nunit; u += THREADS) {
+                const uint32_t lo = u << 4;
+                if (lo >= shift && lo + 16 <= shift + take) {
+                    *reinterpret_cast<uint4 *>(g16 + lo) = *reinterpret_cast<const uint4 *>(sh.out + lo);
+                } else {
+                    for (uint32_t k = 0; k < 16; k++) {
+                        const uint32_t bp = lo + k;
+                        if (bp >= shift && bp < shift + take) g16[bp] = sh.out[bp];
+                    }
+                }
+            }
+        }
+        produced += take;
+        const uint64_t last_end = sh.end[THREADS - 1];
+        __syncthreads();
+        if (produced < block_len) {
+            if (last_end == DEC_POS_EXHAUSTED) { err = HUFE_RW; break; }
+            true_start = last_end;
+        }
+    }
+    if (err == HUFE_OK) *end_bits = sh.qend;
+    return err;
+}
+
+/* Indexed decode: one workgroup per block, block extents from the in-process index. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void decode_kernel(const uint8_t *__restrict__ stream,
+                                                         uint64_t stream_len,
+                                                         const uint64_t *__restrict__ offsets,
+                                                         const HufDecodeMeta *__restrict__ dmeta,
+                                                         const uint64_t *__restrict__ out_offsets,
+                                                         uint8_t *__restrict__ out, uint64_t out_cap,
+                                                         int32_t *__restrict__ status)
+{
+    __shared__ DecShared<THREADS> sh;
+    const int tid = (int)threadIdx.x;
+    const uint64_t blk = blockIdx.x;
+    const HufDecodeMeta m = dmeta[blk];
+    int err = m.status;
+    if (err == HUFE_OK && m.block_len > 0) {
+        const uint64_t o0 = offsets[blk];
+        const uint64_t o1 = dmin<uint64_t>(offsets[blk + 1], stream_len);
+        const uint64_t obase = out_offsets[blk];
+        if (obase + m.block_len > out_cap) {
+            err = HUFE_MEMORY;
+        } else {
+            const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
+            uint64_t end_bits = 0;
+            err = decode_block<THREADS>(sh, stream + o0 + HUF_HEADER_FIXED, m.tree_len, m.block_len,
+                                        pay_bytes, out + obase, &end_bits);
+        }
+    }
+    if (tid == 0) status[blk] = err;
+}
+
+/* Raw-stream decode (no index): the block loop of src/decoder.c:218-276 run by ONE workgroup.
+ * Blocks are taken strictly in order because a block's end is only known once block_len
+ * symbols have been decoded; inside a block all lanes work in parallel.
+ * result[0] = error, [1] = bytes written, [2] = reader bytes consumed, [3] = blocks done. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__restrict__ stream,
+                                                               uint64_t avail, uint64_t length,
+                                                               int max_tree_len, uint8_t *__restrict__ out,
+                                                               uint64_t out_cap, uint64_t *__restrict__ result,
+                                                               uint64_t *__restrict__ block_offsets,
+                                                               uint64_t max_index)
+{
+    __shared__ DecShared<THREADS> sh;
+    uint64_t rd = 0, wr = 0, nblk = 0;
+    int err = HUFE_OK;
+    while (length > rd) {                                             /* decoder.c:218 */
+        if (block_offsets && nblk < max_index) {
+            if (threadIdx.x == 0) block_offsets[nblk] = rd;
+        }
+        if (avail - rd < 8) { err = HUFE_RW; break; }                 /* decoder.c:220-224 */
+        const uint64_t block_len = load_u64_unaligned(stream + rd);
+        rd += 8;
+        if (avail - rd < 2) { err = HUFE_RW; break; }                 /* decoder.c:231-234 */
+        const int16_t tl = (int16_t)((uint16_t)stream[rd] | ((uint16_t)stream[rd + 1] << 8));
+        rd += 2;
+        if (tl < 0 || tl > max_tree_len) { err = HUFE_OVERFLOW; break; }   /* decoder.c:237-239 */
+        if (avail - rd < 2ull * (uint64_t)tl) { err = HUFE_RW; break; }    /* decoder.c:248-252 */
+        const uint8_t *tree = stream + rd;
+        rd += 2ull * (uint64_t)tl;
+        if (block_len == 0) { nblk++; continue; }
+        if (block_len > 0xffffffffull) { err = HUFE_ARGUMENT; break; }
+        if (wr + block_len > out_cap) { err = HUFE_MEMORY; break; }
+        uint64_t end_bits = 0;
+        err = decode_block<THREADS>(sh, tree, tl, block_len, avail - rd, out + wr, &end_bits);
+        if (err != HUFE_OK) break;
+        rd += (end_bits + 7) >> 3;
+        wr += block_len;
+        nblk++;
+    }
+    if (threadIdx.x == 0) {
+        result[0] = (uint64_t)err;
+        result[1] = wr;
+        result[2] = rd;
+        result[3] = nblk;
+        if (block_offsets && nblk < max_index) block_offsets[nblk] = rd;
+    }
+}
+
+/* First failing block in stream order decides the result (decoder.c: first error aborts). */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void decode_status_kernel(const int32_t *__restrict__ status,
+                                                                const uint64_t *__restrict__ out_offsets,
+                                                                uint64_t nblocks, uint64_t *__restrict__ result)
+{
+    /* result[0] = error code, result[1] = raw bytes (all blocks on success, bytes before the
+     * failing block otherwise), result[2] = index of failing block */
+    __shared__ unsigned long long s_first;
+    if (threadIdx.x == 0) s_first = ~0ull;
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    for (uint64_t i = threadIdx.x; i < nblocks; i += THREADS)
+        if (status[i] != HUFE_OK) { mine = i; break; }
+    if (mine != ~0ull) atomicMin(&s_first, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_first == ~0ull) {
+            result[0] = HUFE_OK;
+            result[1] = out_offsets[nblocks];
+            result[2] = nblocks;
+        } else {
+            result[0] = (uint64_t)status[s_first];
+            result[1] = out_offsets[s_first];
+            result[2] = s_first;
+        }
+    }
+}
+
+/* ======================================================================================
+ * Synthetic inputs of SURVEY §8d (libhuffman_amd/datagen.py is the numpy twin).
+ * ==================================================================================== */
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i)
+{
+    uint64_t z = seed + i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void fill_kernel(uint8_t *__restrict__ out, uint64_t n, int kind, uint64_t seed, uint64_t first,
+                            const uint64_t *__restrict__ zipf_cum)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t g = first + i;                 /* global byte index */
+        uint8_t v;
+        if (kind == 0) v = 0x41;
+        else if (kind == 1) v = (uint8_t)(splitmix64_at(seed, (g >> 3) + 1) >> (8 * (g & 7)));
+        else if (kind == 2) v = (uint8_t)(splitmix64_at(seed, g + 1) % 255ull);
+        else {
+            const uint64_t u = splitmix64_at(seed, g + 1) % zipf_cum[254];
+            int lo = 0, hi = 255;                     /* number of cum[r] <= u */
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (zipf_cum[mid] <= u) lo = mid + 1; else hi = mid;
+            }
+            v = (uint8_t)lo;
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace hufgpu

@@ -1,0 +1,296 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).
+
+Every test drives the HIP path through the C ABI of libhuffman_amd/libhuffman.so and compares
+with (a) the golden vectors captured from the unmodified reference, (b) the CPU oracle on the
+same seeded input.  Bit-exact everywhere - the codec is pure integer/byte work.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from libhuffman_amd import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def codec(torch_mod):
+    from libhuffman_amd.codec import GpuCodec
+    c = GpuCodec(0)
+    yield c
+    c.close()
+
+
+def to_dev(torch, arr):
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.size == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda")
+    return torch.from_numpy(a).cuda()
+
+
+def first_diff(a: np.ndarray, b: np.ndarray) -> str:
+    n = min(a.size, b.size)
+    d = np.nonzero(a[:n] != b[:n])[0]
+    if d.size == 0:
+        return f"sizes {a.size} vs {b.size}, common prefix equal"
+    i = int(d[0])
+    return (f"sizes {a.size} vs {b.size}; first diff at byte {i}: "
+            f"{a[max(0, i - 4): i + 8].tobytes().hex()} vs {b[max(0, i - 4): i + 8].tobytes().hex()}; "
+            f"{d.size} bytes differ")
+
+
+def gpu_encode(torch, codec, data: np.ndarray, blocksize: int):
+    d = to_dev(torch, data)
+    if d.numel() == 0:
+        return np.empty(0, np.uint8), np.zeros(1, np.uint64)
+    out, offs, n = codec.encode(d, blocksize)
+    return out.cpu().numpy(), offs.cpu().numpy().astype(np.uint64)
+
+
+def gpu_decode_indexed(torch, codec, stream: np.ndarray, offs: np.ndarray, raw_cap: int, relaxed=False):
+    s = to_dev(torch, stream)
+    o = torch.from_numpy(offs.astype(np.int64)).cuda()
+    out = torch.empty(max(raw_cap, 1), dtype=torch.uint8, device="cuda")
+    n = codec.decode(s, stream.size, o, offs.size - 1, out, relaxed=relaxed)
+    return out[:n].cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
+def test_fill_matches_numpy_generators(torch_mod, codec):
+    torch = torch_mod
+    n = 262144 + 24
+    for kind in ("const41", "uniform256", "uniform255", "zipf255"):
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        codec.fill(buf, kind)
+        want = datagen.GENERATORS[kind](n)
+        got = buf.cpu().numpy()
+        assert np.array_equal(got, want), (kind, first_diff(got, want))
+        # a shard that starts in the middle of the global sequence
+        first = 65536
+        part = torch.empty(1000, dtype=torch.uint8, device="cuda")
+        codec.fill(part, kind, first=first)
+        assert np.array_equal(part.cpu().numpy(), want[first:first + 1000]), kind
+
+
+def test_histogram_matches_oracle(torch_mod, codec, oracle):
+    torch = torch_mod
+    for kind, n, bs in (("zipf255", 262144, 65536), ("uniform256", 200000, 65536),
+                        ("const41", 70000, 65536), ("uniform255", 12305, 4096), ("zipf255", 5000, 1237)):
+        data = datagen.GENERATORS[kind](n)
+        hist = codec.histogram(to_dev(torch, data), bs).cpu().numpy().astype(np.uint64)
+        for b in range(hist.shape[0]):
+            want = oracle.histogram(data[b * bs:(b + 1) * bs])
+            assert np.array_equal(hist[b], want), (kind, b)
+
+
+def test_encode_small_goldens(torch_mod, codec, golden):
+    for vec in golden["encode_small"]:
+        data = np.frombuffer(bytes.fromhex(vec["input_hex"]), dtype=np.uint8)
+        out, offs = gpu_encode(torch_mod, codec, data, vec["blocksize"])
+        want = np.frombuffer(bytes.fromhex(vec["output_hex"]), dtype=np.uint8)
+        assert np.array_equal(out, want), (vec["name"], first_diff(out, want))
+
+
+def test_encode_large_goldens(torch_mod, codec, golden, oracle):
+    for vec in golden["encode_large"]:
+        data = datagen.GENERATORS[vec["generator"]](vec["n"])
+        out, offs = gpu_encode(torch_mod, codec, data, vec["blocksize"])
+        if sha(out) != vec["output_sha256"]:
+            want = oracle.encode(data, vec["blocksize"])
+            pytest.fail(f"{vec['generator']} n={vec['n']} bs={vec['blocksize']}: {first_diff(out, want)}")
+        assert out.size == vec["output_len"]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_encode_random_vs_oracle(torch_mod, codec, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 300000))
+    k = int(rng.integers(1, 257))
+    alphabet = rng.choice(256, size=k, replace=False)
+    p = rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.3, 1.0, 10.0]))))
+    data = alphabet[rng.choice(k, size=n, p=p)].astype(np.uint8)
+    bs = int(rng.choice([0, 7, 256, 1000, 4096, 4097, 65536, 100000]))
+    if bs and n // bs > 3000:
+        data = data[: bs * 3000]
+    want, woffs = oracle.encode(data, bs, with_offsets=True)
+    out, offs = gpu_encode(torch_mod, codec, data, bs)
+    assert np.array_equal(out, want), first_diff(out, want)
+    assert np.array_equal(offs, woffs)
+
+
+def test_encode_deep_codes(torch_mod, codec, oracle):
+    """Fibonacci-weighted inputs give the longest codes a block can have (22 bits at 64 KiB,
+    >32 bits needs > 5.7 MB: exercised with one 8 MiB block)."""
+    def fib_data(limit):
+        f, sym, parts, total = [1, 1], 0, [], 0
+        while total + f[-1] <= limit and sym < 250:
+            parts.append(np.full(f[-2], sym, np.uint8))
+            total += f[-2]
+            f.append(f[-1] + f[-2])
+            sym += 1
+        return np.concatenate(parts)
+    for limit, bs in ((65536, 65536), (1 << 20, 1 << 20), (8 << 20, 8 << 20)):
+        data = fib_data(limit)
+        rng = np.random.default_rng(7)
+        rng.shuffle(data)
+        want = oracle.encode(data, bs)
+        out, offs = gpu_encode(torch_mod, codec, data, bs)
+        assert np.array_equal(out, want), (limit, first_diff(out, want))
+        back = gpu_decode_indexed(torch_mod, codec, out, offs, data.size)
+        assert np.array_equal(back, data), (limit, first_diff(back, data))
+
+
+@pytest.mark.parametrize("kind,n,bs", [("const41", 262144, 65536), ("uniform256", 262144, 65536),
+                                       ("uniform255", 262144, 65536), ("zipf255", 262144, 65536),
+                                       ("zipf255", 2 << 20, 1 << 20), ("logtext", 2 << 20, 1 << 20),
+                                       ("zipf255", 66536, 65536), ("uniform255", 12305, 4096),
+                                       ("zipf255", 50000, 1237)])
+def test_decode_indexed_roundtrip(torch_mod, codec, oracle, kind, n, bs):
+    data = datagen.GENERATORS[kind](n)
+    stream, offs = oracle.encode(data, bs, with_offsets=True)
+    back = gpu_decode_indexed(torch_mod, codec, stream, offs, n, relaxed=True)
+    assert np.array_equal(back, data), first_diff(back, data)
+    # encode on the GPU, decode on the GPU
+    out, goffs = gpu_encode(torch_mod, codec, data, bs)
+    back = gpu_decode_indexed(torch_mod, codec, out, goffs, n, relaxed=True)
+    assert np.array_equal(back, data)
+
+
+def test_decode_strict_rejects_k256(torch_mod, codec, oracle):
+    from libhuffman_amd.codec import HuffmanGpuError
+    data = datagen.uniform256(65536 * 2, 1)
+    stream, offs = oracle.encode(data, 65536, with_offsets=True)
+    with pytest.raises(HuffmanGpuError) as ei:
+        gpu_decode_indexed(torch_mod, codec, stream, offs, data.size, relaxed=False)
+    assert ei.value.err == 5          # src/decoder.c:237-239
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_decode_stream_vs_oracle(torch_mod, codec, oracle, seed):
+    torch = torch_mod
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(1, 120000))
+    k = int(rng.integers(1, 256))
+    alphabet = rng.choice(256, size=k, replace=False)
+    data = alphabet[rng.choice(k, size=n, p=rng.dirichlet(np.full(k, 0.4)))].astype(np.uint8)
+    bs = int(rng.choice([0, 100, 4096, 65536]))
+    if bs == 100:
+        data = data[:20000]
+    stream = oracle.encode(data, bs)
+    out = torch.empty(data.size + 64, dtype=torch.uint8, device="cuda")
+    err, raw, used = codec.decode_stream(to_dev(torch, stream), stream.size, stream.size, out)
+    assert (err, raw, used) == (0, data.size, stream.size)
+    assert np.array_equal(out[:raw].cpu().numpy(), data)
+
+
+def test_decode_stream_error_goldens(torch_mod, codec, golden):
+    torch = torch_mod
+    for vec in golden["decode_errors"] + golden["decode_ok"]:
+        stream = np.frombuffer(bytes.fromhex(vec["stream_hex"]), dtype=np.uint8)
+        length = vec.get("length") or stream.size
+        out = torch.empty(4096, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(to_dev(torch, stream), stream.size, length, out)
+        assert err == vec["err"], vec["name"]
+        assert out[:raw].cpu().numpy().tobytes().hex() == vec["output_hex"], vec["name"]
+
+
+def test_self_synchronisation_worst_cases(torch_mod, codec, oracle):
+    """Inputs on which speculative starts do not re-synchronise by themselves: long runs of
+    one symbol whose code is longer than a bit, and fixed-length codes."""
+    cases = []
+    a = np.zeros(70000, np.uint8); a[::997] = 1; a[5::4999] = 2          # runs of a 2-bit code
+    cases.append(a)
+    cases.append(np.tile(np.arange(4, dtype=np.uint8), 20000))           # 3-bit fixed length, periodic
+    cases.append(np.repeat(np.arange(16, dtype=np.uint8), 4096))         # 5-bit fixed, long runs
+    b = np.full(65536, 7, np.uint8); b[-1] = 9
+    cases.append(b)
+    for data in cases:
+        stream, offs = oracle.encode(data, 65536, with_offsets=True)
+        back = gpu_decode_indexed(torch_mod, codec, stream, offs, data.size)
+        assert np.array_equal(back, data), first_diff(back, data)
+
+
+def test_c_api_roundtrip_readme_example(torch_mod, golden):
+    """README.md:37-104 / BASELINE config 1 through the drop-in C API: huf_memopen streams,
+    huf_encode then huf_decode with swapped streams."""
+    import ctypes as C
+    from libhuffman_amd import _native as N
+    L = N.load()
+    for data, bs, rb, wb in ((b"0123456789", 65536, 0, 0), (b"0123456789", 0, 128, 128),
+                             (b"abcabc", 4, 3, 5), (b"a" * 1000, 131072, 0, 0)):
+        rin, rout = C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)()
+        bin_, bout = C.c_void_p(), C.c_void_p()
+        assert L.huf_memopen(C.byref(rin), C.byref(bin_), 16) == 0
+        assert L.huf_memopen(C.byref(rout), C.byref(bout), 16) == 0
+        assert rin.contents.write(rin.contents.stream, data, len(data)) == 0
+        cfg = N.Config(len(data), bs, rb, wb, rin, rout)
+        assert L.huf_encode(C.byref(cfg)) == 0
+        n = C.c_size_t()
+        L.huf_memlen(rout, C.byref(n))
+        enc = C.string_at(bout.value, n.value)
+        want = next(v for v in golden["encode_small"]
+                    if bytes.fromhex(v["input_hex"]) == data and v["blocksize"] == bs)
+        assert enc.hex() == want["output_hex"]
+        # decode: the encoded stream becomes the reader, a fresh stream the writer
+        rback, bback = C.POINTER(N.ReadWriter)(), C.c_void_p()
+        assert L.huf_memopen(C.byref(rback), C.byref(bback), 16) == 0
+        dcfg = N.Config(n.value, 0, rb, wb, rout, rback)
+        assert L.huf_decode(C.byref(dcfg)) == 0
+        L.huf_memlen(rback, C.byref(n))
+        assert C.string_at(bback.value, n.value) == data
+        for r in (rin, rout, rback):
+            L.huf_memclose(C.byref(r))
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        for b in (bin_, bout, bback):
+            libc.free(b)
+
+
+def test_full_size_config2_const41(torch_mod, codec):
+    """BASELINE config 2 at full size: 1 GiB of 0x41, 64 KiB blocks. Size-independent checks:
+    exact stream length 16384 * 8212, every block record identical, round trip."""
+    torch = torch_mod
+    n, bs = 1 << 30, 65536
+    data = torch.full((n,), 0x41, dtype=torch.uint8, device="cuda")
+    out, offs, length = codec.encode(data, bs)
+    assert length == 16384 * 8212
+    rec = out[:length].view(16384, 8212)
+    assert bool((rec == rec[0:1]).all())
+    head = rec[0, :20].cpu().numpy().tobytes().hex()
+    assert head == "0000010000000000" + "0500" + "0001" + "4100" + "ffffffffffff"
+    assert int(rec[0, 20:].max()) == 0
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(out, length, offs, 16384, back) == n
+    assert torch.equal(back, data)
+
+
+@pytest.mark.parametrize("kind", ["zipf255", "uniform256"])
+def test_full_size_roundtrip_and_block_parity(torch_mod, codec, oracle, kind):
+    """BASELINE configs 3/4 at 1 GiB: GPU round trip, plus bit-exact comparison of a sample of
+    blocks against the oracle (blocks are independent, so any block can be checked alone)."""
+    torch = torch_mod
+    n, bs = 1 << 30, 65536
+    data = torch.empty(n, dtype=torch.uint8, device="cuda")
+    codec.fill(data, kind)
+    out, offs, length = codec.encode(data, bs)
+    offs_h = offs.cpu().numpy()
+    for b in (0, 1, 4095, 8191, 16383):
+        block = data[b * bs:(b + 1) * bs].cpu().numpy()
+        want = oracle.encode(block, bs)
+        got = out[int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy()
+        assert np.array_equal(got, want), (b, first_diff(got, want))
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(out, length, offs, 16384, back, relaxed=True) == n
+    assert torch.equal(back, data)

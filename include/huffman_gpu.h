@@ -9,7 +9,7 @@
  * layer calls when the data already lives on the GPU, and what bench.py times.
  *
  * C ABI only: no C++ or torch types; `stream` arguments are a hipStream_t passed as void*
- * (NULL = the context's own stream).  All functions return a huf_error_t value
+ * (NULL = the device's default stream).  All functions return a huf_error_t value
  * (include/huffman.h); HIP failures map to HUF_ERROR_FATAL and hufgpu_last_error() carries
  * the text.  Nothing here falls back to the CPU.
  *

@@ -137,7 +137,7 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     if (!ctx) return HUFE_MEMORY;
     ctx->device = device;
     HIP_OK(NULL, hipSetDevice(device));
-    HIP_OK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
     HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i <= MAX_STAGES; i++) HIP_OK(ctx, hipEventCreate(&ctx->ev[i]));
@@ -185,7 +185,6 @@ extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
     (void)hipFree(ctx->d_zipf);
     (void)hipHostFree(ctx->h_result);
     for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipStreamDestroy(ctx->stream);
     free(ctx);
     return HUFE_OK;
 }
@@ -218,7 +217,7 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
     return HUFE_OK;
 }
 
-static inline hipStream_t pick_stream(hufgpu_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+static inline hipStream_t pick_stream(hufgpu_ctx *c, void *stream) { (void)c; return (hipStream_t)stream; }
 
 #define STAGE_BEGIN(c, s)                                                    \
     do {                                                                     \

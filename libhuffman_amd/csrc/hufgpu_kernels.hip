@@ -642,6 +642,7 @@ struct DecTree {
 };
 
 #define DEC_POS_EXHAUSTED (~0ull >> 1)   /* "a codeword ran past the readable payload" */
+#define DEC_NO_BAD 0xffffffffu
 
 __device__ __forceinline__ uint32_t dec_window(const DecTree &t, uint64_t pos)
 {
@@ -654,18 +655,20 @@ __device__ __forceinline__ uint32_t dec_window(const DecTree &t, uint64_t pos)
 /* Decode the codewords that start in [start, limit).  Returns the position of the first
  * codeword at or after limit (DEC_POS_EXHAUSTED if a codeword needs bits past the payload:
  * the reference would fail its next byte read there, src/decoder.c:53-56).
- *   WRITE = false: count only; a walk that leaves the tree skips one bit (this only ever
- *           happens on a speculative, not yet synchronised start).
- *   WRITE = true : store at most omax symbols to s_out[obase..] and stop after them; a walk
- *           that leaves the tree sets bad and stops (src/decoder.c:69-71). */
+ *   WRITE = false: count only; a walk that leaves the tree is remembered in bad_at (symbols
+ *           decoded before it) and decoding resumes one bit later.  On a speculative start
+ *           that is harmless; once the starts have converged the first such event in stream
+ *           order is the real error of src/decoder.c:69-71.
+ *   WRITE = true : store at most omax symbols to s_out[obase..] and stop after them (or at
+ *           the first walk that leaves the tree). */
 template <bool WRITE>
 __device__ __forceinline__ uint64_t dec_span(const DecTree &t, uint64_t start, uint64_t limit,
                                              uint32_t &cnt, uint8_t *s_out, uint32_t obase,
-                                             uint32_t omax, bool &bad)
+                                             uint32_t omax, uint32_t &bad_at)
 {
     uint64_t pos = start;
     uint32_t c = 0;
-    bad = false;
+    bad_at = DEC_NO_BAD;          /* symbols decoded before the first walk that left the tree */
     while (pos < limit) {
         if (WRITE && c >= omax) break;
         const uint32_t win = dec_window(t, pos);
@@ -700,7 +703,8 @@ __device__ __forceinline__ uint64_t dec_span(const DecTree &t, uint64_t start, u
             /* the failing bit must be a real payload bit for the failure to be real; otherwise
              * the reference would have failed its byte read first (src/decoder.c:53-56) */
             if (npos > t.pay_bits) { pos = DEC_POS_EXHAUSTED; break; }
-            if (WRITE) { bad = true; break; }
+            if (bad_at == DEC_NO_BAD) bad_at = c;
+            if (WRITE) break;
             pos += 1;
             continue;
         }
@@ -745,7 +749,7 @@ struct DecShared {
     uint64_t end[THREADS];
     uint32_t part[THREADS / 64];
     int efflen;
-    int flag;
+    uint32_t badsym;           /* segment symbol index of the first walk that left the tree */
     uint64_t qend;             /* payload bit right after the block's last symbol */
     __attribute__((aligned(16))) uint8_t out[OUT_BYTES];
 };
@@ -756,8 +760,10 @@ struct DecShared {
  * symbol (valid on success). */
 template <int THREADS>
 __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
-                            uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits)
+                            uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits,
+                            uint64_t *produced_out)
 {
+    *produced_out = 0;
     constexpr int SEG_WORDS = DecShared<THREADS>::SEG_WORDS;
     constexpr int ENT = DecShared<THREADS>::ENT;
     const int tid = (int)threadIdx.x;
@@ -771,7 +777,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         sh.left[i] = DEC_NULL;
         sh.right[i] = DEC_NULL;
     }
-    if (tid == 0) { sh.efflen = tree_len; sh.flag = 0; sh.qend = 0; }
+    if (tid == 0) { sh.efflen = tree_len; sh.badsym = DEC_NO_BAD; sh.qend = 0; }
     __syncthreads();
     {
         constexpr int PER = (ENT + THREADS - 1) / THREADS;
@@ -865,9 +871,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         const uint64_t limit = sub_lo + DEC_SUB_BITS;
         uint64_t start = (tid == 0) ? true_start : sub_lo;
         uint32_t cnt = 0;
-        bool bad;
+        uint32_t bad_at = DEC_NO_BAD;
         uint64_t end = start;
-        if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad);
+        if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad_at);
         sh.end[tid] = end;
         __syncthreads();
         for (;;) {
@@ -877,8 +883,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             if (changed) {
                 start = ns;
                 cnt = 0;
+                bad_at = DEC_NO_BAD;
                 end = start;
-                if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad);
+                if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad_at);
                 sh.end[tid] = end;
             }
             if (!__syncthreads_or(changed)) break;
@@ -888,18 +895,28 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         uint32_t seg_total;
         const uint32_t ex = block_excl_scan<THREADS, uint32_t>(cnt, sh.part, seg_total);
         const uint64_t remaining = block_len - produced;
-        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
+        /* the first walk that left the tree, in stream order, is a real error if it happens
+         * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
+         * Symbols decoded before it are still delivered, like the reference's writer does. */
+        if (bad_at != DEC_NO_BAD && (uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
+        __syncthreads();
+        const uint32_t badsym = sh.badsym;
+        const uint32_t good = (badsym != DEC_NO_BAD) ? badsym : seg_total;
+        const uint32_t take = (uint32_t)dmin<uint64_t>(good, remaining);
         const uint32_t shift = (uint32_t)((uintptr_t)(gout + produced) & 15u);
-        const uint32_t omax = (ex < take) ? dmin<uint32_t>(take - ex, cnt) : 0u;
+        /* (written as plain ifs: the select/min form of this was observed to misbehave when
+         * compiled inside this kernel by ROCm 7.2 hipcc - garbage lanes got a non-zero quota) */
+        uint32_t omax = 0;
+        if (ex < take) {
+            omax = take - ex;
+            if (omax > cnt) omax = cnt;
+        }
         if (omax) {
-            uint32_t c2 = 0;
-            bool bad2 = false;
+            uint32_t c2 = 0, bad2;
             const uint64_t qe = dec_span<true>(t, start, limit, c2, sh.out, shift + ex, omax, bad2);
-            if (bad2) atomicExch(&sh.flag, 1);             /* left the tree inside the quota */
-            else if (ex + omax == take && remaining <= seg_total) sh.qend = qe;   /* block's last symbol */
+            if (ex + omax == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
         }
         __syncthreads();
-        if (sh.flag) { err = HUFE_CORRUPTED; break; }
 
         /* copy out[shift, shift+take) -> gout[produced ...), 16-byte units aligned with HBM */
         {
@@ -920,12 +937,14 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         produced += take;
         const uint64_t last_end = sh.end[THREADS - 1];
         __syncthreads();
+        if (badsym != DEC_NO_BAD) { err = HUFE_CORRUPTED; break; }
         if (produced < block_len) {
             if (last_end == DEC_POS_EXHAUSTED) { err = HUFE_RW; break; }
             true_start = last_end;
         }
     }
     if (err == HUFE_OK) *end_bits = sh.qend;
+    *produced_out = produced;
     return err;
 }
 
@@ -952,9 +971,9 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(const uint8_t *__restri
             err = HUFE_MEMORY;
         } else {
             const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
-            uint64_t end_bits = 0;
+            uint64_t end_bits = 0, produced = 0;
             err = decode_block<THREADS>(sh, stream + o0 + HUF_HEADER_FIXED, m.tree_len, m.block_len,
-                                        pay_bytes, out + obase, &end_bits);
+                                        pay_bytes, out + obase, &end_bits, &produced);
         }
     }
     if (tid == 0) status[blk] = err;
@@ -992,9 +1011,9 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
         if (block_len == 0) { nblk++; continue; }
         if (block_len > 0xffffffffull) { err = HUFE_ARGUMENT; break; }
         if (wr + block_len > out_cap) { err = HUFE_MEMORY; break; }
-        uint64_t end_bits = 0;
-        err = decode_block<THREADS>(sh, tree, tl, block_len, avail - rd, out + wr, &end_bits);
-        if (err != HUFE_OK) break;
+        uint64_t end_bits = 0, produced = 0;
+        err = decode_block<THREADS>(sh, tree, tl, block_len, avail - rd, out + wr, &end_bits, &produced);
+        if (err != HUFE_OK) { wr += produced; break; }   /* symbols before the failure stay delivered */
         rd += (end_bits + 7) >> 3;
         wr += block_len;
         nblk++;

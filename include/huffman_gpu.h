@@ -112,11 +112,15 @@ int hufgpu_memcpy_h2d(hufgpu_ctx_t *ctx, void *d_dst, const void *h_src, uint64_
 int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int hufgpu_synchronize(hufgpu_ctx_t *ctx);
 
-/* Per-stage timing of the last synchronous-style run: enables HIP events around each kernel
- * of subsequent calls (0 = off). Results in milliseconds, in launch order:
- * encode: [hist, tree, scan, pack]; decode: [prepare, scan, decode]. */
+/* Per-kernel timing. While enabled, every hufgpu_encode/hufgpu_decode call records HIP
+ * events around each of its kernels on the stream it launches on (up to 256 calls are kept;
+ * enabling resets the record).  hufgpu_get_profile() then returns, for kind 0 = encode or
+ * 1 = decode, the per-kernel time summed over the recorded calls, in launch order:
+ *   encode: [hist256, tree, scan_sizes, pack]     decode: [prepare, scan_lens, decode]
+ * No host synchronisation happens until hufgpu_get_profile() is called. */
 int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled);
-int hufgpu_get_stage_ms(hufgpu_ctx_t *ctx, float *ms, int max_stages, int *n_stages);
+int hufgpu_get_profile(hufgpu_ctx_t *ctx, int kind, float *ms_sum, int max_stages,
+                       int *n_stages, int *n_calls);
 
 #ifdef __cplusplus
 }

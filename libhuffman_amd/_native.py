@@ -57,7 +57,7 @@ GPU_SYMBOLS = """hufgpu_device_count hufgpu_ctx_create hufgpu_ctx_destroy hufgpu
 hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_decode
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_synchronize hufgpu_set_profiling
-hufgpu_get_stage_ms""".split()
+hufgpu_get_profile""".split()
 
 
 def so_path() -> str:
@@ -112,7 +112,7 @@ def load() -> C.CDLL:
     L.hufgpu_memcpy_d2h.argtypes = [vp, vp, vp, u64]
     L.hufgpu_synchronize.argtypes = [vp]
     L.hufgpu_set_profiling.argtypes = [vp, i32]
-    L.hufgpu_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32)]
+    L.hufgpu_get_profile.argtypes = [vp, i32, C.POINTER(C.c_float), i32, C.POINTER(i32), C.POINTER(i32)]
     _LIB = L
     return L
 

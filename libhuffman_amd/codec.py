@@ -127,8 +127,15 @@ class GpuCodec:
     def set_profiling(self, on: bool):
         self.lib.hufgpu_set_profiling(self._ctx, 1 if on else 0)
 
-    def stage_ms(self):
+    ENCODE_KERNELS = ("hist256", "tree", "scan_sizes", "pack")
+    DECODE_KERNELS = ("decode_prepare", "scan_lens", "decode")
+
+    def profile(self, kind: str):
+        """Per-kernel milliseconds summed over the profiled calls -> (dict name->ms, calls)."""
         ms = (C.c_float * 8)()
-        n = C.c_int(0)
-        self._check(self.lib.hufgpu_get_stage_ms(self._ctx, ms, 8, C.byref(n)), "stage timing failed")
-        return [float(ms[i]) for i in range(n.value)]
+        n, calls = C.c_int(0), C.c_int(0)
+        k = 0 if kind == "encode" else 1
+        self._check(self.lib.hufgpu_get_profile(self._ctx, k, ms, 8, C.byref(n), C.byref(calls)),
+                    "profile readout failed")
+        names = self.ENCODE_KERNELS if k == 0 else self.DECODE_KERNELS
+        return {names[i]: float(ms[i]) for i in range(min(n.value, len(names)))}, calls.value

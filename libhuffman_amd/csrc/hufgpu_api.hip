@@ -23,6 +23,9 @@ using namespace hufgpu;
 #define DEC_THREADS 256
 #define SCAN_THREADS 1024
 #define MAX_STAGES 8
+#define PROF_SLOTS 256
+#define PROF_ENCODE 0
+#define PROF_DECODE 1
 
 struct hufgpu_ctx {
     int device;
@@ -47,10 +50,15 @@ struct hufgpu_ctx {
     uint64_t *h_result;           /* pinned mirror */
     uint64_t *d_zipf;             /* 255 cumulative weights */
 
+    /* per-kernel timing: every profiled call records HIP events around its kernels into the
+     * next slot; hufgpu_get_profile() sums the slots, so a timed loop needs no host sync */
     int profiling;
+    int prof_used;
+    int cur_slot;
     int n_stages;
-    hipEvent_t ev[MAX_STAGES + 1];
-    float stage_ms[MAX_STAGES];
+    hipEvent_t (*ev)[MAX_STAGES + 1];
+    int slot_stages[PROF_SLOTS];
+    int slot_kind[PROF_SLOTS];
     int decode_pending;
     hipStream_t last_stream;
 };
@@ -140,7 +148,6 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
     HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(uint64_t), hipHostMallocDefault));
-    for (int i = 0; i <= MAX_STAGES; i++) HIP_OK(ctx, hipEventCreate(&ctx->ev[i]));
 
     /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
     uint64_t cum[255], acc = 0;
@@ -184,7 +191,11 @@ extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
     (void)hipFree(ctx->d_result);
     (void)hipFree(ctx->d_zipf);
     (void)hipHostFree(ctx->h_result);
-    for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev) {
+        for (int k = 0; k < PROF_SLOTS; k++)
+            for (int i = 0; i <= MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[k][i]);
+        free(ctx->ev);
+    }
     free(ctx);
     return HUFE_OK;
 }
@@ -219,39 +230,63 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
 
 static inline hipStream_t pick_stream(hufgpu_ctx *c, void *stream) { (void)c; return (hipStream_t)stream; }
 
-#define STAGE_BEGIN(c, s)                                                    \
-    do {                                                                     \
-        (c)->n_stages = 0;                                                   \
-        if ((c)->profiling) HIP_OK((c), hipEventRecord((c)->ev[0], (s)));    \
+#define STAGE_BEGIN(c, s, kind)                                                         \
+    do {                                                                                \
+        (c)->n_stages = 0;                                                              \
+        (c)->cur_slot = -1;                                                             \
+        if ((c)->profiling && (c)->prof_used < PROF_SLOTS) {                            \
+            (c)->cur_slot = (c)->prof_used++;                                           \
+            (c)->slot_kind[(c)->cur_slot] = (kind);                                     \
+            (c)->slot_stages[(c)->cur_slot] = 0;                                        \
+            HIP_OK((c), hipEventRecord((c)->ev[(c)->cur_slot][0], (s)));                \
+        }                                                                               \
     } while (0)
-#define STAGE_MARK(c, s)                                                                    \
-    do {                                                                                    \
-        if ((c)->profiling && (c)->n_stages < MAX_STAGES) {                                 \
-            (c)->n_stages++;                                                                \
-            HIP_OK((c), hipEventRecord((c)->ev[(c)->n_stages], (s)));                       \
-        }                                                                                   \
+#define STAGE_MARK(c, s)                                                                \
+    do {                                                                                \
+        if ((c)->cur_slot >= 0 && (c)->n_stages < MAX_STAGES) {                         \
+            (c)->n_stages++;                                                            \
+            (c)->slot_stages[(c)->cur_slot] = (c)->n_stages;                            \
+            HIP_OK((c), hipEventRecord((c)->ev[(c)->cur_slot][(c)->n_stages], (s)));    \
+        }                                                                               \
     } while (0)
 
 extern "C" int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled)
 {
     if (!ctx) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (enabled && !ctx->ev) {
+        ctx->ev = (hipEvent_t(*)[MAX_STAGES + 1])calloc(PROF_SLOTS, sizeof(*ctx->ev));
+        if (!ctx->ev) return HUFE_MEMORY;
+        for (int k = 0; k < PROF_SLOTS; k++)
+            for (int i = 0; i <= MAX_STAGES; i++) HIP_OK(ctx, hipEventCreate(&ctx->ev[k][i]));
+    }
     ctx->profiling = enabled ? 1 : 0;
-    ctx->n_stages = 0;
+    ctx->prof_used = 0;
+    ctx->cur_slot = -1;
     return HUFE_OK;
 }
 
-extern "C" int hufgpu_get_stage_ms(hufgpu_ctx_t *ctx, float *ms, int max_stages, int *n_stages)
+extern "C" int hufgpu_get_profile(hufgpu_ctx_t *ctx, int kind, float *ms_sum, int max_stages,
+                                  int *n_stages, int *n_calls)
 {
-    if (!ctx || !ms || !n_stages) return HUFE_ARGUMENT;
+    if (!ctx || !ms_sum || !n_stages || !n_calls) return HUFE_ARGUMENT;
     HIP_OK(ctx, hipSetDevice(ctx->device));
-    int n = ctx->n_stages < max_stages ? ctx->n_stages : max_stages;
-    if (ctx->profiling && n > 0) {
-        HIP_OK(ctx, hipEventSynchronize(ctx->ev[ctx->n_stages]));
-        for (int i = 0; i < n; i++) HIP_OK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
-    } else {
-        n = 0;
+    *n_stages = 0;
+    *n_calls = 0;
+    for (int i = 0; i < max_stages; i++) ms_sum[i] = 0.f;
+    for (int k = 0; k < ctx->prof_used; k++) {
+        if (ctx->slot_kind[k] != kind) continue;
+        const int ns = ctx->slot_stages[k] < max_stages ? ctx->slot_stages[k] : max_stages;
+        if (ns <= 0) continue;
+        HIP_OK(ctx, hipEventSynchronize(ctx->ev[k][ctx->slot_stages[k]]));
+        for (int i = 0; i < ns; i++) {
+            float ms = 0.f;
+            HIP_OK(ctx, hipEventElapsedTime(&ms, ctx->ev[k][i], ctx->ev[k][i + 1]));
+            ms_sum[i] += ms;
+        }
+        if (ns > *n_stages) *n_stages = ns;
+        (*n_calls)++;
     }
-    *n_stages = n;
     return HUFE_OK;
 }
 
@@ -310,7 +345,7 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     uint64_t *offs = d_block_offsets ? d_block_offsets : ctx->d_offsets;
     const uint8_t *in = (const uint8_t *)d_in;
 
-    STAGE_BEGIN(ctx, s);
+    STAGE_BEGIN(ctx, s, PROF_ENCODE);
     hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
     STAGE_MARK(ctx, s);
     if (blocksize < (1ull << 22))
@@ -369,7 +404,7 @@ extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t s
     const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
     const uint8_t *st = (const uint8_t *)d_stream;
 
-    STAGE_BEGIN(ctx, s);
+    STAGE_BEGIN(ctx, s, PROF_DECODE);
     decode_prepare_kernel<<<dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta);
     STAGE_MARK(ctx, s);
     scan_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_dmeta, nblocks, ctx->d_out_offsets);
@@ -396,7 +431,7 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
     HIP_OK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
     const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
-    STAGE_BEGIN(ctx, s);
+    STAGE_BEGIN(ctx, s, PROF_DECODE);
     decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_stream, avail, length, max_tree,
                                                                         (uint8_t *)d_out, out_cap, ctx->d_result, NULL, 0);
     STAGE_MARK(ctx, s);

@@ -13,6 +13,15 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so.7; libhuffman.so needs the same SONAME.  Importing torch
+# FIRST makes the loader reuse torch's copy, so the process holds ONE HIP runtime.  In the other
+# order the system runtime is loaded for us, torch then loads its own, and the second runtime
+# to initialise sees no device ("no ROCm-capable device is detected").
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:          # pure-C / ctypes users without torch: the system runtime is used
+    _torch = None
+
 from . import build as _build
 
 _LIB = None

@@ -1,0 +1,304 @@
+"""CPU-side tests of the product library: ABI surface and host plumbing (no GPU needed).
+
+Restates, through ctypes, the assertions of the reference's own C unit tests for the host-side
+pieces of the boundary: test/io_test.c, test/histogram_test.c, test/symbol_test.c,
+test/tree_test.c, and the no-input case of test/decode_test.c:32-36.  No codec compute happens
+here - without a GPU huf_encode/huf_decode must fail loudly (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from libhuffman_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from libhuffman_amd import build
+    build.build()
+    return N.load()
+
+
+def have_gpu(L) -> bool:
+    return L.hufgpu_device_count() > 0
+
+
+def test_exports_every_declared_symbol(L):
+    """Every function declared in include/*.h is exported by the shared library."""
+    declared = set()
+    for hdr in ("huffman.h", "huffman_gpu.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b((?:huf|hufgpu)_[a-z0-9_]+)\s*\(", text))
+    declared -= {"huf_error_t", "huf_config_t"}
+    assert len(declared) >= 60
+    missing = sorted(s for s in declared if not hasattr(L, s))
+    assert not missing, missing
+    # the reference's full export list, incl. the non-static stream callbacks
+    assert not [s for s in N.HOST_SYMBOLS if not hasattr(L, s)]
+    assert len(N.HOST_SYMBOLS) == 48   # nm -D of the reference .so lists 48 (SURVEY App. E text says 47)
+
+
+def test_struct_layouts_are_the_reference_abi():
+    assert C.sizeof(N.Config) == 48 and C.sizeof(N.ReadWriter) == 24
+    assert N.Config.reader.offset == 32 and N.Config.writer.offset == 40
+
+
+def test_error_strings(L):
+    want = {0: "Success", 3: "Failed on read/write operation", 4: "Fatal error",
+            5: "Block is corrupted, Huffman tree has impossible size",
+            6: "Huffman tree is corrupted and cannot be used to decode the block",
+            7: "Unknown error", -1: "Unknown error", 8: "Unknown error"}    # src/errors.c:5-33
+    for code, text in want.items():
+        assert L.huf_error_string(code).decode() == text
+
+
+def _memopen(L, cap):
+    rw, buf = C.POINTER(N.ReadWriter)(), C.c_void_p()
+    assert L.huf_memopen(C.byref(rw), C.byref(buf), cap) == 0
+    return rw, buf
+
+
+def _free(buf):
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(buf)
+
+
+def test_memstream_semantics(L):
+    """test/io_test.c:11-94."""
+    rw, buf = _memopen(L, 2)
+    n, cap = C.c_size_t(), C.c_size_t()
+    assert rw.contents.write(rw.contents.stream, b"ab", 2) == 0
+    L.huf_memlen(rw, C.byref(n)); L.huf_memcap(rw, C.byref(cap))
+    assert (n.value, cap.value) == (2, 2)
+    before = buf.value
+    assert rw.contents.write(rw.contents.stream, b"cdefghij", 8) == 0        # growth 2 -> 16
+    L.huf_memlen(rw, C.byref(n)); L.huf_memcap(rw, C.byref(cap))
+    assert (n.value, cap.value) == (10, 16) and buf.value != before            # io_test.c:53,61
+    assert C.string_at(buf.value, 10) == b"abcdefghij"
+    # the growth case the reference under-allocates (cap 16, len 10, count 30 -> needs 40)
+    assert rw.contents.write(rw.contents.stream, b"x" * 30, 30) == 0
+    L.huf_memlen(rw, C.byref(n)); L.huf_memcap(rw, C.byref(cap))
+    assert n.value == 40 and cap.value >= 40
+    # short read returns the count, the next read returns 0 (io_test.c:75-90)
+    out = C.create_string_buffer(64)
+    want = C.c_size_t(64)
+    assert rw.contents.read(rw.contents.stream, out, C.byref(want)) == 0 and want.value == 40
+    want = C.c_size_t(64)
+    assert rw.contents.read(rw.contents.stream, out, C.byref(want)) == 0 and want.value == 0
+    assert L.huf_memrewind(rw) == 0                                            # truncate
+    L.huf_memlen(rw, C.byref(n))
+    assert n.value == 0
+    assert L.huf_memclose(C.byref(rw)) == 0 and not rw                        # does not free *buf
+    _free(buf)
+
+
+def test_fd_stream_roundtrip(L, tmp_path):
+    path = tmp_path / "f.bin"
+    fd = os.open(path, os.O_CREAT | os.O_RDWR)
+    rw = C.POINTER(N.ReadWriter)()
+    assert L.huf_fdopen(C.byref(rw), fd) == 0
+    assert rw.contents.write(rw.contents.stream, b"hello world", 11) == 0
+    os.lseek(fd, 0, os.SEEK_SET)
+    out, want = C.create_string_buffer(32), C.c_size_t(32)
+    assert rw.contents.read(rw.contents.stream, out, C.byref(want)) == 0
+    assert want.value == 11 and out.raw[:11] == b"hello world"
+    assert L.huf_fdclose(C.byref(rw)) == 0
+    os.close(fd)
+
+
+class _Hist(C.Structure):
+    _fields_ = [("frequencies", C.POINTER(C.c_uint64)), ("iota", C.c_size_t),
+                ("length", C.c_size_t), ("start", C.c_size_t)]
+
+
+def test_histogram_host_api(L):
+    """test/histogram_test.c: init values, 4-byte-wide elements, accumulation, start, reset."""
+    h = C.POINTER(_Hist)()
+    assert L.huf_histogram_init(C.byref(h), 4, 10) == 0
+    assert h.contents.start == (1 << 64) - 1 and h.contents.length == 10       # :20-22
+    arr = np.array([1, 2, 3, 3, 5, 9, 9, 9], dtype="<u4")
+    assert L.huf_histogram_populate(h, arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0
+    assert [h.contents.frequencies[i] for i in range(10)] == [0, 1, 1, 2, 0, 1, 0, 0, 0, 3]
+    assert h.contents.start == 1
+    assert L.huf_histogram_populate(h, arr.ctypes.data_as(C.c_void_p), arr.nbytes) == 0
+    assert h.contents.frequencies[9] == 6                                       # accumulates (:36-56)
+    assert L.huf_histogram_reset(h) == 0
+    assert all(h.contents.frequencies[i] == 0 for i in range(10)) and h.contents.start == (1 << 64) - 1
+    assert L.huf_histogram_free(C.byref(h)) == 0 and not h
+
+
+class _Node(C.Structure):
+    pass
+
+
+_Node._fields_ = [("index", C.c_int16), ("parent", C.POINTER(_Node)), ("left", C.POINTER(_Node)),
+                  ("right", C.POINTER(_Node))]
+
+
+class _Tree(C.Structure):
+    _fields_ = [("leaves", C.POINTER(C.POINTER(_Node))), ("root", C.POINTER(_Node))]
+
+
+def test_tree_host_api_single_symbol_shape(L):
+    """test/tree_test.c:12-35: {3,3,3,3} -> root 256, left = leaf 3, right = NULL."""
+    h, t = C.POINTER(_Hist)(), C.POINTER(_Tree)()
+    assert L.huf_histogram_init(C.byref(h), 1, 512) == 0 and L.huf_tree_init(C.byref(t)) == 0
+    data = (C.c_uint8 * 4)(3, 3, 3, 3)
+    assert L.huf_histogram_populate(h, data, 4) == 0
+    assert L.huf_tree_from_histogram(t, h) == 0
+    root = t.contents.root.contents
+    assert root.index == 256 and not root.right
+    assert t.contents.leaves[3].contents.index == 3
+    assert C.addressof(root.left.contents) == C.addressof(t.contents.leaves[3].contents)
+    buf, n = (C.c_int16 * 1032)(), C.c_size_t()
+    assert L.huf_tree_serialize(t, buf, C.byref(n)) == 0
+    assert list(buf[: n.value]) == [256, 3, -1, -1, -1]
+    L.huf_tree_free(C.byref(t)); L.huf_histogram_free(C.byref(h))
+
+
+def test_tree_host_api_matches_oracle_serialization(L, oracle):
+    """The host tree builder is the same algorithm as the device kernel: compare its
+    serialization with the tree inside the oracle's stream for the README input."""
+    h, t = C.POINTER(_Hist)(), C.POINTER(_Tree)()
+    L.huf_histogram_init(C.byref(h), 1, 512); L.huf_tree_init(C.byref(t))
+    for data in (b"0123456789", b"abracadabra", bytes(range(256)) * 3 + b"zzzz"):
+        L.huf_histogram_reset(h); L.huf_tree_reset(t)
+        arr = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        assert L.huf_histogram_populate(h, arr, len(data)) == 0
+        assert L.huf_tree_from_histogram(t, h) == 0
+        buf, n = (C.c_int16 * 1032)(), C.c_size_t()
+        assert L.huf_tree_serialize(t, buf, C.byref(n)) == 0
+        stream = oracle.encode(data, 0)
+        tl = int(np.frombuffer(stream[8:10].tobytes(), "<i2")[0])
+        want = np.frombuffer(stream[10:10 + 2 * tl].tobytes(), "<i2").tolist()
+        assert list(buf[: n.value]) == want
+        # deserialize -> serialize is the identity
+        t2 = C.POINTER(_Tree)()
+        L.huf_tree_init(C.byref(t2))
+        assert L.huf_tree_deserialize(t2, buf, n.value) == 0
+        buf2, n2 = (C.c_int16 * 1032)(), C.c_size_t()
+        assert L.huf_tree_serialize(t2, buf2, C.byref(n2)) == 0
+        assert list(buf2[: n2.value]) == want
+        L.huf_tree_free(C.byref(t2))
+    L.huf_tree_free(C.byref(t)); L.huf_histogram_free(C.byref(h))
+
+
+class _Elem(C.Structure):
+    _fields_ = [("length", C.c_size_t), ("coding", C.POINTER(C.c_uint8))]
+
+
+def test_symbol_mapping_host_api(L):
+    """test/symbol_test.c: insert/get identity, overwrite, reset."""
+    m = C.c_void_p()
+    assert L.huf_symbol_mapping_init(C.byref(m), 256) == 0
+    e1, e2, got = C.POINTER(_Elem)(), C.POINTER(_Elem)(), C.POINTER(_Elem)()
+    assert L.huf_symbol_mapping_element_init(C.byref(e1), b"0101", 4) == 0
+    assert L.huf_symbol_mapping_element_init(C.byref(e2), b"11", 2) == 0
+    L.huf_symbol_mapping_insert.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.huf_symbol_mapping_get.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    assert L.huf_symbol_mapping_insert(m, 65, e1) == 0
+    assert L.huf_symbol_mapping_get(m, 65, C.byref(got)) == 0
+    assert got.contents.length == 4 and bytes(got.contents.coding[:4]) == b"0101"
+    assert L.huf_symbol_mapping_insert(m, 65, e2) == 0          # frees the previous element
+    L.huf_symbol_mapping_get(m, 65, C.byref(got))
+    assert got.contents.length == 2
+    assert L.huf_symbol_mapping_insert(m, 256, e2) == 2         # out of range
+    L.huf_symbol_mapping_reset.argtypes = [C.c_void_p]
+    assert L.huf_symbol_mapping_reset(m) == 0
+    L.huf_symbol_mapping_get(m, 65, C.byref(got))
+    assert not got
+    assert L.huf_symbol_mapping_free(C.byref(m)) == 0
+
+
+def test_bufio_and_bit_writer(L):
+    """huf_bit_write is MSB first (src/bufio.c:18-23); bufio passes through when capacity is 0
+    and counts accepted bytes."""
+    class Bit(C.Structure):
+        _fields_ = [("bits", C.c_uint8), ("offset", C.c_uint8)]
+    b = Bit()
+    L.huf_bit_read_writer_reset(C.byref(b))
+    assert (b.bits, b.offset) == (0, 8)
+    for bit in (1, 0, 1, 1):
+        L.huf_bit_write(C.byref(b), bit)
+    assert (b.bits, b.offset) == (0b10110000, 4)
+
+    class Bufio(C.Structure):
+        _fields_ = [("bytes", C.c_void_p), ("offset", C.c_size_t), ("capacity", C.c_size_t),
+                    ("length", C.c_size_t), ("processed", C.c_uint64), ("rw", C.c_void_p)]
+    for cap in (0, 5):
+        rw, buf = _memopen(L, 4)
+        io = C.POINTER(Bufio)()
+        assert L.huf_bufio_read_writer_init(C.byref(io), rw, cap) == 0
+        assert L.huf_bufio_write(io, b"abc", 3) == 0 and L.huf_bufio_write(io, b"defgh", 5) == 0
+        assert L.huf_bufio_write_uint8(io, 0x69) == 0
+        assert L.huf_bufio_read_writer_flush(io) == 0
+        n = C.c_size_t()
+        L.huf_memlen(rw, C.byref(n))
+        assert C.string_at(buf.value, n.value) == b"abcdefghi" and io.contents.processed == 9
+        # reading back through a second bufio: satisfied request, then a short one -> error 3
+        rd = C.POINTER(Bufio)()
+        L.huf_bufio_read_writer_init(C.byref(rd), rw, cap)
+        out = C.create_string_buffer(16)
+        assert L.huf_bufio_read(rd, out, 4) == 0 and out.raw[:4] == b"abcd"
+        byte = C.c_uint8()
+        assert L.huf_bufio_read_uint8(rd, C.byref(byte)) == 0 and byte.value == ord("e")
+        assert L.huf_bufio_read(rd, out, 10) == 3                               # bufio.c:251-253
+        assert rd.contents.processed == 5
+        L.huf_bufio_read_writer_free(C.byref(io)); L.huf_bufio_read_writer_free(C.byref(rd))
+        L.huf_memclose(C.byref(rw)); _free(buf)
+
+
+def test_argument_checks_instead_of_crashes(L):
+    """NULL config / reader / writer return INVALID_ARGUMENT."""
+    assert L.huf_encode(None) == 2 and L.huf_decode(None) == 2
+    cfg = N.Config(10, 0, 0, 0, None, None)
+    assert L.huf_encode(C.byref(cfg)) == 2 and L.huf_decode(C.byref(cfg)) == 2
+
+
+def test_zero_length_is_success_without_gpu(L):
+    """length == 0: nothing read, nothing written (encoder.c:288, decoder.c:218,
+    test/decode_test.c:32-36) - needs no device."""
+    rin, bin_ = _memopen(L, 16)
+    rout, bout = _memopen(L, 16)
+    cfg = N.Config(0, 0, 128, 128, rin, rout)
+    assert L.huf_decode(C.byref(cfg)) == 0 and L.huf_encode(C.byref(cfg)) == 0
+    n = C.c_size_t(1)
+    L.huf_memlen(rout, C.byref(n))
+    assert n.value == 0
+    for rw, b in ((rin, bin_), (rout, bout)):
+        L.huf_memclose(C.byref(rw)); _free(b)
+
+
+def test_no_gpu_is_a_loud_error(L, capfd):
+    """Without a gfx950 device the codec must fail with HUF_ERROR_FATAL - never fall back."""
+    if have_gpu(L):
+        pytest.skip("a GPU is present")
+    rin, bin_ = _memopen(L, 16)
+    rout, bout = _memopen(L, 16)
+    rin.contents.write(rin.contents.stream, b"0123456789", 10)
+    cfg = N.Config(10, 65536, 0, 0, rin, rout)
+    assert L.huf_encode(C.byref(cfg)) == 4
+    err = capfd.readouterr().err
+    assert "no CPU fallback" in err
+    ctx = C.c_void_p()
+    assert L.hufgpu_ctx_create(C.byref(ctx), 0) == 4 and not ctx
+    assert b"no CPU fallback" in L.hufgpu_last_error(None)
+    for rw, b in ((rin, bin_), (rout, bout)):
+        L.huf_memclose(C.byref(rw)); _free(b)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product package must never import, link or open anything under oracle/."""
+    pkg = os.path.join(ROOT, "libhuffman_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() or f == "datagen.py", os.path.join(dirpath, f)

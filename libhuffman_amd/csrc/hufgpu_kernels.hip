@@ -606,7 +606,7 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
 }
 
 /* ======================================================================================
- * decode_kernel - replaces huf_tree_deserialize (src/tree.c:138-227) and __huf_decode_block
+ * decode - replaces huf_tree_deserialize (src/tree.c:138-227) and __huf_decode_block
  * (src/decoder.c:34-96).
  *
  * One workgroup per block.
@@ -615,107 +615,48 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
  *     marker), entry j+1 is the left child of node j and the first later entry with the same
  *     S as j is its right child; entries after S reaches 0, or past the buffer, do not exist
  *     (tree.c:152-160: a missing entry is a NULL child).
- *  2. A 2^LUT_BITS-entry table in LDS maps the next LUT_BITS stream bits to {leaf, length},
- *     {inner node to continue the bit walk from} or {walk left the tree}.
- *  3. The payload is processed in segments of THREADS x SUB_BITS bits staged in LDS as
- *     big-endian words.  Every lane decodes one SUB_BITS subsequence.  Only the first lane
- *     knows where its first codeword starts; the others start at their subsequence boundary,
- *     then repeatedly restart from the end position their left neighbour reported until no
- *     start changes any more (self-synchronisation; worst case one lane per round, always
- *     exact).  Symbol counts are prefix-summed, the symbols are decoded once more into an LDS
- *     byte image aligned with the destination and stored coalesced.  Exactly block_len
- *     symbols are produced; pad bits are ignored (decoder.c:89-91).
+ *  2. Trees whose root has a single leaf child on the left (every block of one distinct byte,
+ *     e.g. BASELINE config 2) need no table: every symbol is one 0 bit, a 1 bit leaves the
+ *     tree.  The payload is checked for a set bit and the output is a fill.
+ *  3. Otherwise a 2^LUT_BITS-entry table in LDS maps the next LUT_BITS stream bits to
+ *     {leaf, length}, {inner node to continue the bit walk from} or {walk left the tree}.
+ *  4. The payload is processed in segments of THREADS x 128 bits, staged in LDS as big-endian
+ *     words in a [word-in-subsequence][lane] layout (lane-consecutive = bank-consecutive).
+ *     Every lane decodes one 128-bit subsequence through a 64-bit register bit buffer (one
+ *     LDS word per 32 bits consumed + one table read per symbol).  Only lane 0 knows where
+ *     its first codeword starts; the others start at their subsequence boundary and keep a
+ *     128-bit map of the codeword starts they found.  Each round a lane whose left neighbour
+ *     reported a different end position re-decodes from there only until it lands on a
+ *     codeword start it already knows (the tracks have merged; counts follow from popcounts),
+ *     until no start changes any more (self-synchronisation; exact for any stream, worst case
+ *     one lane per round).  Symbol counts are prefix-summed and the symbols are decoded once
+ *     more straight into HBM (32-bit stores, bytes at the edges).  Exactly block_len symbols
+ *     are produced; pad bits are ignored (decoder.c:89-91).
  * ==================================================================================== */
 #define DEC_LUT_BITS 12
-#define DEC_SUB_BITS 128
+#define DEC_SUB_WORDS 4               /* 128-bit subsequence per lane */
+#define DEC_SUB_BITS (32 * DEC_SUB_WORDS)
 #define DEC_NULL 0xffffu
-#define DEC_EXTRA_WORDS 40            /* > (1025 + LUT_BITS)/32: deepest possible bit walk */
-
-struct DecTree {
-    const uint16_t *left;
-    const uint16_t *right;
-    const int16_t *val;
-    const uint16_t *lut;
-    const uint32_t *pay;              /* staged segment, big-endian words */
-    uint64_t seg_bit0;                /* absolute payload bit of pay[0] bit 31 */
-    uint64_t pay_bits;                /* readable payload bits */
-};
-
-#define DEC_POS_EXHAUSTED (~0ull >> 1)   /* "a codeword ran past the readable payload" */
+#define DEC_XCOLS 10                  /* 40 extra words > (1025 + LUT_BITS)/32: deepest bit walk */
+#define DEC_EXH 0xffffffffu           /* "a codeword ran past the readable payload" */
 #define DEC_NO_BAD 0xffffffffu
 
-__device__ __forceinline__ uint32_t dec_window(const DecTree &t, uint64_t pos)
-{
-    const uint32_t rel = (uint32_t)(pos - t.seg_bit0);
-    const uint32_t w = rel >> 5, sh = rel & 31u;
-    const uint32_t hi = t.pay[w], lo = t.pay[w + 1];
-    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
-}
-
-/* Decode the codewords that start in [start, limit).  Returns the position of the first
- * codeword at or after limit (DEC_POS_EXHAUSTED if a codeword needs bits past the payload:
- * the reference would fail its next byte read there, src/decoder.c:53-56).
- *   WRITE = false: count only; a walk that leaves the tree is remembered in bad_at (symbols
- *           decoded before it) and decoding resumes one bit later.  On a speculative start
- *           that is harmless; once the starts have converged the first such event in stream
- *           order is the real error of src/decoder.c:69-71.
- *   WRITE = true : store at most omax symbols to s_out[obase..] and stop after them (or at
- *           the first walk that leaves the tree). */
-template <bool WRITE>
-__device__ __forceinline__ uint64_t dec_span(const DecTree &t, uint64_t start, uint64_t limit,
-                                             uint32_t &cnt, uint8_t *s_out, uint32_t obase,
-                                             uint32_t omax, uint32_t &bad_at)
-{
-    uint64_t pos = start;
-    uint32_t c = 0;
-    bad_at = DEC_NO_BAD;          /* symbols decoded before the first walk that left the tree */
-    while (pos < limit) {
-        if (WRITE && c >= omax) break;
-        const uint32_t win = dec_window(t, pos);
-        const uint32_t e = t.lut[win >> (32 - DEC_LUT_BITS)];
-        const uint32_t type = e >> 14;
-        uint64_t npos;
-        uint32_t symv;
-        bool ok = true;
-        if (type == 0) {
-            symv = e & 0xffu;
-            npos = pos + ((e >> 8) & 0xfu);
-        } else if (type == 1) {
-            uint32_t node = e & 0x7ffu;
-            uint64_t p = pos + DEC_LUT_BITS;
-            for (;;) {
-                if (p >= t.pay_bits) { p = t.pay_bits + 1; break; }   /* forces "exhausted" below */
-                const uint32_t bit = dec_window(t, p) >> 31;
-                p++;
-                const uint32_t nx = bit ? t.right[node] : t.left[node];
-                if (nx == DEC_NULL) { ok = false; break; }
-                node = nx;
-                if (t.left[node] == DEC_NULL && t.right[node] == DEC_NULL) break;
-            }
-            symv = (uint32_t)(uint8_t)t.val[node];
-            npos = p;
-        } else {
-            ok = false;
-            symv = 0;
-            npos = pos + ((e >> 8) & 0xfu);            /* bits read up to the missing child */
-        }
-        if (!ok) {
-            /* the failing bit must be a real payload bit for the failure to be real; otherwise
-             * the reference would have failed its byte read first (src/decoder.c:53-56) */
-            if (npos > t.pay_bits) { pos = DEC_POS_EXHAUSTED; break; }
-            if (bad_at == DEC_NO_BAD) bad_at = c;
-            if (WRITE) break;
-            pos += 1;
-            continue;
-        }
-        if (npos > t.pay_bits) { pos = DEC_POS_EXHAUSTED; break; }
-        if (WRITE) s_out[obase + c] = (uint8_t)symv;
-        pos = npos;
-        c++;
-    }
-    cnt = c;
-    return pos;
-}
+template <int THREADS>
+struct DecShared {
+    static constexpr int ENT = HUF_TREE_STRIDE;
+    static constexpr int COLS = THREADS + DEC_XCOLS;
+    int16_t ent[ENT];
+    uint16_t left[ENT];
+    uint16_t right[ENT];
+    uint16_t lut[1 << DEC_LUT_BITS];
+    uint32_t pay[DEC_SUB_WORDS][COLS];   /* pay[w][l] = word w of lane l's subsequence */
+    uint32_t end[THREADS];               /* end position of each lane, bits relative to the segment */
+    uint32_t part[THREADS / 64];
+    int efflen;
+    uint32_t badsym;                     /* segment symbol index of the first walk that left the tree */
+    uint32_t firstone;                   /* single-leaf trees: first set payload bit */
+    uint32_t qend;                       /* segment bit right after the block's last symbol */
+};
 
 /* big-endian 32-bit word of payload bytes [off, off+4), zero beyond nbytes */
 __device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, uint64_t nbytes)
@@ -735,41 +676,225 @@ __device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, 
     return v;
 }
 
-template <int THREADS>
-struct DecShared {
-    static constexpr int SEG_WORDS = THREADS * DEC_SUB_BITS / 32;
-    static constexpr int ENT = HUF_TREE_STRIDE;
-    static constexpr int OUT_BYTES = THREADS * DEC_SUB_BITS + 32;   /* 1-bit codes: a symbol per bit */
-    int16_t ent[ENT];
-    uint16_t open[ENT];        /* S(i) */
-    uint16_t left[ENT];
-    uint16_t right[ENT];
-    uint16_t lut[1 << DEC_LUT_BITS];
-    uint32_t pay[SEG_WORDS + DEC_EXTRA_WORDS];
-    uint64_t end[THREADS];
-    uint32_t part[THREADS / 64];
-    int efflen;
-    uint32_t badsym;           /* segment symbol index of the first walk that left the tree */
-    uint64_t qend;             /* payload bit right after the block's last symbol */
-    __attribute__((aligned(16))) uint8_t out[OUT_BYTES];
+/* 64-bit MSB-first bit buffer over the staged segment. */
+template <int COLS>
+struct BitReader {
+    const uint32_t (*pay)[COLS];
+    uint64_t acc;      /* next bits, left aligned */
+    uint32_t nb;       /* valid bits in acc (> 32 between calls) */
+    uint32_t g;        /* next segment word to load */
+
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[i & (DEC_SUB_WORDS - 1)][i / DEC_SUB_WORDS]; }
+    __device__ __forceinline__ void seek(uint32_t bit)
+    {
+        g = bit >> 5;
+        const uint32_t sh = bit & 31u;
+        acc = (((uint64_t)word(g) << 32) | word(g + 1)) << sh;
+        nb = 64 - sh;
+        g += 2;
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
+    __device__ __forceinline__ void skip(uint32_t n)        /* n <= 32 */
+    {
+        acc <<= n;
+        nb -= n;
+        if (nb <= 32) {
+            acc |= (uint64_t)word(g) << (32 - nb);
+            nb += 32;
+            g++;
+        }
+    }
 };
+
+enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
+
+/* Decode the codeword at `pos`. CW_OK: sym, npos = position after it (the reader is there too).
+ * CW_BAD: the walk left the tree; npos = position after the failing bit (reader undefined).
+ * CW_EXH: the walk needs bits past the readable payload. */
+template <int THREADS>
+__device__ __forceinline__ int dec_one(const DecShared<THREADS> &sh, BitReader<DecShared<THREADS>::COLS> &br,
+                                       uint32_t pos, uint32_t pay_rel, uint32_t &npos, uint32_t &sym)
+{
+    const uint32_t e = sh.lut[br.peek(DEC_LUT_BITS)];
+    const uint32_t type = e >> 14;
+    if (type == 0) {
+        const uint32_t n = (e >> 8) & 0xfu;
+        sym = e & 0xffu;
+        npos = pos + n;
+        br.skip(n);
+        return CW_OK;
+    }
+    if (type == 1) {
+        uint32_t node = e & 0x7ffu;
+        uint32_t p = pos + DEC_LUT_BITS;
+        br.skip(DEC_LUT_BITS);
+        for (;;) {
+            if (p >= pay_rel) return CW_EXH;
+            const uint32_t bit = br.peek(1);
+            br.skip(1);
+            p++;
+            const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+            if (nx == DEC_NULL) { npos = p; return CW_BAD; }
+            node = nx;
+            if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) break;
+        }
+        sym = (uint32_t)(uint8_t)sh.ent[node];
+        npos = p;
+        return CW_OK;
+    }
+    npos = pos + ((e >> 8) & 0xfu);      /* bits read up to the missing child */
+    return CW_BAD;
+}
+
+__device__ __forceinline__ uint32_t sel4(const uint32_t (&a)[4], uint32_t i)
+{
+    return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
+/* Per-lane decode state that survives the synchronisation rounds. */
+struct LaneTrack {
+    uint32_t start;    /* first codeword of this lane (segment bits) */
+    uint32_t end;      /* first codeword at/after the lane's limit, or DEC_EXH */
+    uint32_t cnt;      /* codewords that start inside the lane's subsequence */
+    uint32_t bad_pos;  /* position of the first walk that left the tree, DEC_NO_BAD if none */
+    uint32_t bm[4];    /* bit (p & 31) of bm[(p - sub_lo) >> 5]: a codeword was decoded at p */
+};
+
+/* Count pass.  MERGE = false: decode everything from `start`.  MERGE = true: `tr` holds the
+ * lane's previous track; decode from the new `start` only until a position the previous
+ * track also decoded at - from there on the two tracks are identical. */
+template <int THREADS, bool MERGE>
+__device__ __forceinline__ void dec_scan(const DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
+                                         uint32_t sub_lo, uint32_t pay_rel)
+{
+    const uint32_t limit = sub_lo + DEC_SUB_BITS;
+    uint32_t nbm[4] = {0u, 0u, 0u, 0u};
+    uint32_t c = 0, nbad = DEC_NO_BAD, pos = start;   /* nbad: position of the first bad walk */
+    bool merged = false;
+    if (pos < limit) {
+        BitReader<DecShared<THREADS>::COLS> br;
+        br.pay = sh.pay;
+        br.seek(pos);
+        while (pos < limit) {
+            const uint32_t lw = (pos - sub_lo) >> 5;
+            const uint32_t bit = 1u << (pos & 31u);
+            if (MERGE && (sel4(tr.bm, lw) & bit)) { merged = true; break; }
+            uint32_t npos, sym;
+            const int st = dec_one<THREADS>(sh, br, pos, pay_rel, npos, sym);
+            if (st == CW_OK) {
+                if (npos > pay_rel) { pos = DEC_EXH; break; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) nbm[k] |= (lw == (uint32_t)k) ? bit : 0u;
+                c++;
+                pos = npos;
+            } else if (st == CW_EXH || npos > pay_rel) {
+                /* the failing bit must be a real payload bit for the failure to be real; else
+                 * the reference would have failed its byte read first (decoder.c:53-56) */
+                pos = DEC_EXH;
+                break;
+            } else {
+                if (nbad == DEC_NO_BAD) nbad = pos;
+                pos += 1;                     /* resume one bit later (speculative starts only) */
+                br.seek(pos);
+            }
+        }
+    }
+    if (MERGE && merged) {
+        const uint32_t lwm = (pos - sub_lo) >> 5;
+        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word lwm before pos */
+        uint32_t old_before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = tr.bm[k];
+            if ((uint32_t)k < lwm) { old_before += __popc(w); tr.bm[k] = nbm[k]; }
+            else if ((uint32_t)k == lwm) { old_before += __popc(w & below); tr.bm[k] = (w & ~below) | nbm[k]; }
+        }
+        if (nbad != DEC_NO_BAD) tr.bad_pos = nbad;                 /* new prefix: before the merge point */
+        else if (tr.bad_pos != DEC_NO_BAD && tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;   /* was on the dead prefix */
+        tr.cnt = c + (tr.cnt - old_before);
+        /* tr.end unchanged */
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) tr.bm[k] = nbm[k];
+        tr.cnt = c;
+        tr.end = pos;
+        tr.bad_pos = nbad;
+    }
+    tr.start = start;
+}
+
+/* Codewords of the lane's track that start before `pos`. */
+__device__ __forceinline__ uint32_t track_count_before(const LaneTrack &tr, uint32_t pos, uint32_t sub_lo)
+{
+    if (pos <= sub_lo) return 0;
+    const uint32_t rel = pos - sub_lo;
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t lo = 32u * k;
+        if (rel >= lo + 32) n += __popc(tr.bm[k]);
+        else if (rel > lo) n += __popc(tr.bm[k] & ((1u << (rel - lo)) - 1u));
+    }
+    return n;
+}
+
+/* Write pass: the lane's first `quota` symbols go to g[0..quota). Returns the position after
+ * the last one.  The track has been validated by the count pass, so every codeword is CW_OK. */
+template <int THREADS>
+__device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
+                                              uint32_t quota, uint8_t *g)
+{
+    BitReader<DecShared<THREADS>::COLS> br;
+    br.pay = sh.pay;
+    br.seek(start);
+    uint32_t pos = start;
+    const uintptr_t ga = (uintptr_t)g;
+    uint32_t lo = (uint32_t)(ga & 3u);                    /* first byte of the current word that is ours */
+    uint32_t fill = lo;
+    uint32_t *gw = reinterpret_cast<uint32_t *>(ga - lo);
+    uint32_t wacc = 0;
+    for (uint32_t c = 0; c < quota; c++) {
+        uint32_t npos, sym;
+        (void)dec_one<THREADS>(sh, br, pos, pay_rel, npos, sym);
+        pos = npos;
+        wacc |= sym << (8 * fill);
+        if (++fill == 4) {
+            if (lo == 0) *gw = wacc;
+            else {
+                uint8_t *b = reinterpret_cast<uint8_t *>(gw);
+                for (uint32_t k = lo; k < 4; k++) b[k] = (uint8_t)(wacc >> (8 * k));
+            }
+            gw++;
+            wacc = 0;
+            fill = 0;
+            lo = 0;
+        }
+    }
+    if (fill > lo) {
+        uint8_t *b = reinterpret_cast<uint8_t *>(gw);
+        for (uint32_t k = lo; k < fill; k++) b[k] = (uint8_t)(wacc >> (8 * k));
+    }
+    return pos;
+}
 
 /* Decode one block whose header has been parsed.  `tree` points at the tree_len int16 entries,
  * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
  * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
- * symbol (valid on success). */
+ * symbol (valid on success); *produced_out = symbols delivered (also on failure). */
 template <int THREADS>
 __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
                             uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits,
                             uint64_t *produced_out)
 {
-    *produced_out = 0;
-    constexpr int SEG_WORDS = DecShared<THREADS>::SEG_WORDS;
     constexpr int ENT = DecShared<THREADS>::ENT;
+    constexpr int COLS = DecShared<THREADS>::COLS;
     const int tid = (int)threadIdx.x;
+    *produced_out = 0;
 
     /* ---- 1. tree ---- */
     __syncthreads();           /* previous user of sh is done */
+    uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0][0]);   /* S(i); payload not staged yet */
+    static_assert(sizeof(sh.pay) >= ENT * sizeof(uint16_t), "S(i) scratch must fit");
     for (int i = tid; i < ENT; i += THREADS) {
         int16_t v = -1;
         if (i < tree_len) v = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
@@ -777,7 +902,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         sh.left[i] = DEC_NULL;
         sh.right[i] = DEC_NULL;
     }
-    if (tid == 0) { sh.efflen = tree_len; sh.badsym = DEC_NO_BAD; sh.qend = 0; }
+    if (tid == 0) { sh.efflen = tree_len; sh.badsym = DEC_NO_BAD; sh.firstone = DEC_NO_BAD; sh.qend = 0; }
     __syncthreads();
     {
         constexpr int PER = (ENT + THREADS - 1) / THREADS;
@@ -797,7 +922,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         for (int k = 0; k < PER; k++) {
             const int i = tid * PER + k;
             if (i < ENT) {
-                sh.open[i] = (uint16_t)(run < 0 ? 0 : run);
+                s_open[i] = (uint16_t)(run < 0 ? 0 : run);
                 if (i < tree_len && run <= 0) atomicMin(&sh.efflen, i);
                 run += local[k];
             }
@@ -807,11 +932,11 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     const int eff = sh.efflen;
     for (int j = tid; j < eff; j += THREADS) {
         if (sh.ent[j] == -1) continue;
-        const uint16_t sj = sh.open[j];
+        const uint16_t sj = s_open[j];
         const int c = j + 1;
         if (c < eff && sh.ent[c] != -1) sh.left[j] = (uint16_t)c;
         for (int r = j + 2; r < eff; r++) {
-            if (sh.open[r] == sj) {
+            if (s_open[r] == sj) {
                 if (sh.ent[r] != -1) sh.right[j] = (uint16_t)r;
                 break;
             }
@@ -822,7 +947,46 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
      * the decision is BTREE_CORRUPTED */
     if (!(eff > 0 && sh.ent[0] != -1)) return HUFE_CORRUPTED;
 
-    /* ---- 2. lookup table ---- */
+    const uint8_t *pay = tree + 2 * tree_len;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+
+    /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
+    {
+        const uint32_t l0 = sh.left[0];
+        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL) {
+            const uint32_t symv = (uint32_t)(uint8_t)sh.ent[l0];
+            const uint64_t have = dmin<uint64_t>(block_len, pay_bits);       /* bits we may look at */
+            const uint64_t nwords = (have + 31) >> 5;
+            uint32_t first = DEC_NO_BAD;
+            for (uint64_t w = (uint64_t)tid; w < nwords; w += THREADS) {
+                uint32_t v = load_be32(pay, w * 4, pay_bytes);
+                const uint64_t left_bits = have - (w << 5);
+                if (left_bits < 32) v &= ~(0xffffffffu >> (uint32_t)left_bits);
+                if (v) { first = (uint32_t)dmin<uint64_t>(first, (w << 5) + (uint32_t)__clz(v)); break; }
+            }
+            if (first != DEC_NO_BAD) atomicMin(&sh.firstone, first);
+            __syncthreads();
+            const uint32_t fo = sh.firstone;
+            const uint64_t good = (fo != DEC_NO_BAD) ? (uint64_t)fo : have;
+            /* fill gout[0, good) */
+            const uint32_t rep = symv * 0x01010101u;
+            const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
+            if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
+            uint4 *q = reinterpret_cast<uint4 *>(gout + head);
+            const uint64_t nvec = (good - head) >> 4;
+            const uint4 v4 = make_uint4(rep, rep, rep, rep);
+            for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
+            const uint64_t tail0 = head + (nvec << 4);
+            if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
+            *produced_out = good;
+            if (fo != DEC_NO_BAD) return HUFE_CORRUPTED;                     /* decoder.c:69-71 */
+            if (have < block_len) return HUFE_RW;                            /* decoder.c:53-56 */
+            *end_bits = block_len;
+            return HUFE_OK;
+        }
+    }
+
+    /* ---- 3. lookup table ---- */
     for (int idx = tid; idx < (1 << DEC_LUT_BITS); idx += THREADS) {
         uint32_t node = 0, e = 2u << 14;
         bool done = false;
@@ -843,107 +1007,76 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     }
     __syncthreads();
 
-    /* ---- 3. payload ---- */
-    const uint8_t *pay = tree + 2 * tree_len;
-    DecTree t;
-    t.left = sh.left;
-    t.right = sh.right;
-    t.val = sh.ent;
-    t.lut = sh.lut;
-    t.pay = sh.pay;
-    t.pay_bits = pay_bytes * 8ull;
-
+    /* ---- 4. payload ---- */
     uint64_t true_start = 0;      /* bit where the next undecoded codeword starts */
     uint64_t produced = 0;        /* symbols written so far */
     int err = HUFE_OK;
+    const uint32_t sub_lo = (uint32_t)tid * DEC_SUB_BITS;
 
     while (produced < block_len) {
-        if (true_start >= t.pay_bits) { err = HUFE_RW; break; }          /* input exhausted */
+        if (true_start >= pay_bits) { err = HUFE_RW; break; }          /* input exhausted */
         /* segment origin: the 32-bit word that holds true_start */
         const uint64_t seg0 = true_start & ~31ull;
         const uint64_t byte0 = seg0 >> 3;
-        for (int i = tid; i < SEG_WORDS + DEC_EXTRA_WORDS; i += THREADS)
-            sh.pay[i] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
+        for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
+            sh.pay[i & (DEC_SUB_WORDS - 1)][i / DEC_SUB_WORDS] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
         __syncthreads();
-        t.seg_bit0 = seg0;
+        const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
+        const uint32_t first_start = (uint32_t)(true_start - seg0);
 
-        const uint64_t sub_lo = seg0 + (uint64_t)tid * DEC_SUB_BITS;
-        const uint64_t limit = sub_lo + DEC_SUB_BITS;
-        uint64_t start = (tid == 0) ? true_start : sub_lo;
-        uint32_t cnt = 0;
-        uint32_t bad_at = DEC_NO_BAD;
-        uint64_t end = start;
-        if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad_at);
-        sh.end[tid] = end;
+        LaneTrack tr;
+        dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+        sh.end[tid] = tr.end;
         __syncthreads();
         for (;;) {
-            uint64_t ns = (tid == 0) ? true_start : sh.end[tid - 1];
-            const int changed = (ns != start);
+            const uint32_t ns = (tid == 0) ? first_start : sh.end[tid - 1];
+            const int changed = (ns != tr.start);
             __syncthreads();                               /* everyone has read sh.end */
             if (changed) {
-                start = ns;
-                cnt = 0;
-                bad_at = DEC_NO_BAD;
-                end = start;
-                if (start < limit) end = dec_span<false>(t, start, limit, cnt, nullptr, 0, 0, bad_at);
-                sh.end[tid] = end;
+                dec_scan<THREADS, true>(sh, tr, ns, sub_lo, pay_rel);
+                sh.end[tid] = tr.end;
             }
             if (!__syncthreads_or(changed)) break;
         }
 
         /* output positions */
         uint32_t seg_total;
-        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(cnt, sh.part, seg_total);
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(tr.cnt, sh.part, seg_total);
         const uint64_t remaining = block_len - produced;
         /* the first walk that left the tree, in stream order, is a real error if it happens
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
          * Symbols decoded before it are still delivered, like the reference's writer does. */
-        if (bad_at != DEC_NO_BAD && (uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
+        if (tr.bad_pos != DEC_NO_BAD) {
+            const uint32_t bad_at = track_count_before(tr, tr.bad_pos, sub_lo);
+            if ((uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
+        }
         __syncthreads();
         const uint32_t badsym = sh.badsym;
         const uint32_t good = (badsym != DEC_NO_BAD) ? badsym : seg_total;
         const uint32_t take = (uint32_t)dmin<uint64_t>(good, remaining);
-        const uint32_t shift = (uint32_t)((uintptr_t)(gout + produced) & 15u);
-        /* (written as plain ifs: the select/min form of this was observed to misbehave when
-         * compiled inside this kernel by ROCm 7.2 hipcc - garbage lanes got a non-zero quota) */
-        uint32_t omax = 0;
+        /* (plain ifs: the select/min form of this was observed to misbehave when compiled inside
+         * the previous version of this kernel by ROCm 7.2 hipcc) */
+        uint32_t quota = 0;
         if (ex < take) {
-            omax = take - ex;
-            if (omax > cnt) omax = cnt;
+            quota = take - ex;
+            if (quota > tr.cnt) quota = tr.cnt;
         }
-        if (omax) {
-            uint32_t c2 = 0, bad2;
-            const uint64_t qe = dec_span<true>(t, start, limit, c2, sh.out, shift + ex, omax, bad2);
-            if (ex + omax == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
+        if (quota) {
+            const uint32_t qe = dec_write<THREADS>(sh, tr.start, pay_rel, quota, gout + produced + ex);
+            if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
         }
+        const uint32_t last_end = sh.end[THREADS - 1];
         __syncthreads();
-
-        /* copy out[shift, shift+take) -> gout[produced ...), 16-byte units aligned with HBM */
-        {
-            uint8_t *g16 = gout + produced - shift;       /* 16-byte aligned */
-            const uint32_t nunit = (shift + take + 15u) >> 4;
-            for (uint32_t u = tid; u < nunit; u += THREADS) {
-                const uint32_t lo = u << 4;
-                if (lo >= shift && lo + 16 <= shift + take) {
-                    *reinterpret_cast<uint4 *>(g16 + lo) = *reinterpret_cast<const uint4 *>(sh.out + lo);
-                } else {
-                    for (uint32_t k = 0; k < 16; k++) {
-                        const uint32_t bp = lo + k;
-                        if (bp >= shift && bp < shift + take) g16[bp] = sh.out[bp];
-                    }
-                }
-            }
-        }
         produced += take;
-        const uint64_t last_end = sh.end[THREADS - 1];
-        __syncthreads();
         if (badsym != DEC_NO_BAD) { err = HUFE_CORRUPTED; break; }
         if (produced < block_len) {
-            if (last_end == DEC_POS_EXHAUSTED) { err = HUFE_RW; break; }
-            true_start = last_end;
+            if (last_end == DEC_EXH) { err = HUFE_RW; break; }
+            true_start = seg0 + last_end;
+        } else {
+            true_start = seg0 + sh.qend;
         }
     }
-    if (err == HUFE_OK) *end_bits = sh.qend;
+    if (err == HUFE_OK) *end_bits = true_start;
     *produced_out = produced;
     return err;
 }

@@ -14,7 +14,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SO_PATH = os.path.join(PKG, "libhuffman.so")
+SO_PATH = os.environ.get("HUF_LIB_PATH") or os.path.join(PKG, "libhuffman.so")   # override: tooling experiments only
 SOURCES = ["hufgpu_api.hip", "huf_host.cpp"]
 DEPENDS = SOURCES + ["hufgpu_kernels.hip", "hufgpu_common.h",
                      os.path.join("..", "..", "include", "huffman.h"),

@@ -634,10 +634,12 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
  *     are produced; pad bits are ignored (decoder.c:89-91).
  * ==================================================================================== */
 #define DEC_LUT_BITS 12
-#define DEC_SUB_WORDS 4               /* 128-bit subsequence per lane */
+#ifndef DEC_SUB_WORDS
+#define DEC_SUB_WORDS 8               /* 32-bit words per lane subsequence (power of two) */
+#endif
 #define DEC_SUB_BITS (32 * DEC_SUB_WORDS)
 #define DEC_NULL 0xffffu
-#define DEC_XCOLS 10                  /* 40 extra words > (1025 + LUT_BITS)/32: deepest bit walk */
+#define DEC_XCOLS ((40 + DEC_SUB_WORDS - 1) / DEC_SUB_WORDS + 1)   /* >= 40 extra words > (1025 + LUT_BITS)/32: deepest bit walk */
 #define DEC_EXH 0xffffffffu           /* "a codeword ran past the readable payload" */
 #define DEC_NO_BAD 0xffffffffu
 
@@ -650,6 +652,7 @@ struct DecShared {
     uint16_t right[ENT];
     uint16_t lut[1 << DEC_LUT_BITS];
     uint32_t pay[DEC_SUB_WORDS][COLS];   /* pay[w][l] = word w of lane l's subsequence */
+    uint32_t bm[DEC_SUB_WORDS][THREADS]; /* bit (p & 31) of bm[(p - sub_lo) >> 5][l]: lane l decoded a codeword at p */
     uint32_t end[THREADS];               /* end position of each lane, bits relative to the segment */
     uint32_t part[THREADS / 64];
     int efflen;
@@ -746,30 +749,30 @@ __device__ __forceinline__ int dec_one(const DecShared<THREADS> &sh, BitReader<D
     return CW_BAD;
 }
 
-__device__ __forceinline__ uint32_t sel4(const uint32_t (&a)[4], uint32_t i)
-{
-    return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
-}
-
-/* Per-lane decode state that survives the synchronisation rounds. */
+/* Per-lane decode state that survives the synchronisation rounds (the map of codeword starts
+ * lives in sh.bm). */
 struct LaneTrack {
     uint32_t start;    /* first codeword of this lane (segment bits) */
     uint32_t end;      /* first codeword at/after the lane's limit, or DEC_EXH */
     uint32_t cnt;      /* codewords that start inside the lane's subsequence */
     uint32_t bad_pos;  /* position of the first walk that left the tree, DEC_NO_BAD if none */
-    uint32_t bm[4];    /* bit (p & 31) of bm[(p - sub_lo) >> 5]: a codeword was decoded at p */
 };
 
-/* Count pass.  MERGE = false: decode everything from `start`.  MERGE = true: `tr` holds the
- * lane's previous track; decode from the new `start` only until a position the previous
- * track also decoded at - from there on the two tracks are identical. */
+/* Count pass.  MERGE = false: decode everything from `start`.  MERGE = true: `tr`/sh.bm hold the
+ * lane's previous track; decode from the new `start` only until a position the previous track
+ * also decoded at - from there on the two tracks are identical.  The bit map is updated word by
+ * word as the position leaves each word (bits of the old track behind the position are dead). */
 template <int THREADS, bool MERGE>
-__device__ __forceinline__ void dec_scan(const DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
+__device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
                                          uint32_t sub_lo, uint32_t pay_rel)
 {
+    const int tid = (int)threadIdx.x;
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
-    uint32_t nbm[4] = {0u, 0u, 0u, 0u};
     uint32_t c = 0, nbad = DEC_NO_BAD, pos = start;   /* nbad: position of the first bad walk */
+    uint32_t cur_lw = 0;          /* word being filled */
+    uint32_t newbits = 0;         /* new track's bits in word cur_lw */
+    uint32_t oldw = MERGE ? sh.bm[0][tid] : 0u;       /* previous track's bits in word cur_lw */
+    uint32_t old_before = 0;      /* previous track's codewords in the words already left */
     bool merged = false;
     if (pos < limit) {
         BitReader<DecShared<THREADS>::COLS> br;
@@ -777,14 +780,24 @@ __device__ __forceinline__ void dec_scan(const DecShared<THREADS> &sh, LaneTrack
         br.seek(pos);
         while (pos < limit) {
             const uint32_t lw = (pos - sub_lo) >> 5;
+            if (lw != cur_lw) {                        /* leave cur_lw (and skip words in between) */
+                sh.bm[cur_lw][tid] = newbits;
+                old_before += __popc(oldw);
+                for (uint32_t k = cur_lw + 1; k < lw; k++) {
+                    if (MERGE) old_before += __popc(sh.bm[k][tid]);
+                    sh.bm[k][tid] = 0;
+                }
+                cur_lw = lw;
+                newbits = 0;
+                if (MERGE) oldw = sh.bm[lw][tid];
+            }
             const uint32_t bit = 1u << (pos & 31u);
-            if (MERGE && (sel4(tr.bm, lw) & bit)) { merged = true; break; }
+            if (MERGE && (oldw & bit)) { merged = true; break; }
             uint32_t npos, sym;
             const int st = dec_one<THREADS>(sh, br, pos, pay_rel, npos, sym);
             if (st == CW_OK) {
                 if (npos > pay_rel) { pos = DEC_EXH; break; }
-#pragma unroll
-                for (int k = 0; k < 4; k++) nbm[k] |= (lw == (uint32_t)k) ? bit : 0u;
+                newbits |= bit;
                 c++;
                 pos = npos;
             } else if (st == CW_EXH || npos > pay_rel) {
@@ -800,22 +813,16 @@ __device__ __forceinline__ void dec_scan(const DecShared<THREADS> &sh, LaneTrack
         }
     }
     if (MERGE && merged) {
-        const uint32_t lwm = (pos - sub_lo) >> 5;
-        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word lwm before pos */
-        uint32_t old_before = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t w = tr.bm[k];
-            if ((uint32_t)k < lwm) { old_before += __popc(w); tr.bm[k] = nbm[k]; }
-            else if ((uint32_t)k == lwm) { old_before += __popc(w & below); tr.bm[k] = (w & ~below) | nbm[k]; }
-        }
+        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word cur_lw before pos */
+        old_before += __popc(oldw & below);
+        sh.bm[cur_lw][tid] = (oldw & ~below) | newbits;
         if (nbad != DEC_NO_BAD) tr.bad_pos = nbad;                 /* new prefix: before the merge point */
         else if (tr.bad_pos != DEC_NO_BAD && tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;   /* was on the dead prefix */
         tr.cnt = c + (tr.cnt - old_before);
         /* tr.end unchanged */
     } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) tr.bm[k] = nbm[k];
+        sh.bm[cur_lw][tid] = newbits;
+        for (uint32_t k = cur_lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
         tr.cnt = c;
         tr.end = pos;
         tr.bad_pos = nbad;
@@ -824,16 +831,17 @@ __device__ __forceinline__ void dec_scan(const DecShared<THREADS> &sh, LaneTrack
 }
 
 /* Codewords of the lane's track that start before `pos`. */
-__device__ __forceinline__ uint32_t track_count_before(const LaneTrack &tr, uint32_t pos, uint32_t sub_lo)
+template <int THREADS>
+__device__ __forceinline__ uint32_t track_count_before(const DecShared<THREADS> &sh, uint32_t pos, uint32_t sub_lo)
 {
     if (pos <= sub_lo) return 0;
     const uint32_t rel = pos - sub_lo;
     uint32_t n = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < DEC_SUB_WORDS; k++) {
         const uint32_t lo = 32u * k;
-        if (rel >= lo + 32) n += __popc(tr.bm[k]);
-        else if (rel > lo) n += __popc(tr.bm[k] & ((1u << (rel - lo)) - 1u));
+        const uint32_t w = sh.bm[k][threadIdx.x];
+        if (rel >= lo + 32) n += __popc(w);
+        else if (rel > lo) n += __popc(w & ((1u << (rel - lo)) - 1u));
     }
     return n;
 }
@@ -930,17 +938,40 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     }
     __syncthreads();
     const int eff = sh.efflen;
-    for (int j = tid; j < eff; j += THREADS) {
-        if (sh.ent[j] == -1) continue;
-        const uint16_t sj = s_open[j];
-        const int c = j + 1;
-        if (c < eff && sh.ent[c] != -1) sh.left[j] = (uint16_t)c;
-        for (int r = j + 2; r < eff; r++) {
-            if (s_open[r] == sj) {
-                if (sh.ent[r] != -1) sh.right[j] = (uint16_t)r;
-                break;
+    /* Child links from subtree sizes: size(marker) = 1, size(node) = 1 + size(left) + size(right),
+     * left child of node j is entry j+1, right child is entry j+1+size(j+1); entries at or past
+     * `eff` do not exist (size 0, NULL).  Sizes become known bottom-up, one tree level per round
+     * (s_open is reused as the size array, 0 = not known yet). */
+    __syncthreads();
+    uint16_t *s_size = s_open;
+    for (int i = tid; i < ENT; i += THREADS) s_size[i] = (i < eff && sh.ent[i] == -1) ? 1 : 0;
+    __syncthreads();
+    for (int round = 0; round < ENT; round++) {
+        int progress = 0;
+        for (int j = tid; j < eff; j += THREADS) {
+            if (s_size[j] != 0) continue;                 /* marker or already done */
+            const int l = j + 1;
+            uint32_t sl = 0, sr = 0;
+            bool ready = true;
+            if (l < eff) {
+                sl = s_size[l];
+                if (sl == 0) ready = false;
+                else {
+                    const int r = l + (int)sl;
+                    if (r < eff) {
+                        sr = s_size[r];
+                        if (sr == 0) ready = false;
+                        else if (sh.ent[r] != -1) sh.right[j] = (uint16_t)r;
+                    }
+                }
+                if (ready && sh.ent[l] != -1) sh.left[j] = (uint16_t)l;
+            }
+            if (ready) {
+                s_size[j] = (uint16_t)(1 + sl + sr);
+                progress = 1;
             }
         }
+        if (!__syncthreads_or(progress)) break;
     }
     __syncthreads();
     /* tree_len == 0 or a tree that starts with -1 is a NULL root: the reference crashes,
@@ -949,6 +980,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 
     const uint8_t *pay = tree + 2 * tree_len;
     const uint64_t pay_bits = pay_bytes * 8ull;
+#if defined(DEC_ABLATE) && DEC_ABLATE == 1
+    *end_bits = 0; return HUFE_OK;
+#endif
 
     /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
     {
@@ -1007,6 +1041,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     }
     __syncthreads();
 
+#if defined(DEC_ABLATE) && DEC_ABLATE == 2
+    *end_bits = 0; return HUFE_OK;
+#endif
     /* ---- 4. payload ---- */
     uint64_t true_start = 0;      /* bit where the next undecoded codeword starts */
     uint64_t produced = 0;        /* symbols written so far */
@@ -1028,7 +1065,13 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
         sh.end[tid] = tr.end;
         __syncthreads();
+#if defined(DEC_ABLATE) && DEC_ABLATE == 5
+        int dbg_rounds = 0, dbg_changed_total = 0;
+#endif
         for (;;) {
+#if defined(DEC_ABLATE) && DEC_ABLATE == 3
+            break;
+#endif
             const uint32_t ns = (tid == 0) ? first_start : sh.end[tid - 1];
             const int changed = (ns != tr.start);
             __syncthreads();                               /* everyone has read sh.end */
@@ -1036,8 +1079,15 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 dec_scan<THREADS, true>(sh, tr, ns, sub_lo, pay_rel);
                 sh.end[tid] = tr.end;
             }
+#if defined(DEC_ABLATE) && DEC_ABLATE == 5
+            dbg_rounds++;
+            dbg_changed_total += __syncthreads_count(changed);
+#endif
             if (!__syncthreads_or(changed)) break;
         }
+#if defined(DEC_ABLATE) && DEC_ABLATE == 5
+        if (tid == 0 && blockIdx.x == 7) printf("seg0=%llu rounds=%d changed_total=%d\n", (unsigned long long)seg0, dbg_rounds, dbg_changed_total);
+#endif
 
         /* output positions */
         uint32_t seg_total;
@@ -1047,7 +1097,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
          * Symbols decoded before it are still delivered, like the reference's writer does. */
         if (tr.bad_pos != DEC_NO_BAD) {
-            const uint32_t bad_at = track_count_before(tr, tr.bad_pos, sub_lo);
+            const uint32_t bad_at = track_count_before<THREADS>(sh, tr.bad_pos, sub_lo);
             if ((uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
         }
         __syncthreads();
@@ -1061,6 +1111,10 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             quota = take - ex;
             if (quota > tr.cnt) quota = tr.cnt;
         }
+#if defined(DEC_ABLATE) && DEC_ABLATE == 4
+        quota = 0;
+        if (tid == 0) sh.qend = sh.end[THREADS - 1] == DEC_EXH ? pay_rel : sh.end[THREADS - 1];
+#endif
         if (quota) {
             const uint32_t qe = dec_write<THREADS>(sh, tr.start, pay_rel, quota, gout + produced + ex);
             if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */

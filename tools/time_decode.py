@@ -1,0 +1,22 @@
+"""Times hufgpu_decode kernels for one library build (HUF_LIB_PATH) without checking results."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from libhuffman_amd.codec import GpuCodec
+wl = sys.argv[1] if len(sys.argv) > 1 else "zipf255"
+n, bs = 1 << 30, 65536
+c = GpuCodec(0)
+data = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(data, wl)
+# the stream comes from this build's own encoder (encode is not ablated)
+out, offs, length = c.encode(data, bs)
+back = torch.empty(n, dtype=torch.uint8, device="cuda")
+nb = c.block_count(n, bs)
+for _ in range(2):
+    try: c.decode(out, length, offs, nb, back, relaxed=True)
+    except Exception as e: pass
+c.set_profiling(True)
+for _ in range(5):
+    try: c.decode(out, length, offs, nb, back, relaxed=True)
+    except Exception as e: pass
+prof, calls = c.profile("decode")
+print(os.environ.get("HUF_LIB_PATH", "default"), wl, {k: round(v / calls, 3) for k, v in prof.items()})

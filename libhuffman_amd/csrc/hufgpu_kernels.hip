@@ -359,44 +359,185 @@ __global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta 
  * pack_kernel - replaces the header emission (src/encoder.c:322-339) and __huf_encode_block
  * + huf_bit_write (src/encoder.c:85-131, src/bufio.c:18-23).
  *
- * One workgroup per block.  The block record [u64 len][i16 tree_len][tree][payload] is built
- * in an LDS image of big-endian 32-bit words whose word 0 is the 4-byte-aligned global word
- * that contains the record's first byte, so bit b of the stream (MSB first inside each byte)
- * is simply bit 31-(b&31) of word b>>5, and a finished word is byte-swapped and stored.
+ * One workgroup per block.  The block record [u64 len][i16 tree_len][tree][payload] is a bit
+ * string that starts at byte offsets[blk] of the output; it is produced as big-endian 32-bit
+ * words aligned with the 4-byte words of the destination (stream bit b, MSB first inside each
+ * byte, is bit 31-(b&31) of word b>>5; a finished word is byte-swapped and stored).
  *
- * Payload tiles of THREADS*16 symbols: every lane loads 16 contiguous input bytes, looks the
- * codes up in the LDS table, the workgroup prefix-sums the per-lane bit counts, and each
- * lane shifts its codes into a 64-bit accumulator and writes whole words: plain LDS stores
- * for words it owns entirely, atomic OR for its first and last word, which it may share
- * with a neighbour.  Finished words are flushed to HBM coalesced; the partial last word is
- * carried into the next tile.  First/last word of the record are byte-masked because the
- * neighbouring blocks (other workgroups) own the rest of those words.
+ * Payload tiles of THREADS*32 symbols.  Every lane loads 32 contiguous input bytes, looks the
+ * codes up in the LDS table and keeps them in registers; the workgroup prefix-sums the per-lane
+ * bit counts; then each lane shifts its codes through a 64-bit accumulator and stores every
+ * word that ENDS inside its bit range straight to HBM.  32 symbols are at least 32 bits, so
+ * every lane owns at least one word end: the only thing a lane needs from its left neighbour
+ * is the neighbour's unfinished tail (< 32 bits), one __shfl_up (LDS for the wave seams, the
+ * header tail / previous tile for lane 0).  No LDS image, no atomics.  The record's first and
+ * last word are byte-masked because neighbouring blocks own the rest of those words.
  * ==================================================================================== */
-#define PACK_SYMS_PER_LANE 16
+#define PACK_SPT 32
 
-struct PackImage {
-    uint32_t *words;      /* LDS image */
-    uint64_t  win_word;   /* absolute word index (relative to A0) of words[0] */
+template <typename CodeT>
+struct PackAcc {
+    uint64_t acc;       /* right-aligned bits not yet emitted */
+    uint32_t nacc;      /* number of them (< 32 between pushes) */
+    uint32_t first;     /* first finished word (its leading bits belong to the left neighbour) */
+    bool have_first;
+    uint32_t *gw;       /* where the next finished word goes */
+
+    __device__ __forceinline__ void emit(uint32_t word)
+    {
+        if (!have_first) { first = word; have_first = true; }
+        else *gw = __builtin_bswap32(word);
+        gw++;
+    }
+    __device__ __forceinline__ void push32(uint32_t code, uint32_t len)     /* len <= 32 */
+    {
+        acc = (acc << len) | code;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            emit((uint32_t)(acc >> nacc));
+        }
+    }
+    __device__ __forceinline__ void push(CodeT e)
+    {
+        uint32_t len = (uint32_t)(e & 0xffu);
+        if constexpr (sizeof(CodeT) == 8) {
+            const uint64_t c = e >> 8;
+            if (len > 32) {                      /* long code: high part first */
+                push32((uint32_t)(c >> 32), len - 32);
+                len = 32;
+            }
+            push32((uint32_t)c, len);
+        } else {
+            push32((uint32_t)(e >> 8), len);
+        }
+    }
 };
 
-template <int THREADS>
-__device__ __forceinline__ void pack_flush(uint32_t *s_img, uint32_t nwords, uint64_t win_word,
-                                           uint8_t *__restrict__ g_a0, uint64_t rec_lo, uint64_t rec_hi)
+/* byte j of the block header (encoder.c:325-339, little-endian fields) */
+__device__ __forceinline__ uint32_t header_byte(uint32_t j, uint64_t block_len, uint32_t tree_len,
+                                                const int16_t *__restrict__ tb)
 {
-    /* words [0, nwords) of the image are complete; byte range of the record relative to A0
-     * is [rec_lo, rec_hi): only those bytes may be written. */
-    for (uint32_t i = threadIdx.x; i < nwords; i += THREADS) {
-        const uint64_t byte0 = (win_word + i) << 2;
-        const uint32_t w = s_img[i];
-        if (byte0 >= rec_lo && byte0 + 4 <= rec_hi) {
-            *reinterpret_cast<uint32_t *>(g_a0 + byte0) = __builtin_bswap32(w);
+    if (j < 8) return (uint32_t)(block_len >> (8 * j)) & 0xffu;
+    if (j < 10) return (tree_len >> (8 * (j - 8))) & 0xffu;
+    const uint16_t e = (uint16_t)tb[(j - 10) >> 1];
+    return (e >> (8 * (j & 1))) & 0xffu;
+}
+
+template <int THREADS, typename CodeT>
+__device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint64_t len,
+                                           const hufcode_t *__restrict__ codes64,
+                                           const int16_t *__restrict__ tb, uint32_t tree_len,
+                                           uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
+                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail)
+{
+    constexpr int TILE = THREADS * PACK_SPT;
+    constexpr int WAVES = THREADS / 64;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    uint8_t *g_a0 = out + (dst0 & ~3ull);
+    const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
+    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
+    uint32_t *g_w0 = reinterpret_cast<uint32_t *>(g_a0);
+
+    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = (CodeT)codes64[i];
+
+    /* ---- header: whole aligned words are stored here, the unfinished last word becomes the
+     *      incoming tail of the payload's first lane ---- */
+    const uint32_t hdr_bytes = HUF_HEADER_FIXED + 2u * tree_len;
+    const uint32_t hdr_end = rec_lo + hdr_bytes;                 /* relative to A0 */
+    for (uint32_t w = tid; w < (hdr_end >> 2); w += THREADS) {
+        uint32_t v = 0;                                          /* little-endian memory word */
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t bp = 4 * w + k;
+            if (bp >= rec_lo) v |= header_byte(bp - rec_lo, len, tree_len, tb) << (8 * k);
+        }
+        if (4 * w >= rec_lo) g_w0[w] = v;
+        else {
+            for (uint32_t k = rec_lo - 4 * w; k < 4; k++) g_a0[4 * w + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+    if (tid == 0) {
+        uint32_t t = 0;                                          /* big-endian partial word */
+        for (uint32_t bp = hdr_end & ~3u; bp < hdr_end; bp++)
+            t = (t << 8) | header_byte(bp - rec_lo, len, tree_len, tb);
+        s_tail[WAVES] = t;                                       /* carry: value of the (hdr_end&3)*8 leading bits */
+    }
+    __syncthreads();
+
+    uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
+
+    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
+        /* ---- load + look up ---- */
+        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SPT;
+        uint32_t nsym = 0;
+        CodeT code[PACK_SPT];
+        uint32_t mybits = 0;
+        if (my0 < len) {
+            nsym = (uint32_t)dmin<uint64_t>(PACK_SPT, len - my0);
+            const uint8_t *p = src + my0;
+            if (nsym == PACK_SPT && (((uintptr_t)p) & 15u) == 0) {
+                const uint4 v0 = reinterpret_cast<const uint4 *>(p)[0];
+                const uint4 v1 = reinterpret_cast<const uint4 *>(p)[1];
+                const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k++) code[k] = s_code[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+            } else {
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k++) code[k] = (k < (int)nsym) ? s_code[p[k]] : (CodeT)0;
+            }
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) mybits += (uint32_t)(code[k] & 0xffu);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t bp = byte0 + k;
-                if (bp >= rec_lo && bp < rec_hi) g_a0[bp] = (uint8_t)(w >> (24 - 8 * k));
-            }
+            for (int k = 0; k < PACK_SPT; k++) code[k] = 0;
         }
+        uint32_t tile_bits;
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
+
+        /* ---- shift the codes out ---- */
+        const uint64_t s = bitpos + ex;                          /* my first bit */
+        PackAcc<CodeT> a;
+        a.acc = 0;
+        a.nacc = (uint32_t)(s & 31u);                            /* leading bits come from the left */
+        a.have_first = false;
+        a.first = 0;
+        a.gw = g_w0 + (s >> 5);
+        uint32_t *const first_gw = a.gw;
+#pragma unroll
+        for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);      /* absent symbols have len 0 */
+        const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
+
+        /* ---- tails hop one lane to the right ---- */
+        uint32_t in_tail = (uint32_t)__shfl_up((int)tail_val, 1);
+        if (lane == 63) s_tail[wave] = tail_val;
+        __syncthreads();
+        if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];
+        const uint32_t n_in = (uint32_t)(s & 31u);
+        const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
+        if (a.have_first) {
+            *first_gw = __builtin_bswap32(a.first | (n_in ? (in_tail << (32 - n_in)) : 0u));
+        }
+        uint32_t out_tail = tail_val;
+        if (!a.have_first && nsym > 0) {
+            /* only the block's last lane can be shorter than a word: its tail continues the
+             * neighbour's */
+            out_tail = (n_in ? (in_tail << (a.nacc - n_in)) : 0u) | tail_val;
+        }
+        if (is_last && a.nacc) {
+            /* zero-padded final byte(s) (encoder.c:123-128); bytes past the record belong to
+             * the next block */
+            const uint32_t word = out_tail << (32 - a.nacc);
+            const uint32_t nbytes = (a.nacc + 7) >> 3;
+            uint8_t *b = reinterpret_cast<uint8_t *>(a.gw);
+            for (uint32_t k = 0; k < nbytes; k++) b[k] = (uint8_t)(word >> (24 - 8 * k));
+        }
+        __syncthreads();                                         /* s_tail is rewritten next tile */
+        if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
+        bitpos += tile_bits;
+        (void)rec_hi;
     }
 }
 
@@ -409,144 +550,22 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ offsets,
                                                        uint8_t *__restrict__ out)
 {
-    constexpr int TILE = THREADS * PACK_SYMS_PER_LANE;
-    /* worst case per tile: TILE symbols of HUF_CODE_MAXBITS bits, + header tile, + carry */
-    constexpr int IMG_WORDS = TILE * HUF_CODE_MAXBITS / 32 + 8;
-    static_assert(IMG_WORDS * 4 >= HUF_HEADER_FIXED + 2 * HUF_TREE_MAX + 16, "header must fit");
-    __shared__ uint32_t s_img[IMG_WORDS];
-    __shared__ hufcode_t s_code[HUF_NSYM];
+    __shared__ hufcode_t s_code[HUF_NSYM];                       /* viewed as u32[256] on the short-code path */
     __shared__ uint32_t s_part[THREADS / 64];
+    __shared__ uint32_t s_tail[THREADS / 64 + 1];
 
-    const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
     const uint64_t len = dmin<uint64_t>(blocksize, n - base);
     const HufBlockMeta m = meta[blk];
-    const uint64_t dst0 = offsets[blk];
-    const uint64_t dst1 = offsets[blk + 1];
-
-    uint8_t *g_a0 = out + (dst0 & ~3ull);
-    const uint64_t rec_lo = dst0 & 3ull;                  /* record bytes relative to A0 */
-    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
-
-    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = codetab[blk * HUF_NSYM + i];
-    for (int i = tid; i < IMG_WORDS; i += THREADS) s_img[i] = 0;
-    __syncthreads();
-
-    /* ---- header (encoder.c:325-339): little-endian fields, placed bytewise ---- */
-    const uint32_t hdr_bytes = HUF_HEADER_FIXED + 2u * m.tree_len;
+    const hufcode_t *codes = codetab + blk * HUF_NSYM;
     const int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
-    for (uint32_t j = tid; j < hdr_bytes; j += THREADS) {
-        uint32_t byte;
-        if (j < 8) byte = (uint32_t)(len >> (8 * j)) & 0xffu;
-        else if (j < 10) byte = (m.tree_len >> (8 * (j - 8))) & 0xffu;
-        else {
-            const uint16_t e = (uint16_t)tb[(j - 10) >> 1];
-            byte = (e >> (8 * (j & 1))) & 0xffu;
-        }
-        const uint32_t bp = (uint32_t)rec_lo + j;
-        atomicOr(&s_img[bp >> 2], byte << (24 - 8 * (bp & 3)));
-    }
-    __syncthreads();
-
-    uint64_t bitpos = (rec_lo + hdr_bytes) * 8ull;        /* absolute, relative to A0 bit 0 */
-    uint64_t win_word = 0;
-    {
-        const uint32_t done = (uint32_t)(bitpos >> 5);
-        pack_flush<THREADS>(s_img, done, win_word, g_a0, rec_lo, rec_hi);
-        __syncthreads();
-        const uint32_t carry = s_img[done];
-        __syncthreads();
-        for (uint32_t i = tid; i <= done; i += THREADS) s_img[i] = 0;
-        __syncthreads();
-        if (tid == 0) s_img[0] = carry;
-        win_word = done;
-        __syncthreads();
-    }
-
-    /* ---- payload tiles ---- */
-    const uint8_t *src = in + base;
-    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
-        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SYMS_PER_LANE;
-        uint32_t nsym = 0;
-        uint8_t sym[PACK_SYMS_PER_LANE];
-        if (my0 < len) {
-            nsym = (uint32_t)dmin<uint64_t>(PACK_SYMS_PER_LANE, len - my0);
-            const uint8_t *p = src + my0;
-            if (nsym == PACK_SYMS_PER_LANE && (((uintptr_t)p) & 15u) == 0) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(p);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 16; k++) sym[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-            } else {
-#pragma unroll
-                for (int k = 0; k < PACK_SYMS_PER_LANE; k++) sym[k] = (k < (int)nsym) ? p[k] : 0;
-            }
-        }
-        hufcode_t code[PACK_SYMS_PER_LANE];
-        uint32_t mybits = 0;
-#pragma unroll
-        for (int k = 0; k < PACK_SYMS_PER_LANE; k++) {
-            code[k] = (k < (int)nsym) ? s_code[sym[k]] : 0;
-            mybits += (uint32_t)(code[k] & 0xffu);
-        }
-        uint32_t tile_bits;
-        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
-
-        /* emit this lane's bits */
-        if (mybits) {
-            const uint64_t rel = bitpos + ex - (win_word << 5);   /* bit index inside the image */
-            uint32_t w = (uint32_t)(rel >> 5);
-            uint32_t nacc = (uint32_t)(rel & 31);                 /* bits already used in word w */
-            uint64_t acc = 0;                                     /* left-aligned pending bits */
-            bool first = true;
-#pragma unroll
-            for (int k = 0; k < PACK_SYMS_PER_LANE; k++) {
-                uint32_t l = (uint32_t)(code[k] & 0xffu);
-                uint64_t c = code[k] >> 8;
-                if (l > 32) {                                     /* long code: high part first */
-                    const uint32_t lh = l - 32;
-                    acc |= (c >> 32) << (64 - nacc - lh);
-                    nacc += lh;
-                    if (nacc >= 32) {
-                        const uint32_t word = (uint32_t)(acc >> 32);
-                        if (first) { atomicOr(&s_img[w], word); first = false; }
-                        else s_img[w] = word;
-                        w++; acc <<= 32; nacc -= 32;
-                    }
-                    c &= 0xffffffffull;
-                    l = 32;
-                }
-                if (l) {
-                    acc |= c << (64 - nacc - l);
-                    nacc += l;
-                    if (nacc >= 32) {
-                        const uint32_t word = (uint32_t)(acc >> 32);
-                        if (first) { atomicOr(&s_img[w], word); first = false; }
-                        else s_img[w] = word;
-                        w++; acc <<= 32; nacc -= 32;
-                    }
-                }
-            }
-            if (nacc) atomicOr(&s_img[w], (uint32_t)(acc >> 32));
-        }
-        __syncthreads();
-
-        bitpos += tile_bits;
-        const uint32_t done = (uint32_t)((bitpos >> 5) - win_word);
-        pack_flush<THREADS>(s_img, done, win_word, g_a0, rec_lo, rec_hi);
-        __syncthreads();
-        const uint32_t carry = s_img[done];
-        __syncthreads();
-        for (uint32_t i = tid; i <= done; i += THREADS) s_img[i] = 0;
-        __syncthreads();
-        if (tid == 0) s_img[0] = carry;
-        win_word += done;
-        __syncthreads();
-    }
-
-    /* final partial word: zero-padded tail byte(s) (encoder.c:123-128) */
-    if (bitpos & 31) pack_flush<THREADS>(s_img, 1, win_word, g_a0, rec_lo, rec_hi);
+    if (m.max_len <= 24)
+        pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
+                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail);
+    else
+        pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
+                                       s_code, s_part, s_tail);
 }
 
 /* ======================================================================================

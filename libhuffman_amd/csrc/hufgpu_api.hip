@@ -349,7 +349,7 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
     STAGE_MARK(ctx, s);
     if (blocksize < (1ull << 22))
-        tree_kernel<uint32_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        tree_fast_kernel<<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
     else
         tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
     STAGE_MARK(ctx, s);
@@ -378,10 +378,20 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
     ctx->decode_pending = 0;
-    if (raw_len) *raw_len = ctx->h_result[1];
-    const int err = (int)ctx->h_result[0];
-    if (err == HUFE_ARGUMENT) set_err(ctx, "block %llu is longer than the kernels support", (unsigned long long)ctx->h_result[2]);
-    if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small (block %llu)", (unsigned long long)ctx->h_result[2]);
+    const uint64_t failing = ctx->h_result[2];
+    if (failing == ~0ull) {                        /* every block decoded */
+        if (raw_len) *raw_len = ctx->h_result[1];
+        return HUFE_OK;
+    }
+    /* first failing block in stream order: its error code, and the bytes of the blocks before it */
+    int32_t err = HUFE_FATAL;
+    uint64_t before = 0;
+    HIP_OK(ctx, hipMemcpyAsync(&err, ctx->d_status + failing, sizeof(err), hipMemcpyDeviceToHost, ctx->last_stream));
+    HIP_OK(ctx, hipMemcpyAsync(&before, ctx->d_out_offsets + failing, sizeof(before), hipMemcpyDeviceToHost, ctx->last_stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
+    if (raw_len) *raw_len = before;
+    if (err == HUFE_ARGUMENT) set_err(ctx, "block %llu is longer than the kernels support", (unsigned long long)failing);
+    if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small (block %llu)", (unsigned long long)failing);
     return err;
 }
 
@@ -405,13 +415,14 @@ extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t s
     const uint8_t *st = (const uint8_t *)d_stream;
 
     STAGE_BEGIN(ctx, s, PROF_DECODE);
-    decode_prepare_kernel<<<dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta);
+    unsigned long long *res = (unsigned long long *)ctx->d_result;
+    HIP_OK(ctx, hipMemsetAsync(ctx->d_result, 0xff, 4 * sizeof(uint64_t), s));   /* [2] = no failing block */
+    decode_prepare_kernel<<<dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta, ctx->d_status, res);
     STAGE_MARK(ctx, s);
-    scan_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_dmeta, nblocks, ctx->d_out_offsets);
+    scan_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_dmeta, nblocks, ctx->d_out_offsets, res);
     STAGE_MARK(ctx, s);
-    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, (uint8_t *)d_out, out_cap, ctx->d_status);
+    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, (uint8_t *)d_out, out_cap, ctx->d_status, res);
     STAGE_MARK(ctx, s);
-    decode_status_kernel<256><<<dim3(1), dim3(256), 0, s>>>(ctx->d_status, ctx->d_out_offsets, nblocks, ctx->d_result);
     HIP_OK(ctx, hipGetLastError());
     ctx->decode_pending = 1;
     ctx->last_stream = s;

@@ -330,6 +330,190 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
 }
 
 /* ======================================================================================
+ * tree_fast_kernel - same algorithm and outputs as tree_kernel<uint32_t>, tuned for the wave.
+ *   - At most 256 items are alive at any time (k leaves, one fewer after every merge), so the
+ *     live keys fit a pool of 4 registers per lane; the node created by a merge takes over the
+ *     pool position of the smaller of the two items it replaces.  A key still carries the
+ *     item's logical index (rate<<9 | 511-index), so the selection order is unchanged.
+ *   - The wave minimum is a DPP reduction (quad_perm, row_half_mirror, row_mirror, row_bcast15,
+ *     row_bcast31) ending in lane 63 and read back as a scalar: no LDS round trips in the loop.
+ *   - Children are written to LDS fire-and-forget; leaf counts are derived after the loop.
+ * ==================================================================================== */
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v, const int ctrl_sel)
+{
+    uint32_t o;
+    switch (ctrl_sel) {
+    case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); break;   /* quad_perm [1,0,3,2] */
+    case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); break;   /* quad_perm [2,3,0,1] */
+    case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); break;  /* row_half_mirror */
+    case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); break;  /* row_mirror */
+    case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); break;  /* row_bcast:15 -> rows 1,3 */
+    default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); break; /* row_bcast:31 -> rows 2,3 */
+    }
+    return dmin(v, o);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = dpp_min_step(v, 0);
+    v = dpp_min_step(v, 1);
+    v = dpp_min_step(v, 2);
+    v = dpp_min_step(v, 3);
+    v = dpp_min_step(v, 4);
+    v = dpp_min_step(v, 5);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restrict__ hist,
+                                                       hufcode_t *__restrict__ codetab,
+                                                       int16_t *__restrict__ treebuf,
+                                                       HufBlockMeta *__restrict__ meta)
+{
+    __shared__ int16_t s_left[HUF_NSLOT];
+    __shared__ int16_t s_right[HUF_NSLOT];
+    __shared__ uint16_t s_lcnt[HUF_NSLOT];    /* leaves below each slot, 0xffff = not known yet */
+    __shared__ uint16_t s_depth[HUF_NSLOT];   /* 0xffff = not reached */
+    __shared__ uint16_t s_pos[HUF_NSLOT];     /* preorder position */
+    __shared__ uint64_t s_code[HUF_NSLOT];
+    __shared__ int16_t s_tree[HUF_TREE_STRIDE];
+
+    const uint32_t KMAX = 0xffffffffu;
+    const int lane = lane_id();
+    const uint64_t blk = blockIdx.x;
+    const uint32_t *h = hist + blk * HUF_NSYM;
+
+    uint32_t k[4], rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        rate[j] = h[slot];
+        k[j] = rate[j] ? ((rate[j] << 9) | (uint32_t)(511 - slot)) : KMAX;
+        s_lcnt[slot] = rate[j] ? 1 : 0;
+        s_lcnt[256 + slot] = 0xffffu;
+        s_depth[slot] = 0xffffu;
+        s_depth[256 + slot] = 0xffffu;
+        s_left[256 + slot] = -1;
+        s_right[256 + slot] = -1;
+    }
+    for (int i = lane; i < HUF_TREE_STRIDE; i += 64) s_tree[i] = -1;
+
+    int node = HUF_NSYM;
+    int root = -1;
+    for (;;) {
+        const uint32_t a = wave_min_u32(dmin(dmin(k[0], k[1]), dmin(k[2], k[3])));
+        if (a == KMAX) { root = node - 1; break; }                 /* tree.c:355-358 */
+        uint32_t t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[j] = (k[j] == a) ? KMAX : k[j];
+        const uint32_t b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
+        const int i1 = 511 - (int)(a & 511u);
+        if (b == KMAX) {                                           /* tree.c:410-413: left-only wrap root */
+            if (lane == 0) s_left[node] = (int16_t)i1;
+            root = node;
+            node++;
+            break;
+        }
+        const int i2 = 511 - (int)(b & 511u);
+        const uint32_t nk = (((a >> 9) + (b >> 9)) << 9) | (uint32_t)(511 - node);   /* tree.c:407 */
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = (k[j] == a) ? nk : ((t[j] == b) ? KMAX : t[j]);
+        if (lane == 0) {
+            s_left[node] = (int16_t)i1;                            /* tree.c:390-404 */
+            s_right[node] = (int16_t)i2;
+        }
+        node++;
+    }
+    __syncthreads();
+    const int nodes = node;
+
+    /* leaves below every internal node: children always have smaller indices, so a few rounds of
+     * "both children known -> sum" settle it (one tree level per round) */
+    for (int round = 0; round < HUF_NSLOT; round++) {
+        bool pending = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int slot = 256 + lane + 64 * j;
+            if (slot < nodes && s_lcnt[slot] == 0xffffu) {
+                const int l = s_left[slot], r = s_right[slot];
+                const uint32_t cl = s_lcnt[l];
+                const uint32_t cr = (r >= 0) ? (uint32_t)s_lcnt[r] : 0u;
+                if (cl != 0xffffu && cr != 0xffffu) s_lcnt[slot] = (uint16_t)(cl + cr);
+                else pending = true;
+            }
+        }
+        __syncthreads();
+        if (!__any(pending)) break;
+    }
+    const int nleaves = (root >= 0) ? (int)s_lcnt[root] : 0;
+    const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
+
+    if (lane == 0 && root >= 0) {
+        s_depth[root] = 0;
+        s_code[root] = 0;
+        s_pos[root] = 0;
+    }
+    __syncthreads();
+
+    /* level sweep: codes, depths, preorder positions (see tree_kernel) */
+    for (int d = 0; d < HUF_NSLOT; d++) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int slot = 256 + lane + 64 * j;
+            if (slot < nodes && s_depth[slot] == (uint16_t)d) {
+                any = true;
+                const int l = s_left[slot], r = s_right[slot];
+                const uint64_t c = s_code[slot];
+                const int p = s_pos[slot];
+                s_tree[p] = (int16_t)slot;
+                s_depth[l] = (uint16_t)(d + 1);
+                s_code[l] = c << 1;
+                s_pos[l] = (uint16_t)(p + 1);
+                if (l < HUF_NSYM) s_tree[p + 1] = (int16_t)l;
+                if (r >= 0) {
+                    const int pr = p + 1 + 4 * (int)s_lcnt[l] - 1;
+                    s_depth[r] = (uint16_t)(d + 1);
+                    s_code[r] = (c << 1) | 1u;
+                    s_pos[r] = (uint16_t)pr;
+                    if (r < HUF_NSYM) s_tree[pr] = (int16_t)r;
+                }
+            }
+        }
+        __syncthreads();
+        if (!__any(any)) break;
+    }
+
+    uint64_t bits = 0;
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        hufcode_t e = 0;
+        if (rate[j]) {
+            const uint32_t len = s_depth[slot];
+            e = (s_code[slot] << 8) | (hufcode_t)len;
+            bits += (uint64_t)rate[j] * len;
+            maxlen = dmax(maxlen, len);
+        }
+        codetab[blk * HUF_NSYM + slot] = e;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        bits += shfl_xor_u64(bits, o);
+        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    }
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
+    if (lane == 0) {
+        HufBlockMeta mm;
+        mm.tree_len = (uint32_t)tree_len;
+        mm.max_len = maxlen;
+        mm.payload_bits = bits;
+        meta[blk] = mm;
+    }
+}
+
+/* ======================================================================================
  * scan_sizes_kernel - byte offset of every block header in the output stream.
  * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
  * Single workgroup; offsets[nblocks] = stream length.
@@ -579,9 +763,13 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
     return v;
 }
 
+/* result words: [0] unused, [1] total raw bytes (sum of block_len), [2] first failing block in
+ * stream order (~0 = none), [3] unused.  Word [2] is reset here and lowered with atomicMin by
+ * whoever finds an error: first error in stream order wins, like the reference's abort. */
 __global__ void decode_prepare_kernel(const uint8_t *__restrict__ stream, uint64_t stream_len,
                                       const uint64_t *__restrict__ offsets, uint64_t nblocks,
-                                      int max_tree_len, HufDecodeMeta *__restrict__ dmeta)
+                                      int max_tree_len, HufDecodeMeta *__restrict__ dmeta,
+                                      int32_t *__restrict__ status, unsigned long long *__restrict__ result)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
@@ -605,11 +793,14 @@ __global__ void decode_prepare_kernel(const uint8_t *__restrict__ stream, uint64
         }
     }
     dmeta[b] = m;
+    status[b] = m.status;
+    if (m.status != HUFE_OK) atomicMin(&result[2], (unsigned long long)b);
 }
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta *__restrict__ dmeta,
-                                                            uint64_t nblocks, uint64_t *__restrict__ out_offsets)
+                                                            uint64_t nblocks, uint64_t *__restrict__ out_offsets,
+                                                            unsigned long long *__restrict__ result)
 {
     __shared__ uint64_t s_part[THREADS / 64];
     uint64_t carry = 0;
@@ -621,7 +812,10 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
         if (i < nblocks) out_offsets[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) out_offsets[nblocks] = carry;
+    if (threadIdx.x == 0) {
+        out_offsets[nblocks] = carry;
+        result[1] = carry;
+    }
 }
 
 /* ======================================================================================
@@ -1162,7 +1356,8 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(const uint8_t *__restri
                                                          const HufDecodeMeta *__restrict__ dmeta,
                                                          const uint64_t *__restrict__ out_offsets,
                                                          uint8_t *__restrict__ out, uint64_t out_cap,
-                                                         int32_t *__restrict__ status)
+                                                         int32_t *__restrict__ status,
+                                                         unsigned long long *__restrict__ result)
 {
     __shared__ DecShared<THREADS> sh;
     const int tid = (int)threadIdx.x;
@@ -1182,7 +1377,10 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(const uint8_t *__restri
                                         pay_bytes, out + obase, &end_bits, &produced);
         }
     }
-    if (tid == 0) status[blk] = err;
+    if (tid == 0 && err != m.status) {       /* header errors were recorded by decode_prepare */
+        status[blk] = err;
+        if (err != HUFE_OK) atomicMin(&result[2], (unsigned long long)blk);
+    }
 }
 
 /* Raw-stream decode (no index): the block loop of src/decoder.c:218-276 run by ONE workgroup.
@@ -1230,35 +1428,6 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
         result[2] = rd;
         result[3] = nblk;
         if (block_offsets && nblk < max_index) block_offsets[nblk] = rd;
-    }
-}
-
-/* First failing block in stream order decides the result (decoder.c: first error aborts). */
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void decode_status_kernel(const int32_t *__restrict__ status,
-                                                                const uint64_t *__restrict__ out_offsets,
-                                                                uint64_t nblocks, uint64_t *__restrict__ result)
-{
-    /* result[0] = error code, result[1] = raw bytes (all blocks on success, bytes before the
-     * failing block otherwise), result[2] = index of failing block */
-    __shared__ unsigned long long s_first;
-    if (threadIdx.x == 0) s_first = ~0ull;
-    __syncthreads();
-    unsigned long long mine = ~0ull;
-    for (uint64_t i = threadIdx.x; i < nblocks; i += THREADS)
-        if (status[i] != HUFE_OK) { mine = i; break; }
-    if (mine != ~0ull) atomicMin(&s_first, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_first == ~0ull) {
-            result[0] = HUFE_OK;
-            result[1] = out_offsets[nblocks];
-            result[2] = nblocks;
-        } else {
-            result[0] = (uint64_t)status[s_first];
-            result[1] = out_offsets[s_first];
-            result[2] = s_first;
-        }
     }
 }
 

@@ -521,3 +521,18 @@ extern "C" int hufgpu_synchronize(hufgpu_ctx_t *ctx)
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     return HUFE_OK;
 }
+
+#ifdef DEC_PHASE_PROF
+/* diagnostic builds only: cycle sums of the decode phases (thread 0 of every workgroup) */
+extern "C" int hufgpu_debug_phase_cycles(hufgpu_ctx_t *ctx, unsigned long long *out16, int reset)
+{
+    if (!ctx || !out16) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipDeviceSynchronize());
+    HIP_OK(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(hufgpu::g_dec_prof), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        HIP_OK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(hufgpu::g_dec_prof), z, sizeof(z)));
+    }
+    return HUFE_OK;
+}
+#endif

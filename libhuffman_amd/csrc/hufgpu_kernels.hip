@@ -856,6 +856,15 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
 #define DEC_EXH 0xffffffffu           /* "a codeword ran past the readable payload" */
 #define DEC_NO_BAD 0xffffffffu
 
+#ifdef DEC_PHASE_PROF
+__device__ unsigned long long g_dec_prof[16];
+#define DPROF_T() (__builtin_readcyclecounter())
+#define DPROF_ADD(slot, t0) do { if (threadIdx.x == 0) atomicAdd(&g_dec_prof[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
+#else
+#define DPROF_T() 0ull
+#define DPROF_ADD(slot, t0) do { (void)(t0); } while (0)
+#endif
+
 template <int THREADS>
 struct DecShared {
     static constexpr int ENT = HUF_TREE_STRIDE;
@@ -892,74 +901,68 @@ __device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, 
     return v;
 }
 
-/* 64-bit MSB-first bit buffer over the staged segment. */
+/* Two-word MSB-first window over the staged segment: w0 = word g, w1 = word g+1.  A table
+ * codeword is at most DEC_LUT_BITS long, so after it the position is in word g or g+1. */
 template <int COLS>
-struct BitReader {
+struct WordReader {
     const uint32_t (*pay)[COLS];
-    uint64_t acc;      /* next bits, left aligned */
-    uint32_t nb;       /* valid bits in acc (> 32 between calls) */
-    uint32_t g;        /* next segment word to load */
+    uint32_t w0, w1, g;
 
     __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[i & (DEC_SUB_WORDS - 1)][i / DEC_SUB_WORDS]; }
-    __device__ __forceinline__ void seek(uint32_t bit)
+    __device__ __forceinline__ void load(uint32_t pos)
     {
-        g = bit >> 5;
-        const uint32_t sh = bit & 31u;
-        acc = (((uint64_t)word(g) << 32) | word(g + 1)) << sh;
-        nb = 64 - sh;
-        g += 2;
+        g = pos >> 5;
+        w0 = word(g);
+        w1 = word(g + 1);
     }
-    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
-    __device__ __forceinline__ void skip(uint32_t n)        /* n <= 32 */
+    /* the 32 bits that start at pos (pos >> 5 == g) */
+    __device__ __forceinline__ uint32_t window(uint32_t pos) const
     {
-        acc <<= n;
-        nb -= n;
-        if (nb <= 32) {
-            acc |= (uint64_t)word(g) << (32 - nb);
-            nb += 32;
-            g++;
-        }
+        return (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - (pos & 31u)));   /* one 64-bit shift, no branch */
+    }
+    __device__ __forceinline__ void step_to(uint32_t ng)      /* ng > g */
+    {
+        if (ng == g + 1) w0 = w1;
+        else w0 = word(ng);
+        w1 = word(ng + 1);
+        g = ng;
     }
 };
 
 enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
-/* Decode the codeword at `pos`. CW_OK: sym, npos = position after it (the reader is there too).
- * CW_BAD: the walk left the tree; npos = position after the failing bit (reader undefined).
- * CW_EXH: the walk needs bits past the readable payload. */
+/* Rare paths of a table lookup (entry type != 0), bit-serial on the staged words.
+ * CW_OK: sym, npos = position after the codeword.  CW_BAD: the walk left the tree, npos =
+ * position after the failing bit.  CW_EXH: the walk needs bits past the readable payload. */
+/* result packed in registers (no stack): bits 0-31 npos, 32-39 sym, 40-41 status */
 template <int THREADS>
-__device__ __forceinline__ int dec_one(const DecShared<THREADS> &sh, BitReader<DecShared<THREADS>::COLS> &br,
-                                       uint32_t pos, uint32_t pay_rel, uint32_t &npos, uint32_t &sym)
+__device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
 {
-    const uint32_t e = sh.lut[br.peek(DEC_LUT_BITS)];
-    const uint32_t type = e >> 14;
-    if (type == 0) {
-        const uint32_t n = (e >> 8) & 0xfu;
-        sym = e & 0xffu;
-        npos = pos + n;
-        br.skip(n);
-        return CW_OK;
+    if ((e >> 14) != 1u)                         /* the table walk already left the tree */
+        return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + ((e >> 8) & 0xfu));
+    uint32_t node = e & 0x7ffu;
+    uint32_t p = pos + DEC_LUT_BITS;
+    for (;;) {
+        if (p >= pay_rel) return (uint64_t)CW_EXH << 40;
+        const uint32_t w = sh.pay[(p >> 5) & (DEC_SUB_WORDS - 1)][(p >> 5) / DEC_SUB_WORDS];
+        const uint32_t bit = (w >> (31u - (p & 31u))) & 1u;
+        p++;
+        const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+        if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
+        node = nx;
+        if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) break;
     }
-    if (type == 1) {
-        uint32_t node = e & 0x7ffu;
-        uint32_t p = pos + DEC_LUT_BITS;
-        br.skip(DEC_LUT_BITS);
-        for (;;) {
-            if (p >= pay_rel) return CW_EXH;
-            const uint32_t bit = br.peek(1);
-            br.skip(1);
-            p++;
-            const uint32_t nx = bit ? sh.right[node] : sh.left[node];
-            if (nx == DEC_NULL) { npos = p; return CW_BAD; }
-            node = nx;
-            if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) break;
-        }
-        sym = (uint32_t)(uint8_t)sh.ent[node];
-        npos = p;
-        return CW_OK;
-    }
-    npos = pos + ((e >> 8) & 0xfu);      /* bits read up to the missing child */
-    return CW_BAD;
+    return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
+}
+
+template <int THREADS>
+__device__ __forceinline__ int dec_rare(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel,
+                                        uint32_t &npos, uint32_t &sym)
+{
+    const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
+    npos = (uint32_t)r;
+    sym = (uint32_t)(r >> 32) & 0xffu;
+    return (int)(r >> 40);
 }
 
 /* Per-lane decode state that survives the synchronisation rounds (the map of codeword starts
@@ -973,73 +976,153 @@ struct LaneTrack {
 
 /* Count pass.  MERGE = false: decode everything from `start`.  MERGE = true: `tr`/sh.bm hold the
  * lane's previous track; decode from the new `start` only until a position the previous track
- * also decoded at - from there on the two tracks are identical.  The bit map is updated word by
- * word as the position leaves each word (bits of the old track behind the position are dead). */
-template <int THREADS, bool MERGE>
+ * also decoded at - from there on the two tracks are identical.  The map is updated word by
+ * word as the position leaves each word (bits of the old track behind the position are dead).
+ * CHECK = false when no table codeword that starts before the lane's limit can reach the end of
+ * the readable payload (the common case): the per-symbol bound test is dropped. */
+template <int THREADS, bool MERGE, bool CHECK>
 __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
                                          uint32_t sub_lo, uint32_t pay_rel)
 {
     const int tid = (int)threadIdx.x;
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
+    const uint32_t sub_w0 = sub_lo >> 5;
     uint32_t c = 0, nbad = DEC_NO_BAD, pos = start;   /* nbad: position of the first bad walk */
-    uint32_t cur_lw = 0;          /* word being filled */
-    uint32_t newbits = 0;         /* new track's bits in word cur_lw */
-    uint32_t oldw = MERGE ? sh.bm[0][tid] : 0u;       /* previous track's bits in word cur_lw */
+    uint32_t lw = 0;              /* map word being filled */
+    uint32_t newbits = 0;         /* new track's bits in word lw */
+    uint32_t oldw = 0;            /* previous track's bits in word lw */
     uint32_t old_before = 0;      /* previous track's codewords in the words already left */
     bool merged = false;
     if (pos < limit) {
-        BitReader<DecShared<THREADS>::COLS> br;
-        br.pay = sh.pay;
-        br.seek(pos);
-        while (pos < limit) {
-            const uint32_t lw = (pos - sub_lo) >> 5;
-            if (lw != cur_lw) {                        /* leave cur_lw (and skip words in between) */
-                sh.bm[cur_lw][tid] = newbits;
-                old_before += __popc(oldw);
-                for (uint32_t k = cur_lw + 1; k < lw; k++) {
-                    if (MERGE) old_before += __popc(sh.bm[k][tid]);
-                    sh.bm[k][tid] = 0;
-                }
-                cur_lw = lw;
-                newbits = 0;
-                if (MERGE) oldw = sh.bm[lw][tid];
-            }
+        WordReader<DecShared<THREADS>::COLS> rd;
+        rd.pay = sh.pay;
+        rd.load(pos);
+        lw = rd.g - sub_w0;
+        for (uint32_t k = 0; k < lw; k++) {                    /* words in front of the start */
+            if (MERGE) old_before += __popc(sh.bm[k][tid]);
+            sh.bm[k][tid] = 0;
+        }
+        if (MERGE) oldw = sh.bm[lw][tid];
+        for (;;) {
             const uint32_t bit = 1u << (pos & 31u);
             if (MERGE && (oldw & bit)) { merged = true; break; }
-            uint32_t npos, sym;
-            const int st = dec_one<THREADS>(sh, br, pos, pay_rel, npos, sym);
-            if (st == CW_OK) {
-                if (npos > pay_rel) { pos = DEC_EXH; break; }
+            const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
+            if (__builtin_expect(e < 0x4000u, 1)) {
+                const uint32_t npos = pos + (e >> 8);
+                if (CHECK && npos > pay_rel) { pos = DEC_EXH; break; }
                 newbits |= bit;
                 c++;
                 pos = npos;
-            } else if (st == CW_EXH || npos > pay_rel) {
-                /* the failing bit must be a real payload bit for the failure to be real; else
-                 * the reference would have failed its byte read first (decoder.c:53-56) */
-                pos = DEC_EXH;
-                break;
             } else {
-                if (nbad == DEC_NO_BAD) nbad = pos;
-                pos += 1;                     /* resume one bit later (speculative starts only) */
-                br.seek(pos);
+                uint32_t npos, sym;
+                const int st = dec_rare<THREADS>(sh, e, pos, pay_rel, npos, sym);
+                if (st == CW_OK) {
+                    if (npos > pay_rel) { pos = DEC_EXH; break; }
+                    newbits |= bit;
+                    c++;
+                    pos = npos;
+                } else if (st == CW_EXH || npos > pay_rel) {
+                    /* the failing bit must be a real payload bit for the failure to be real; else
+                     * the reference would have failed its byte read first (decoder.c:53-56) */
+                    pos = DEC_EXH;
+                    break;
+                } else {
+                    if (nbad == DEC_NO_BAD) nbad = pos;
+                    pos += 1;                 /* resume one bit later (speculative starts only) */
+                }
+            }
+            if (pos >= limit) break;
+            const uint32_t ng = pos >> 5;
+            if (ng != rd.g) {                                  /* left map word lw */
+                sh.bm[lw][tid] = newbits;
+                if (MERGE) old_before += __popc(oldw);
+                const uint32_t nlw = ng - sub_w0;
+                for (uint32_t k = lw + 1; k < nlw; k++) {
+                    if (MERGE) old_before += __popc(sh.bm[k][tid]);
+                    sh.bm[k][tid] = 0;
+                }
+                lw = nlw;
+                newbits = 0;
+                if (MERGE) oldw = sh.bm[lw][tid];
+                rd.step_to(ng);
             }
         }
     }
     if (MERGE && merged) {
-        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word cur_lw before pos */
+        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word lw before pos */
         old_before += __popc(oldw & below);
-        sh.bm[cur_lw][tid] = (oldw & ~below) | newbits;
+        sh.bm[lw][tid] = (oldw & ~below) | newbits;
         if (nbad != DEC_NO_BAD) tr.bad_pos = nbad;                 /* new prefix: before the merge point */
         else if (tr.bad_pos != DEC_NO_BAD && tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;   /* was on the dead prefix */
         tr.cnt = c + (tr.cnt - old_before);
         /* tr.end unchanged */
     } else {
-        sh.bm[cur_lw][tid] = newbits;
-        for (uint32_t k = cur_lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
+        sh.bm[lw][tid] = newbits;
+        for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
         tr.cnt = c;
         tr.end = pos;
         tr.bad_pos = nbad;
     }
+    tr.start = start;
+}
+
+/* Bulk form of the first count pass (no previous track, payload end far away): one exit, the
+ * rare table entries are handled behind a wave-uniform ballot so that the common iteration has
+ * no divergent branch besides the word change. */
+template <int THREADS>
+__device__ __forceinline__ void dec_scan_bulk(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
+                                              uint32_t sub_lo, uint32_t pay_rel)
+{
+    const int tid = (int)threadIdx.x;
+    const uint32_t limit = sub_lo + DEC_SUB_BITS;
+    const uint32_t sub_w0 = sub_lo >> 5;
+    uint32_t c = 0, nbad = DEC_NO_BAD, pos = start, lw = 0, newbits = 0;
+    if (pos < limit) {
+        WordReader<DecShared<THREADS>::COLS> rd;
+        rd.pay = sh.pay;
+        rd.load(pos);
+        lw = rd.g - sub_w0;
+        for (uint32_t k = 0; k < lw; k++) sh.bm[k][tid] = 0;
+        for (;;) {
+            const uint32_t shift = pos & 31u;
+            const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
+            uint32_t len = e >> 8, ok = 1u;
+            if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
+                if (e >= 0x4000u) {
+                    const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
+                    const uint32_t npos = (uint32_t)r;
+                    const int st = (int)(r >> 40);
+                    if (st == CW_OK && npos <= pay_rel) len = npos - pos;
+                    else if (st == CW_BAD && npos <= pay_rel) {       /* a real bit left the tree */
+                        if (nbad == DEC_NO_BAD) nbad = pos;
+                        len = 1;
+                        ok = 0;
+                    } else {                                          /* needs bits past the payload */
+                        len = DEC_EXH - pos;
+                        ok = 0;
+                    }
+                }
+            }
+            newbits |= ok << shift;
+            c += ok;
+            pos += len;
+            if (pos >= limit) break;
+            const uint32_t ng = pos >> 5;
+            if (ng != rd.g) {                                  /* left map word lw */
+                sh.bm[lw][tid] = newbits;
+                const uint32_t nlw = ng - sub_w0;
+                for (uint32_t k = lw + 1; k < nlw; k++) sh.bm[k][tid] = 0;
+                lw = nlw;
+                newbits = 0;
+                rd.step_to(ng);
+            }
+        }
+    }
+    sh.bm[lw][tid] = newbits;
+    for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
+    tr.cnt = c;
+    tr.end = pos;
+    tr.bad_pos = nbad;
     tr.start = start;
 }
 
@@ -1060,14 +1143,14 @@ __device__ __forceinline__ uint32_t track_count_before(const DecShared<THREADS> 
 }
 
 /* Write pass: the lane's first `quota` symbols go to g[0..quota). Returns the position after
- * the last one.  The track has been validated by the count pass, so every codeword is CW_OK. */
+ * the last one.  The track has been validated by the count pass, so every codeword decodes. */
 template <int THREADS>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
 {
-    BitReader<DecShared<THREADS>::COLS> br;
-    br.pay = sh.pay;
-    br.seek(start);
+    WordReader<DecShared<THREADS>::COLS> rd;
+    rd.pay = sh.pay;
+    rd.load(start);
     uint32_t pos = start;
     const uintptr_t ga = (uintptr_t)g;
     uint32_t lo = (uint32_t)(ga & 3u);                    /* first byte of the current word that is ours */
@@ -1075,9 +1158,18 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
     uint32_t *gw = reinterpret_cast<uint32_t *>(ga - lo);
     uint32_t wacc = 0;
     for (uint32_t c = 0; c < quota; c++) {
-        uint32_t npos, sym;
-        (void)dec_one<THREADS>(sh, br, pos, pay_rel, npos, sym);
-        pos = npos;
+        const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
+        uint32_t sym = e & 0xffu, len = e >> 8;
+        if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
+            if (e >= 0x4000u) {
+                const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
+                sym = (uint32_t)(r >> 32) & 0xffu;
+                len = (uint32_t)r - pos;
+            }
+        }
+        pos += len;
+        const uint32_t ng = pos >> 5;
+        if (ng != rd.g) rd.step_to(ng);
         wacc |= sym << (8 * fill);
         if (++fill == 4) {
             if (lo == 0) *gw = wacc;
@@ -1113,6 +1205,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     *produced_out = 0;
 
     /* ---- 1. tree ---- */
+    unsigned long long pt = DPROF_T();
     __syncthreads();           /* previous user of sh is done */
     uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0][0]);   /* S(i); payload not staged yet */
     static_assert(sizeof(sh.pay) >= ENT * sizeof(uint16_t), "S(i) scratch must fit");
@@ -1193,6 +1286,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 
     const uint8_t *pay = tree + 2 * tree_len;
     const uint64_t pay_bits = pay_bytes * 8ull;
+    DPROF_ADD(0, pt); pt = DPROF_T();
 #if defined(DEC_ABLATE) && DEC_ABLATE == 1
     *end_bits = 0; return HUFE_OK;
 #endif
@@ -1254,6 +1348,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     }
     __syncthreads();
 
+    DPROF_ADD(1, pt);
 #if defined(DEC_ABLATE) && DEC_ABLATE == 2
     *end_bits = 0; return HUFE_OK;
 #endif
@@ -1266,6 +1361,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     while (produced < block_len) {
         if (true_start >= pay_bits) { err = HUFE_RW; break; }          /* input exhausted */
         /* segment origin: the 32-bit word that holds true_start */
+        pt = DPROF_T();
         const uint64_t seg0 = true_start & ~31ull;
         const uint64_t byte0 = seg0 >> 3;
         for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
@@ -1273,11 +1369,16 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         __syncthreads();
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
         const uint32_t first_start = (uint32_t)(true_start - seg0);
+        DPROF_ADD(2, pt); pt = DPROF_T();
 
         LaneTrack tr;
-        dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+        /* wave-uniform: the whole segment (plus the longest table codeword) lies inside the payload */
+        const bool far_from_end = pay_rel >= (uint32_t)(THREADS * DEC_SUB_BITS + DEC_LUT_BITS);
+        if (far_from_end) dec_scan_bulk<THREADS>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+        else dec_scan<THREADS, false, true>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
         sh.end[tid] = tr.end;
         __syncthreads();
+        DPROF_ADD(3, pt); pt = DPROF_T();
 #if defined(DEC_ABLATE) && DEC_ABLATE == 5
         int dbg_rounds = 0, dbg_changed_total = 0;
 #endif
@@ -1289,7 +1390,8 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             const int changed = (ns != tr.start);
             __syncthreads();                               /* everyone has read sh.end */
             if (changed) {
-                dec_scan<THREADS, true>(sh, tr, ns, sub_lo, pay_rel);
+                if (far_from_end) dec_scan<THREADS, true, false>(sh, tr, ns, sub_lo, pay_rel);
+                else dec_scan<THREADS, true, true>(sh, tr, ns, sub_lo, pay_rel);
                 sh.end[tid] = tr.end;
             }
 #if defined(DEC_ABLATE) && DEC_ABLATE == 5
@@ -1302,6 +1404,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         if (tid == 0 && blockIdx.x == 7) printf("seg0=%llu rounds=%d changed_total=%d\n", (unsigned long long)seg0, dbg_rounds, dbg_changed_total);
 #endif
 
+        DPROF_ADD(4, pt); pt = DPROF_T();
         /* output positions */
         uint32_t seg_total;
         const uint32_t ex = block_excl_scan<THREADS, uint32_t>(tr.cnt, sh.part, seg_total);
@@ -1324,6 +1427,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             quota = take - ex;
             if (quota > tr.cnt) quota = tr.cnt;
         }
+        DPROF_ADD(5, pt); pt = DPROF_T();
 #if defined(DEC_ABLATE) && DEC_ABLATE == 4
         quota = 0;
         if (tid == 0) sh.qend = sh.end[THREADS - 1] == DEC_EXH ? pay_rel : sh.end[THREADS - 1];
@@ -1334,6 +1438,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         }
         const uint32_t last_end = sh.end[THREADS - 1];
         __syncthreads();
+        DPROF_ADD(6, pt);
         produced += take;
         if (badsym != DEC_NO_BAD) { err = HUFE_CORRUPTED; break; }
         if (produced < block_len) {

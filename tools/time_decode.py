@@ -20,3 +20,13 @@ for _ in range(5):
     except Exception as e: pass
 prof, calls = c.profile("decode")
 print(os.environ.get("HUF_LIB_PATH", "default"), wl, {k: round(v / calls, 3) for k, v in prof.items()})
+if hasattr(c.lib, "hufgpu_debug_phase_cycles"):
+    import ctypes as C
+    arr = (C.c_ulonglong * 16)()
+    c.lib.hufgpu_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    c.lib.hufgpu_debug_phase_cycles(c._ctx, arr, 1)
+    c.decode(out, length, offs, nb, back, relaxed=True)
+    c.lib.hufgpu_debug_phase_cycles(c._ctx, arr, 0)
+    names = ["tree", "lut", "stage", "passA", "rounds", "scan", "write"]
+    tot = sum(arr[i] for i in range(7))
+    print({n: round(arr[i] / nb) for i, n in enumerate(names)}, "cycles per block; total", round(tot / nb))

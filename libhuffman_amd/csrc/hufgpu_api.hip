@@ -20,7 +20,9 @@ using namespace hufgpu;
 
 #define HIST_THREADS 256
 #define PACK_THREADS 256
-#define DEC_THREADS 256
+#ifndef DEC_THREADS
+#define DEC_THREADS 512
+#endif
 #define SCAN_THREADS 1024
 #define MAX_STAGES 8
 #define PROF_SLOTS 256

@@ -83,6 +83,10 @@ __device__ __forceinline__ T block_excl_scan(T v, T *s_part, T &total)
  * one atomic, and a whole wave-step of one value costs one atomic for the wave - that is the
  * common case on BASELINE config 2 (all 0x41), where per-byte atomics would serialise 64-way.
  * ==================================================================================== */
+#ifndef HIST_COPIES
+#define HIST_COPIES 4
+#endif
+
 __device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w)
 {
     atomicAdd(&h[w & 0xffu], 1u);
@@ -118,18 +122,22 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void hist256_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                           uint64_t blocksize, uint32_t *__restrict__ hist)
 {
+    /* HIST_COPIES private histograms per wavefront, selected by lane: hot symbols of skewed data
+     * then collide HIST_COPIES times less inside one ds_add (SQ_LDS_BANK_CONFLICT was 82 % of the
+     * LDS cycles with one copy on Zipf data) */
     constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t s_hist[WAVES * HUF_NSYM];
+    constexpr int COPIES = WAVES * HIST_COPIES;
+    __shared__ uint32_t s_hist[COPIES * HUF_NSYM];
 
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
     const uint64_t len = dmin<uint64_t>(blocksize, n - base);
     const int tid = (int)threadIdx.x;
 
-    for (int i = tid; i < WAVES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
+    for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
     __syncthreads();
 
-    uint32_t *mine = s_hist + (tid >> 6) * HUF_NSYM;
+    uint32_t *mine = s_hist + ((tid >> 6) * HIST_COPIES + (tid & (HIST_COPIES - 1))) * HUF_NSYM;
     const uint8_t *p = in + base;
     const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
     if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
@@ -143,10 +151,10 @@ __global__ __launch_bounds__(THREADS) void hist256_kernel(const uint8_t *__restr
     __syncthreads();
 
     for (int b = tid; b < HUF_NSYM; b += THREADS) {
-        uint32_t s = 0;
+        uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) s += s_hist[w * HUF_NSYM + b];
-        hist[blk * HUF_NSYM + b] = s;
+        for (int w = 0; w < COPIES; w++) sum += s_hist[w * HUF_NSYM + b];
+        hist[blk * HUF_NSYM + b] = sum;
     }
 }
 
@@ -874,7 +882,7 @@ struct DecShared {
     uint16_t right[ENT];
     uint16_t lut[1 << DEC_LUT_BITS];
     uint32_t pay[DEC_SUB_WORDS][COLS];   /* pay[w][l] = word w of lane l's subsequence */
-    uint32_t bm[DEC_SUB_WORDS][THREADS]; /* bit (p & 31) of bm[(p - sub_lo) >> 5][l]: lane l decoded a codeword at p */
+    uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
     uint32_t end[THREADS];               /* end position of each lane, bits relative to the segment */
     uint32_t part[THREADS / 64];
     int efflen;
@@ -965,21 +973,30 @@ __device__ __forceinline__ int dec_rare(const DecShared<THREADS> &sh, uint32_t e
     return (int)(r >> 40);
 }
 
-/* Per-lane decode state that survives the synchronisation rounds (the map of codeword starts
- * lives in sh.bm). */
+/* Per-lane decode state that survives the synchronisation rounds.  The lane's track is also
+ * summarised in sh.mark: for every 32-bit word of the subsequence, where the track first
+ * visited it and how many codewords it had decoded before that visit. */
 struct LaneTrack {
     uint32_t start;    /* first codeword of this lane (segment bits) */
     uint32_t end;      /* first codeword at/after the lane's limit, or DEC_EXH */
     uint32_t cnt;      /* codewords that start inside the lane's subsequence */
     uint32_t bad_pos;  /* position of the first walk that left the tree, DEC_NO_BAD if none */
+    uint32_t bad_at;   /* codewords decoded before it */
 };
 
-/* Count pass.  MERGE = false: decode everything from `start`.  MERGE = true: `tr`/sh.bm hold the
- * lane's previous track; decode from the new `start` only until a position the previous track
- * also decoded at - from there on the two tracks are identical.  The map is updated word by
- * word as the position leaves each word (bits of the old track behind the position are dead).
+#define DEC_NO_MARK 0xffffu
+__device__ __forceinline__ uint16_t dec_mark(uint32_t count, uint32_t pos) { return (uint16_t)((count << 5) | (pos & 31u)); }
+
+/* Count pass.  A track is the sequence of positions the decoder visits from `start` (a walk
+ * that leaves the tree resumes one bit later - only speculative starts ever do that).
+ * MERGE = false: decode everything.  MERGE = true: tr/sh.mark describe the lane's previous
+ * track; decode from the new `start` only until the new track enters a word at exactly the
+ * position where the previous track entered it - from there on the two are identical, so the
+ * old end stays valid and the counts differ by a constant.
  * CHECK = false when no table codeword that starts before the lane's limit can reach the end of
- * the readable payload (the common case): the per-symbol bound test is dropped. */
+ * the readable payload (the common case): the per-symbol bound test is dropped.
+ * Rare table entries sit behind a wave-uniform ballot, so the common iteration has no
+ * divergent branch besides the word change and the loop exit. */
 template <int THREADS, bool MERGE, bool CHECK>
 __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
                                          uint32_t sub_lo, uint32_t pay_rel)
@@ -987,159 +1004,80 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
     const int tid = (int)threadIdx.x;
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
     const uint32_t sub_w0 = sub_lo >> 5;
-    uint32_t c = 0, nbad = DEC_NO_BAD, pos = start;   /* nbad: position of the first bad walk */
-    uint32_t lw = 0;              /* map word being filled */
-    uint32_t newbits = 0;         /* new track's bits in word lw */
-    uint32_t oldw = 0;            /* previous track's bits in word lw */
-    uint32_t old_before = 0;      /* previous track's codewords in the words already left */
+    uint32_t c = 0, nbad_pos = DEC_NO_BAD, nbad_at = 0, pos = start;
+    uint32_t lw = DEC_SUB_WORDS;  /* word of the latest mark; DEC_SUB_WORDS = none written */
+    uint32_t old_c = 0;
     bool merged = false;
     if (pos < limit) {
         WordReader<DecShared<THREADS>::COLS> rd;
         rd.pay = sh.pay;
         rd.load(pos);
         lw = rd.g - sub_w0;
-        for (uint32_t k = 0; k < lw; k++) {                    /* words in front of the start */
-            if (MERGE) old_before += __popc(sh.bm[k][tid]);
-            sh.bm[k][tid] = 0;
+        for (uint32_t k = 0; k < lw; k++) sh.mark[k][tid] = DEC_NO_MARK;     /* nothing visits these */
+        if (MERGE) {
+            const uint32_t old = sh.mark[lw][tid];
+            if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; }
         }
-        if (MERGE) oldw = sh.bm[lw][tid];
-        for (;;) {
-            const uint32_t bit = 1u << (pos & 31u);
-            if (MERGE && (oldw & bit)) { merged = true; break; }
-            const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
-            if (__builtin_expect(e < 0x4000u, 1)) {
-                const uint32_t npos = pos + (e >> 8);
-                if (CHECK && npos > pay_rel) { pos = DEC_EXH; break; }
-                newbits |= bit;
-                c++;
-                pos = npos;
-            } else {
-                uint32_t npos, sym;
-                const int st = dec_rare<THREADS>(sh, e, pos, pay_rel, npos, sym);
-                if (st == CW_OK) {
-                    if (npos > pay_rel) { pos = DEC_EXH; break; }
-                    newbits |= bit;
-                    c++;
-                    pos = npos;
-                } else if (st == CW_EXH || npos > pay_rel) {
-                    /* the failing bit must be a real payload bit for the failure to be real; else
-                     * the reference would have failed its byte read first (decoder.c:53-56) */
-                    pos = DEC_EXH;
-                    break;
-                } else {
-                    if (nbad == DEC_NO_BAD) nbad = pos;
-                    pos += 1;                 /* resume one bit later (speculative starts only) */
+        if (!merged) {
+            sh.mark[lw][tid] = dec_mark(c, pos);
+            for (;;) {
+                const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
+                uint32_t len = e >> 8, ok = 1u;
+                if (CHECK && pos + len > pay_rel) { len = DEC_EXH - pos; ok = 0; }   /* also catches rare entries: fixed below */
+                if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
+                    if (e >= 0x4000u) {
+                        const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
+                        const uint32_t npos = (uint32_t)r;
+                        const int st = (int)(r >> 40);
+                        ok = 0;
+                        if (st == CW_OK && npos <= pay_rel) { len = npos - pos; ok = 1u; }
+                        else if (st == CW_BAD && npos <= pay_rel) {   /* a real payload bit left the tree */
+                            if (nbad_pos == DEC_NO_BAD) { nbad_pos = pos; nbad_at = c; }
+                            len = 1;
+                        } else len = DEC_EXH - pos;                   /* needs bits past the payload (decoder.c:53-56) */
+                    }
                 }
-            }
-            if (pos >= limit) break;
-            const uint32_t ng = pos >> 5;
-            if (ng != rd.g) {                                  /* left map word lw */
-                sh.bm[lw][tid] = newbits;
-                if (MERGE) old_before += __popc(oldw);
-                const uint32_t nlw = ng - sub_w0;
-                for (uint32_t k = lw + 1; k < nlw; k++) {
-                    if (MERGE) old_before += __popc(sh.bm[k][tid]);
-                    sh.bm[k][tid] = 0;
+                c += ok;
+                pos += len;
+                if (pos >= limit) break;
+                const uint32_t ng = pos >> 5;
+                if (ng != rd.g) {                              /* the track enters a new word */
+                    const uint32_t nlw = ng - sub_w0;
+                    for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
+                    lw = nlw;
+                    if (MERGE) {
+                        const uint32_t old = sh.mark[lw][tid];
+                        if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; break; }
+                    }
+                    sh.mark[lw][tid] = dec_mark(c, pos);
+                    rd.step_to(ng);
                 }
-                lw = nlw;
-                newbits = 0;
-                if (MERGE) oldw = sh.bm[lw][tid];
-                rd.step_to(ng);
             }
         }
     }
     if (MERGE && merged) {
-        const uint32_t below = (1u << (pos & 31u)) - 1u;         /* bits of word lw before pos */
-        old_before += __popc(oldw & below);
-        sh.bm[lw][tid] = (oldw & ~below) | newbits;
-        if (nbad != DEC_NO_BAD) tr.bad_pos = nbad;                 /* new prefix: before the merge point */
-        else if (tr.bad_pos != DEC_NO_BAD && tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;   /* was on the dead prefix */
-        tr.cnt = c + (tr.cnt - old_before);
+        /* identical from `pos` on: later marks keep their positions, their counts shift */
+        const uint32_t delta = c - old_c;                      /* modulo 2^32, may be "negative" */
+        for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) {
+            const uint32_t r = sh.mark[k][tid];
+            if (r != DEC_NO_MARK) sh.mark[k][tid] = (uint16_t)(r + (delta << 5));
+        }
+        sh.mark[lw][tid] = dec_mark(c, pos);
+        if (nbad_pos != DEC_NO_BAD) { tr.bad_pos = nbad_pos; tr.bad_at = nbad_at; }        /* on the new prefix */
+        else if (tr.bad_pos != DEC_NO_BAD) {
+            if (tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;                                  /* was on the dead prefix */
+            else tr.bad_at += delta;
+        }
+        tr.cnt += delta;
         /* tr.end unchanged */
     } else {
-        sh.bm[lw][tid] = newbits;
-        for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
+        for (uint32_t k = (lw == DEC_SUB_WORDS ? 0u : lw + 1); k < DEC_SUB_WORDS; k++) sh.mark[k][tid] = DEC_NO_MARK;
         tr.cnt = c;
         tr.end = pos;
-        tr.bad_pos = nbad;
+        tr.bad_pos = nbad_pos;
+        tr.bad_at = nbad_at;
     }
     tr.start = start;
-}
-
-/* Bulk form of the first count pass (no previous track, payload end far away): one exit, the
- * rare table entries are handled behind a wave-uniform ballot so that the common iteration has
- * no divergent branch besides the word change. */
-template <int THREADS>
-__device__ __forceinline__ void dec_scan_bulk(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
-                                              uint32_t sub_lo, uint32_t pay_rel)
-{
-    const int tid = (int)threadIdx.x;
-    const uint32_t limit = sub_lo + DEC_SUB_BITS;
-    const uint32_t sub_w0 = sub_lo >> 5;
-    uint32_t c = 0, nbad = DEC_NO_BAD, pos = start, lw = 0, newbits = 0;
-    if (pos < limit) {
-        WordReader<DecShared<THREADS>::COLS> rd;
-        rd.pay = sh.pay;
-        rd.load(pos);
-        lw = rd.g - sub_w0;
-        for (uint32_t k = 0; k < lw; k++) sh.bm[k][tid] = 0;
-        for (;;) {
-            const uint32_t shift = pos & 31u;
-            const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
-            uint32_t len = e >> 8, ok = 1u;
-            if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
-                if (e >= 0x4000u) {
-                    const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
-                    const uint32_t npos = (uint32_t)r;
-                    const int st = (int)(r >> 40);
-                    if (st == CW_OK && npos <= pay_rel) len = npos - pos;
-                    else if (st == CW_BAD && npos <= pay_rel) {       /* a real bit left the tree */
-                        if (nbad == DEC_NO_BAD) nbad = pos;
-                        len = 1;
-                        ok = 0;
-                    } else {                                          /* needs bits past the payload */
-                        len = DEC_EXH - pos;
-                        ok = 0;
-                    }
-                }
-            }
-            newbits |= ok << shift;
-            c += ok;
-            pos += len;
-            if (pos >= limit) break;
-            const uint32_t ng = pos >> 5;
-            if (ng != rd.g) {                                  /* left map word lw */
-                sh.bm[lw][tid] = newbits;
-                const uint32_t nlw = ng - sub_w0;
-                for (uint32_t k = lw + 1; k < nlw; k++) sh.bm[k][tid] = 0;
-                lw = nlw;
-                newbits = 0;
-                rd.step_to(ng);
-            }
-        }
-    }
-    sh.bm[lw][tid] = newbits;
-    for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) sh.bm[k][tid] = 0;
-    tr.cnt = c;
-    tr.end = pos;
-    tr.bad_pos = nbad;
-    tr.start = start;
-}
-
-/* Codewords of the lane's track that start before `pos`. */
-template <int THREADS>
-__device__ __forceinline__ uint32_t track_count_before(const DecShared<THREADS> &sh, uint32_t pos, uint32_t sub_lo)
-{
-    if (pos <= sub_lo) return 0;
-    const uint32_t rel = pos - sub_lo;
-    uint32_t n = 0;
-    for (uint32_t k = 0; k < DEC_SUB_WORDS; k++) {
-        const uint32_t lo = 32u * k;
-        const uint32_t w = sh.bm[k][threadIdx.x];
-        if (rel >= lo + 32) n += __popc(w);
-        else if (rel > lo) n += __popc(w & ((1u << (rel - lo)) - 1u));
-    }
-    return n;
 }
 
 /* Write pass: the lane's first `quota` symbols go to g[0..quota). Returns the position after
@@ -1374,7 +1312,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         LaneTrack tr;
         /* wave-uniform: the whole segment (plus the longest table codeword) lies inside the payload */
         const bool far_from_end = pay_rel >= (uint32_t)(THREADS * DEC_SUB_BITS + DEC_LUT_BITS);
-        if (far_from_end) dec_scan_bulk<THREADS>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+        if (far_from_end) dec_scan<THREADS, false, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
         else dec_scan<THREADS, false, true>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
         sh.end[tid] = tr.end;
         __syncthreads();
@@ -1412,10 +1350,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         /* the first walk that left the tree, in stream order, is a real error if it happens
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
          * Symbols decoded before it are still delivered, like the reference's writer does. */
-        if (tr.bad_pos != DEC_NO_BAD) {
-            const uint32_t bad_at = track_count_before<THREADS>(sh, tr.bad_pos, sub_lo);
-            if ((uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
-        }
+        if (tr.bad_pos != DEC_NO_BAD && (uint64_t)ex + tr.bad_at < remaining) atomicMin(&sh.badsym, ex + tr.bad_at);
         __syncthreads();
         const uint32_t badsym = sh.badsym;
         const uint32_t good = (badsym != DEC_NO_BAD) ? badsym : seg_total;

@@ -1,0 +1,304 @@
+"""bz2-style Python interface over the GPU Huffman codec - mirror of the reference's
+``huffmanfile`` module (huffmanfile/huffmanfile.py), bound through ctypes instead of CFFI.
+
+Same public names, defaults, exception type and message format as the reference:
+
+    HuffmanError, HuffmanFile, HuffmanCompressor, HuffmanDecompressor, compress, decompress, open
+    DEFAULT_BLOCK_SIZE = 131072, DEFAULT_MEM_LIMIT = 262144
+
+Every call ends in ``huf_encode`` / ``huf_decode`` of libhuffman.so, i.e. on the MI355X (there is
+no CPU fallback: without a GPU the calls raise ``HuffmanError("Fatal error. ...")``).
+
+Deliberate differences from the reference (SURVEY Appendix D - defects that are not copied):
+  * incremental ``HuffmanCompressor.compress`` never loses buffered bytes and equals the
+    one-shot result (reference: huffmanfile.py:319-340 drops data when a call completes no block);
+  * ``compress()`` after ``flush()`` raises ``ValueError`` (reference: an accidental TypeError);
+  * ``HuffmanDecompressor`` can be used for any number of calls (reference never rewinds its
+    input stream, huffmanfile.py:391-392);
+  * ``HuffmanFile.read(size)`` returns up to ``size`` *uncompressed* bytes and ``read(-1)`` the
+    whole file (reference decodes the first 8192 compressed bytes and fails on larger files);
+  * ``open`` is part of ``__all__``.
+The objects are not thread-safe (same as the reference, huffmanfile.py:5-7).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import os
+from builtins import open as _builtin_open
+
+from . import _native as N
+
+__all__ = ["HuffmanError", "HuffmanFile", "HuffmanCompressor", "HuffmanDecompressor",
+           "compress", "decompress", "open"]
+
+DEFAULT_BLOCK_SIZE = 131072     # huffmanfile.py:26
+DEFAULT_MEM_LIMIT = 262144      # huffmanfile.py:27 (initial stream capacity, not a limit)
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+class HuffmanError(Exception):
+    """Raised when the codec reports an error (huffmanfile.py:30-37)."""
+
+
+def _check(err: int, context: str) -> None:
+    if err != N.HUF_ERROR_SUCCESS:
+        raise HuffmanError(f"{N.error_string(err)}. {context}")
+
+
+class _MemStream:
+    """A growable huf_memopen() stream; the buffer itself is owned here (huf_memclose only frees
+    the stream objects, src/io.c:213-226)."""
+
+    def __init__(self, capacity: int):
+        self._lib = N.load()
+        self._rw = C.POINTER(N.ReadWriter)()
+        self._buf = C.c_void_p()
+        _check(self._lib.huf_memopen(C.byref(self._rw), C.byref(self._buf), max(int(capacity), 1)),
+               f"Failed to allocate memory stream of {capacity} bytes long")
+
+    @property
+    def handle(self):
+        return self._rw
+
+    def __len__(self) -> int:
+        n = C.c_size_t()
+        _check(self._lib.huf_memlen(self._rw, C.byref(n)), "Failed to retrieve length of the memory stream")
+        return n.value
+
+    def write(self, data) -> None:
+        view = memoryview(data).cast("B")
+        if not len(view):
+            return
+        raw = (C.c_char * len(view)).from_buffer_copy(view)
+        _check(self._rw.contents.write(self._rw.contents.stream, raw, len(view)),
+               "Failed to write data to the memory stream")
+
+    def getvalue(self) -> bytes:
+        n = len(self)
+        return C.string_at(self._buf.value, n) if n else b""
+
+    def rewind(self) -> None:
+        _check(self._lib.huf_memrewind(self._rw), "Failed to rewind memory stream")
+
+    def close(self) -> None:
+        if self._rw:
+            _check(self._lib.huf_memclose(C.byref(self._rw)), "Failed to close memory stream")
+            _libc.free(self._buf)
+            self._buf = C.c_void_p()
+
+
+class HuffmanCompressor:
+    """Incremental compressor: whole blocks are encoded as soon as they are available, the
+    remainder (< blocksize bytes) at flush()."""
+
+    def __init__(self, blocksize: int = DEFAULT_BLOCK_SIZE):
+        if blocksize <= 0:
+            raise ValueError("blocksize must be positive")
+        self._lib = N.load()
+        self._blocksize = int(blocksize)
+        self._pending = bytearray()
+        self._flushed = False
+
+    def _encode(self, data) -> bytes:
+        n = len(data)
+        if n == 0:
+            return b""
+        src, dst = _MemStream(n), _MemStream(n + n // 8 + 4096)
+        try:
+            src.write(data)
+            cfg = N.Config(n, self._blocksize, 0, 0, src.handle, dst.handle)
+            _check(self._lib.huf_encode(C.byref(cfg)), "Failed to encode the data")
+            return dst.getvalue()
+        finally:
+            src.close()
+            dst.close()
+
+    def compress(self, data) -> bytes:
+        """Feed data; returns the encoding of the blocks that became complete (maybe b"")."""
+        if self._flushed:
+            raise ValueError("Compressor has been flushed")
+        self._pending += memoryview(data).cast("B")
+        whole = len(self._pending) - len(self._pending) % self._blocksize
+        if not whole:
+            return b""
+        out = self._encode(memoryview(self._pending)[:whole])
+        del self._pending[:whole]
+        return out
+
+    def flush(self) -> bytes:
+        """Encode what is left as one short block; the object cannot be used afterwards."""
+        if self._flushed:
+            return b""
+        self._flushed = True
+        out = self._encode(self._pending)
+        self._pending = bytearray()
+        return out
+
+
+class HuffmanDecompressor:
+    """Decompressor object; every decompress() call must be given whole blocks (like the
+    reference), and may be the concatenation of any number of streams."""
+
+    def __init__(self, memlimit: int = DEFAULT_MEM_LIMIT):
+        self._lib = N.load()
+        self._memlimit = int(memlimit)
+        self._closed = False
+
+    def decompress(self, data) -> bytes:
+        if self._closed:
+            raise ValueError("Decompressor has been closed")
+        view = memoryview(data).cast("B")
+        n = len(view)
+        if n == 0:
+            return b""
+        src, dst = _MemStream(n), _MemStream(max(self._memlimit, 4 * n))
+        try:
+            src.write(view)
+            cfg = N.Config(n, 0, 0, 0, src.handle, dst.handle)
+            _check(self._lib.huf_decode(C.byref(cfg)), "Failed to decode the data")
+            return dst.getvalue()
+        finally:
+            src.close()
+            dst.close()
+
+    def close(self) -> None:
+        self._closed = True
+
+
+def compress(data, blocksize: int = DEFAULT_BLOCK_SIZE) -> bytes:
+    """One-shot compression (huffmanfile.py:409-417)."""
+    comp = HuffmanCompressor(blocksize)
+    return comp.compress(data) + comp.flush()
+
+
+def decompress(data, memlimit: int = DEFAULT_MEM_LIMIT) -> bytes:
+    """One-shot decompression of one or several concatenated streams (huffmanfile.py:420-432)."""
+    dec = HuffmanDecompressor(memlimit)
+    try:
+        return dec.decompress(data)
+    finally:
+        dec.close()
+
+
+_CLOSED, _READ, _WRITE = 0, 1, 2
+
+
+class HuffmanFile(io.BufferedIOBase):
+    """Binary file object with transparent Huffman (de)compression (huffmanfile.py:45-181)."""
+
+    def __init__(self, filename, mode: str = "w", blocksize: int = DEFAULT_BLOCK_SIZE,
+                 memlimit: int = DEFAULT_MEM_LIMIT):
+        self._fp = None
+        self._mode = _CLOSED
+        self._own_fp = False
+        self._plain = None          # decoded contents, filled by the first read
+        self._cursor = 0
+        if mode in ("", "r", "rb"):
+            file_mode, state = "rb", _READ
+            self._decompressor = HuffmanDecompressor(memlimit)
+        elif mode in ("w", "wb", "x", "xb", "a", "ab"):
+            file_mode, state = mode[0] + "b", _WRITE
+            self._compressor = HuffmanCompressor(blocksize)
+        else:
+            raise ValueError("Invalid mode: %r" % (mode,))
+        if isinstance(filename, (str, bytes, os.PathLike)):
+            self._fp = _builtin_open(filename, file_mode)
+            self._own_fp = True
+        elif hasattr(filename, "read") or hasattr(filename, "write"):
+            self._fp = filename
+        else:
+            raise TypeError("filename must be a str, bytes, file or PathLike object")
+        self._mode = state
+
+    # -- state ------------------------------------------------------------------------------
+    def close(self) -> None:
+        if self._mode == _CLOSED:
+            return
+        try:
+            if self._mode == _WRITE:
+                self._fp.write(self._compressor.flush())
+            else:
+                self._decompressor.close()
+        finally:
+            try:
+                if self._own_fp:
+                    self._fp.close()
+            finally:
+                self._fp, self._own_fp, self._mode = None, False, _CLOSED
+
+    @property
+    def closed(self) -> bool:
+        return self._mode == _CLOSED
+
+    def _require_open(self) -> None:
+        if self.closed:
+            raise ValueError("I/O operation on closed file")
+
+    def fileno(self) -> int:
+        self._require_open()
+        return self._fp.fileno()
+
+    def seekable(self) -> bool:
+        return False
+
+    def readable(self) -> bool:
+        self._require_open()
+        return self._mode == _READ
+
+    def writable(self) -> bool:
+        self._require_open()
+        return self._mode == _WRITE
+
+    # -- I/O --------------------------------------------------------------------------------
+    def _load(self) -> None:
+        if self._plain is None:
+            # block boundaries are only known by decoding (the format stores no payload length),
+            # so the file is decoded in one piece, on the GPU
+            self._plain = self._decompressor.decompress(self._fp.read())
+            self._cursor = 0
+
+    def read(self, size: int = -1) -> bytes:
+        """Up to `size` uncompressed bytes; everything that is left when size < 0."""
+        if not self.readable():
+            raise io.UnsupportedOperation("File not open for reading")
+        self._load()
+        if size is None or size < 0:
+            size = len(self._plain) - self._cursor
+        chunk = self._plain[self._cursor:self._cursor + size]
+        self._cursor += len(chunk)
+        return chunk
+
+    def read1(self, size: int = -1) -> bytes:
+        return self.read(size)
+
+    def readinto(self, b) -> int:
+        view = memoryview(b).cast("B")
+        data = self.read(len(view))
+        view[:len(data)] = data
+        return len(data)
+
+    def write(self, data) -> int:
+        if not self.writable():
+            raise io.UnsupportedOperation("File not open for writing")
+        view = memoryview(data).cast("B")
+        self._fp.write(self._compressor.compress(view))
+        return len(view)
+
+
+def open(filename, mode: str = "rb", encoding=None, errors=None, newline=None):
+    """Open a Huffman-compressed file in binary or text mode (huffmanfile.py:184-216)."""
+    if "t" in mode:
+        if "b" in mode:
+            raise ValueError("Invalid mode: %r" % (mode,))
+    else:
+        if encoding is not None:
+            raise ValueError("Argument 'encoding' not supported in binary mode")
+        if errors is not None:
+            raise ValueError("Argument 'errors' not supported in binary mode")
+        if newline is not None:
+            raise ValueError("Argument 'newline' not supported in binary mode")
+    binary = HuffmanFile(filename, mode.replace("t", ""))
+    return io.TextIOWrapper(binary, encoding, errors, newline) if "t" in mode else binary

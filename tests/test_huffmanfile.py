@@ -1,0 +1,172 @@
+"""The Python surface (libhuffman_amd/huffmanfile.py, importable as `huffmanfile`).
+
+CPU tests cover the API shape; GPU tests restate the reference's four pytest cases
+(huffmanfile/huffmanfile_test.py:8-54) and the captures of SURVEY §8c through the real codec.
+"""
+import hashlib
+import io
+
+import numpy as np
+import pytest
+
+import huffmanfile
+from libhuffman_amd import datagen
+
+
+def _have_gpu():
+    from libhuffman_amd import _native
+    return _native.load().hufgpu_device_count() > 0
+
+
+# ------------------------------------------------------------------ CPU: API shape
+def test_public_names_and_defaults():
+    assert set(huffmanfile.__all__) >= {"HuffmanError", "HuffmanFile", "HuffmanCompressor",
+                                        "HuffmanDecompressor", "compress", "decompress"}
+    assert huffmanfile.DEFAULT_BLOCK_SIZE == 131072 and huffmanfile.DEFAULT_MEM_LIMIT == 262144
+    assert issubclass(huffmanfile.HuffmanError, Exception)
+
+
+def test_empty_inputs_need_no_device():
+    assert huffmanfile.compress(b"") == b"" and huffmanfile.decompress(b"") == b""
+    c = huffmanfile.HuffmanCompressor()
+    assert c.compress(b"") == b"" and c.flush() == b"" and c.flush() == b""
+    with pytest.raises(ValueError):
+        c.compress(b"x")                       # bz2 semantics; the reference raises TypeError here
+
+
+def test_file_object_argument_checks(tmp_path):
+    with pytest.raises(ValueError):
+        huffmanfile.HuffmanFile(tmp_path / "x", mode="rw")
+    with pytest.raises(TypeError):
+        huffmanfile.HuffmanFile(12345)
+    with pytest.raises(ValueError):
+        huffmanfile.open(tmp_path / "x", "rbt")
+    with pytest.raises(ValueError):
+        huffmanfile.open(tmp_path / "x", "rb", encoding="utf-8")
+    f = huffmanfile.HuffmanFile(io.BytesIO(), "w")
+    assert f.writable() and not f.readable() and not f.seekable() and not f.closed
+    with pytest.raises(io.UnsupportedOperation):
+        f.read()
+    f.close()
+    f.close()                                   # idempotent
+    assert f.closed
+    with pytest.raises(ValueError):
+        f.writable()
+
+
+def test_no_gpu_raises_huffman_error_with_reference_format():
+    if _have_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(huffmanfile.HuffmanError) as ei:
+        huffmanfile.compress(b"abc")
+    assert str(ei.value) == "Fatal error. Failed to encode the data"
+
+
+# ------------------------------------------------------------------ GPU: behaviour
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_compress_decompress():                              # huffmanfile_test.py:8-12
+    data = b"a" * 1000
+    c = huffmanfile.compress(data)
+    assert len(c) == 145 and hashlib.sha256(c).hexdigest().startswith("c4270ae06ed145d8")
+    assert huffmanfile.decompress(c) == data
+
+
+@gpu
+def test_decompress_corrupted():                             # huffmanfile_test.py:15-18
+    with pytest.raises(huffmanfile.HuffmanError) as ei:
+        huffmanfile.decompress(b"\x08\x00\x00\x00\x00\x00\x00\x00\x02\x00")
+    assert str(ei.value) == "Failed on read/write operation. Failed to decode the data"
+
+
+@gpu
+def test_compress_incremental():                             # huffmanfile_test.py:21-34
+    comp = huffmanfile.HuffmanCompressor()
+    out, data = b"", b""
+    for _ in range(10):
+        part = b"z" * 1000
+        out += comp.compress(part)
+        data += part
+    out += comp.flush()
+    assert len(out) == 1270
+    assert huffmanfile.decompress(out) == data
+    assert out == huffmanfile.compress(data)
+
+
+@gpu
+def test_incremental_equals_one_shot_across_blocks():
+    """The reference loses buffered bytes here; incremental must equal one-shot."""
+    data = datagen.zipf255(300000).tobytes()
+    comp = huffmanfile.HuffmanCompressor(65536)
+    out = b"".join(comp.compress(data[i:i + 7001]) for i in range(0, len(data), 7001)) + comp.flush()
+    assert out == huffmanfile.compress(data, 65536)
+    assert huffmanfile.decompress(out) == data
+
+
+@gpu
+def test_write_file_text_mode(tmp_path):                     # huffmanfile_test.py:37-54
+    text = "Donec rhoncus quis sapien sit amet molestie.\nhéllo\n" * 40
+    name = tmp_path / "archive.hm"
+    with huffmanfile.open(name, "wt", encoding="utf-8") as f:
+        f.write(text)
+    with huffmanfile.open(name, "rt", encoding="utf-8") as f:
+        assert f.read() == text
+
+
+@gpu
+def test_file_bytes_equal_compress_and_chunked_reads(tmp_path):
+    data = datagen.logtext(400000).tobytes()
+    name = tmp_path / "a.hm"
+    with huffmanfile.HuffmanFile(name, "w") as f:
+        assert f.write(data[:150000]) == 150000
+        f.write(memoryview(data)[150000:])
+    assert name.read_bytes() == huffmanfile.compress(data)            # default blocksize 131072
+    with huffmanfile.HuffmanFile(name, "r") as f:
+        got = b""
+        while True:
+            chunk = f.read(50001)
+            if not chunk:
+                break
+            got += chunk
+    assert got == data
+    with huffmanfile.open(name) as f:
+        assert f.read() == data and f.read() == b""
+
+
+@gpu
+def test_concatenated_streams_and_reuse():
+    d = huffmanfile.HuffmanDecompressor()
+    c1, c2 = huffmanfile.compress(b"hello hello"), huffmanfile.compress(b"world!", 4)
+    assert d.decompress(c1 + c2) == b"hello helloworld!"
+    assert d.decompress(c2) == b"world!"                               # reusable
+
+
+@gpu
+def test_golden_streams_through_python_layer(golden):
+    for vec in golden["encode_small"]:
+        if vec["blocksize"] == 0:
+            continue
+        data = bytes.fromhex(vec["input_hex"])
+        assert huffmanfile.compress(data, vec["blocksize"]).hex() == vec["output_hex"], vec["name"]
+    vec = next(v for v in golden["encode_large"] if v["generator"] == "logtext" and v["blocksize"] == 1 << 20)
+    data = datagen.logtext(vec["n"]).tobytes()
+    out = huffmanfile.compress(data, 1 << 20)                           # config 5 shape
+    assert len(out) == vec["output_len"] and hashlib.sha256(out).hexdigest() == vec["output_sha256"]
+    assert huffmanfile.decompress(out) == data
+
+
+@gpu
+def test_k256_block_strict_and_relaxed():
+    from libhuffman_amd import _native
+    data = bytes(range(256)) * 4
+    c = huffmanfile.compress(data, 65536)
+    with pytest.raises(huffmanfile.HuffmanError) as ei:
+        huffmanfile.decompress(c)
+    assert str(ei.value).startswith("Block is corrupted, Huffman tree has impossible size.")
+    _native.load().huf_gpu_set_relaxed_tree(1)
+    try:
+        assert huffmanfile.decompress(c) == data
+    finally:
+        _native.load().huf_gpu_set_relaxed_tree(0)

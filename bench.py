@@ -104,8 +104,11 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the codec has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank test of the RCCL path
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from libhuffman_amd.codec import GpuCodec
     from libhuffman_amd.sharding import shard_range
@@ -128,7 +131,7 @@ def main() -> None:
 
     def step():
         codec.encode(data, bs, out=out, offsets=offs, sync=False)
-        if world > 1:
+        if use_dist:
             # the one real exchange: every rank learns where its stream starts in the job's stream
             dist.all_gather_into_tensor(sizes, offs[nb:nb + 1])
         codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False)
@@ -137,7 +140,7 @@ def main() -> None:
         step()
     raw = codec.decode_result() if args.warmup else None
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -149,7 +152,7 @@ def main() -> None:
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -159,7 +162,7 @@ def main() -> None:
     dec_prof, dec_calls = codec.profile("decode")
     codec.set_profiling(False)
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -168,7 +171,7 @@ def main() -> None:
     bit_exact = None
     if not args.no_verify:
         bit_exact = bool(torch.equal(back, data))      # full-size round trip on every rank
-        if world > 1:
+        if use_dist:
             ok = torch.tensor([1 if bit_exact else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             bit_exact = bool(ok.item())
@@ -187,6 +190,16 @@ def main() -> None:
                              "alg_GBps": round(alg[name] / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None}
         dom = max(("pack", "decode", "hist256", "tree"), key=lambda k: kernels[k]["avg_ms"])
         achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
+        # HBM bytes of that kernel from the TCC counters (separate rocprofv3 --pmc passes of this same
+        # command, tools/gpu_traffic.sh -> profiles/traffic.json); null when not collected for the workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                t = json.load(f)["workloads"][args.workload][dom]
+            if n == (1 << 30) and bs == 65536:
+                traffic = round(t["hbm"])
+        except Exception:
+            traffic = None
         pipeline_bytes = 2 * (n + comp_len)
         gpu_ms = ev0.elapsed_time(ev1) / K
         result = {
@@ -207,7 +220,7 @@ def main() -> None:
                        "compressed_bytes_per_gpu": comp_len, "ratio": round(comp_len / n, 5),
                        "parallelism": f"block-sharded x{world}", "bit_exact_roundtrip": bit_exact},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg[dom],
                          "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
@@ -217,7 +230,7 @@ def main() -> None:
             result["cpu_baseline"] = cpu_baseline(args.workload, bs)
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

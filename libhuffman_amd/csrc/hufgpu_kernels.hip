@@ -1128,6 +1128,45 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
     return pos;
 }
 
+/* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit
+ * leaves the tree (src/decoder.c:69-71).  Scan the needed payload bits for a set bit, then the
+ * output is a fill.  sh.firstone must be DEC_NO_BAD on entry. */
+template <int THREADS>
+__device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const uint8_t *pay, uint64_t block_len,
+                                  uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits, uint64_t *produced_out)
+{
+    const int tid = (int)threadIdx.x;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+    const uint64_t have = dmin<uint64_t>(block_len, pay_bits);       /* bits we may look at */
+    const uint64_t nwords = (have + 31) >> 5;
+    uint32_t first = DEC_NO_BAD;
+    for (uint64_t w = (uint64_t)tid; w < nwords; w += THREADS) {
+        uint32_t v = load_be32(pay, w * 4, pay_bytes);
+        const uint64_t left_bits = have - (w << 5);
+        if (left_bits < 32) v &= ~(0xffffffffu >> (uint32_t)left_bits);
+        if (v) { first = (uint32_t)dmin<uint64_t>(first, (w << 5) + (uint32_t)__clz(v)); break; }
+    }
+    if (first != DEC_NO_BAD) atomicMin(&sh.firstone, first);
+    __syncthreads();
+    const uint32_t fo = sh.firstone;
+    const uint64_t good = (fo != DEC_NO_BAD) ? (uint64_t)fo : have;
+    /* fill gout[0, good) */
+    const uint32_t rep = symv * 0x01010101u;
+    const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
+    if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
+    uint4 *q = reinterpret_cast<uint4 *>(gout + head);
+    const uint64_t nvec = (good - head) >> 4;
+    const uint4 v4 = make_uint4(rep, rep, rep, rep);
+    for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
+    *produced_out = good;
+    if (fo != DEC_NO_BAD) return HUFE_CORRUPTED;                     /* decoder.c:69-71 */
+    if (have < block_len) return HUFE_RW;                            /* decoder.c:53-56 */
+    *end_bits = block_len;
+    return HUFE_OK;
+}
+
 /* Decode one block whose header has been parsed.  `tree` points at the tree_len int16 entries,
  * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
  * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
@@ -1142,8 +1181,24 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     const int tid = (int)threadIdx.x;
     *produced_out = 0;
 
-    /* ---- 1. tree ---- */
+    /* ---- 0. the tree every one-symbol block carries, [root, leaf, -1, -1, -1],
+     *         is recognised straight from its five entries; other shapes of single-leaf trees are
+     *         caught after the general tree build below ---- */
     unsigned long long pt = DPROF_T();
+    if (tree_len == 5) {
+        int16_t e5[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) e5[i] = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
+        if (e5[0] != -1 && e5[1] != -1 && e5[2] == -1 && e5[3] == -1 && e5[4] == -1) {
+            __syncthreads();
+            if (tid == 0) sh.firstone = DEC_NO_BAD;
+            __syncthreads();
+            return decode_single_leaf<THREADS>(sh, (uint32_t)(uint8_t)e5[1], tree + 10, block_len, pay_bytes, gout,
+                                               end_bits, produced_out);
+        }
+    }
+
+    /* ---- 1. tree ---- */
     __syncthreads();           /* previous user of sh is done */
     uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0][0]);   /* S(i); payload not staged yet */
     static_assert(sizeof(sh.pay) >= ENT * sizeof(uint16_t), "S(i) scratch must fit");
@@ -1232,37 +1287,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
     {
         const uint32_t l0 = sh.left[0];
-        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL) {
-            const uint32_t symv = (uint32_t)(uint8_t)sh.ent[l0];
-            const uint64_t have = dmin<uint64_t>(block_len, pay_bits);       /* bits we may look at */
-            const uint64_t nwords = (have + 31) >> 5;
-            uint32_t first = DEC_NO_BAD;
-            for (uint64_t w = (uint64_t)tid; w < nwords; w += THREADS) {
-                uint32_t v = load_be32(pay, w * 4, pay_bytes);
-                const uint64_t left_bits = have - (w << 5);
-                if (left_bits < 32) v &= ~(0xffffffffu >> (uint32_t)left_bits);
-                if (v) { first = (uint32_t)dmin<uint64_t>(first, (w << 5) + (uint32_t)__clz(v)); break; }
-            }
-            if (first != DEC_NO_BAD) atomicMin(&sh.firstone, first);
-            __syncthreads();
-            const uint32_t fo = sh.firstone;
-            const uint64_t good = (fo != DEC_NO_BAD) ? (uint64_t)fo : have;
-            /* fill gout[0, good) */
-            const uint32_t rep = symv * 0x01010101u;
-            const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
-            if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
-            uint4 *q = reinterpret_cast<uint4 *>(gout + head);
-            const uint64_t nvec = (good - head) >> 4;
-            const uint4 v4 = make_uint4(rep, rep, rep, rep);
-            for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
-            const uint64_t tail0 = head + (nvec << 4);
-            if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
-            *produced_out = good;
-            if (fo != DEC_NO_BAD) return HUFE_CORRUPTED;                     /* decoder.c:69-71 */
-            if (have < block_len) return HUFE_RW;                            /* decoder.c:53-56 */
-            *end_bits = block_len;
-            return HUFE_OK;
-        }
+        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL)
+            return decode_single_leaf<THREADS>(sh, (uint32_t)(uint8_t)sh.ent[l0], pay, block_len, pay_bytes, gout,
+                                               end_bits, produced_out);
     }
 
     /* ---- 3. lookup table ---- */

@@ -144,7 +144,15 @@ __global__ __launch_bounds__(THREADS) void hist256_kernel(const uint8_t *__restr
 
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
-    for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
+    uint64_t i = (uint64_t)tid;
+    for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
+        const uint4 v0 = q[i], v1 = q[i + THREADS], v2 = q[i + 2 * THREADS], v3 = q[i + 3 * THREADS];
+        hist_add_chunk(mine, v0);
+        hist_add_chunk(mine, v1);
+        hist_add_chunk(mine, v2);
+        hist_add_chunk(mine, v3);
+    }
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
 
     const uint64_t tail0 = head + (nvec << 4);
     if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
@@ -526,25 +534,65 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
  * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
  * Single workgroup; offsets[nblocks] = stream length.
  * ==================================================================================== */
+/* Exclusive prefix sum of f(i), i < n, by ONE workgroup (n is the block count: 16 384 per GiB).
+ * Per chunk of THREADS*PER elements: coalesced loads into an LDS tile (padded one word per 32
+ * against bank conflicts), every lane sums PER consecutive elements, one workgroup scan, the
+ * per-element prefixes go back through the tile and out with coalesced stores - 5 barriers per
+ * chunk instead of 2 per THREADS elements. */
+#define SCAN_PER 4
+template <int THREADS, typename F>
+__device__ __forceinline__ uint64_t chunked_excl_scan(uint64_t n, uint64_t *__restrict__ out, F f)
+{
+    constexpr int CH = THREADS * SCAN_PER;
+    __shared__ uint64_t s_tile[CH + CH / 32 + 1];
+    __shared__ uint64_t s_part[THREADS / 64];
+    const int tid = (int)threadIdx.x;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += CH) {
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t k = (uint32_t)(j * THREADS + tid);
+            const uint64_t i = base + k;
+            s_tile[k + (k >> 5)] = (i < n) ? f(i) : 0ull;
+        }
+        __syncthreads();
+        uint64_t local[SCAN_PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t k = (uint32_t)(tid * SCAN_PER + j);
+            local[j] = s_tile[k + (k >> 5)];
+            sum += local[j];
+        }
+        uint64_t total;
+        uint64_t run = block_excl_scan<THREADS, uint64_t>(sum, s_part, total);
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t k = (uint32_t)(tid * SCAN_PER + j);
+            s_tile[k + (k >> 5)] = run;
+            run += local[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t k = (uint32_t)(j * THREADS + tid);
+            const uint64_t i = base + k;
+            if (i < n) out[i] = carry + s_tile[k + (k >> 5)];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    return carry;
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta *__restrict__ meta,
                                                              uint64_t nblocks, uint64_t *__restrict__ offsets)
 {
-    __shared__ uint64_t s_part[THREADS / 64];
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < nblocks; base += THREADS) {
-        const uint64_t i = base + threadIdx.x;
-        uint64_t v = 0;
-        if (i < nblocks) {
-            const HufBlockMeta m = meta[i];
-            v = HUF_HEADER_FIXED + 2ull * m.tree_len + ((m.payload_bits + 7) >> 3);
-        }
-        uint64_t total;
-        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(v, s_part, total);
-        if (i < nblocks) offsets[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) offsets[nblocks] = carry;
+    const uint64_t total = chunked_excl_scan<THREADS>(nblocks, offsets, [meta](uint64_t i) {
+        const HufBlockMeta m = meta[i];
+        return (uint64_t)HUF_HEADER_FIXED + 2ull * m.tree_len + ((m.payload_bits + 7) >> 3);
+    });
+    if (threadIdx.x == 0) offsets[nblocks] = total;
 }
 
 /* ======================================================================================
@@ -650,6 +698,27 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         else {
             for (uint32_t k = rec_lo - 4 * w; k < 4; k++) g_a0[4 * w + k] = (uint8_t)(v >> (8 * k));
         }
+    }
+    if (tree_len == 5) {
+        /* One distinct byte in the block: its code is the single bit 0 (tree.c:410-413 with one
+         * leaf), so the payload is ceil(len/8) zero bytes - nothing of the input needs reading
+         * again (the histogram already saw it). */
+        for (uint32_t bp = (hdr_end & ~3u) + tid; bp < hdr_end; bp += THREADS)       /* header bytes of the seam word */
+            g_a0[bp] = (uint8_t)header_byte(bp - rec_lo, len, tree_len, tb);
+        const uint64_t z0 = hdr_end, z1 = rec_hi;                /* zero bytes [z0, z1) relative to A0 */
+        const uint64_t a0 = dmin<uint64_t>((z0 + 15) & ~15ull, z1);
+        const uint64_t a1 = dmax<uint64_t>(a0, z1 & ~15ull);
+        /* g_a0 is 4-byte aligned; 16-byte stores need the absolute address aligned */
+        const uint64_t skew = (uint64_t)((uintptr_t)g_a0 & 15u);
+        const uint64_t b0 = dmin<uint64_t>(((z0 + skew + 15) & ~15ull) - skew, z1);
+        const uint64_t b1 = dmax<uint64_t>(b0, ((z1 + skew) & ~15ull) - skew);
+        (void)a0; (void)a1;
+        for (uint64_t bp = z0 + tid; bp < b0; bp += THREADS) g_a0[bp] = 0;
+        uint4 *q = reinterpret_cast<uint4 *>(g_a0 + b0);
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t i = (uint64_t)tid; i < ((b1 - b0) >> 4); i += THREADS) q[i] = zero4;
+        for (uint64_t bp = b1 + tid; bp < z1; bp += THREADS) g_a0[bp] = 0;
+        return;
     }
     if (tid == 0) {
         uint32_t t = 0;                                          /* big-endian partial word */
@@ -810,19 +879,10 @@ __global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta 
                                                             uint64_t nblocks, uint64_t *__restrict__ out_offsets,
                                                             unsigned long long *__restrict__ result)
 {
-    __shared__ uint64_t s_part[THREADS / 64];
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < nblocks; base += THREADS) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t v = (i < nblocks) ? dmeta[i].block_len : 0;
-        uint64_t total;
-        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(v, s_part, total);
-        if (i < nblocks) out_offsets[i] = carry + ex;
-        carry += total;
-    }
+    const uint64_t total = chunked_excl_scan<THREADS>(nblocks, out_offsets, [dmeta](uint64_t i) { return dmeta[i].block_len; });
     if (threadIdx.x == 0) {
-        out_offsets[nblocks] = carry;
-        result[1] = carry;
+        out_offsets[nblocks] = total;
+        result[1] = total;
     }
 }
 

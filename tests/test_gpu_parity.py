@@ -130,6 +130,36 @@ def test_encode_random_vs_oracle(torch_mod, codec, oracle, seed):
     assert np.array_equal(offs, woffs)
 
 
+def test_one_symbol_blocks_any_alignment(torch_mod, codec, oracle):
+    """Blocks of one distinct byte take dedicated paths in pack (zero payload) and decode (fill);
+    exercise them at odd block sizes, odd stream offsets and next to ordinary blocks."""
+    rng = np.random.default_rng(77)
+    for bs in (1, 3, 7, 8, 33, 255, 333, 4096, 5001, 65536):
+        parts = []
+        for i in range(12):
+            if i % 3 == 2:
+                parts.append(rng.integers(0, 7, size=bs, dtype=np.uint8))          # ordinary block
+            else:
+                parts.append(np.full(bs, int(rng.integers(0, 256)), np.uint8))     # one-symbol block
+        parts.append(np.full(max(1, bs // 3), 0x41, np.uint8))                     # short one-symbol tail
+        data = np.concatenate(parts)
+        want, woffs = oracle.encode(data, bs, with_offsets=True)
+        out, offs = gpu_encode(torch_mod, codec, data, bs)
+        assert np.array_equal(out, want), (bs, first_diff(out, want))
+        back = gpu_decode_indexed(torch_mod, codec, out, offs, data.size)
+        assert np.array_equal(back, data), (bs, first_diff(back, data))
+        # a 1 bit inside an all-zero payload must be reported as a corrupted tree (decoder.c:69-71)
+        bad = want.copy()
+        pos = int(woffs[0]) + 20                      # first payload byte of block 0 (header is 20 bytes)
+        if pos < int(woffs[1]):
+            bad[pos] |= 0x80
+            torch = torch_mod
+            o = torch.empty(data.size + 8, dtype=torch.uint8, device="cuda")
+            err, raw, _ = codec.decode_stream(to_dev(torch, bad), bad.size, bad.size, o)
+            oerr, oout, _ = oracle.decode(bad, data.size + 8)
+            assert err == oerr == 6 and raw == oout.size == 0
+
+
 def test_encode_deep_codes(torch_mod, codec, oracle):
     """Fibonacci-weighted inputs give the longest codes a block can have (22 bits at 64 KiB,
     >32 bits needs > 5.7 MB: exercised with one 8 MiB block)."""

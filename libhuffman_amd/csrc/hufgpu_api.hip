@@ -357,7 +357,10 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     STAGE_MARK(ctx, s);
     scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
     STAGE_MARK(ctx, s);
-    pack_kernel<PACK_THREADS><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
+    if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
+        pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
+    else
+        pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
 

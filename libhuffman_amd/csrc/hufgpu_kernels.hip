@@ -614,6 +614,7 @@ __global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta 
  * last word are byte-masked because neighbouring blocks own the rest of those words.
  * ==================================================================================== */
 #define PACK_SPT 32
+#define PACK_STAGE_WORDS 3328          /* 13 KiB: a 256x32-symbol tile at up to ~12.9 bits per symbol */
 
 template <typename CodeT>
 struct PackAcc {
@@ -621,7 +622,7 @@ struct PackAcc {
     uint32_t nacc;      /* number of them (< 32 between pushes) */
     uint32_t first;     /* first finished word (its leading bits belong to the left neighbour) */
     bool have_first;
-    uint32_t *gw;       /* where the next finished word goes */
+    uint32_t *gw;       /* where the next finished word goes (LDS stage or HBM, fixed per tile) */
 
     __device__ __forceinline__ void emit(uint32_t word)
     {
@@ -669,7 +670,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                                            const hufcode_t *__restrict__ codes64,
                                            const int16_t *__restrict__ tb, uint32_t tree_len,
                                            uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
-                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail)
+                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage)
 {
     constexpr int TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
@@ -758,17 +759,36 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         uint32_t tile_bits;
         const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
 
-        /* ---- shift the codes out ---- */
+        /* ---- shift the codes out ----
+         * Finished words go to an LDS stage laid out like the destination (stage word i <-> HBM
+         * address stage_addr + 4 i, both 16-byte aligned), then the workgroup flushes the stage
+         * with 16-byte stores: lanes' words are adjacent in memory but not in time, so storing
+         * them one by one costs a partially filled store instruction per word.  A tile whose
+         * codes are too long for the stage (possible only far above the 9-bit average) stores
+         * straight to HBM instead. */
         const uint64_t s = bitpos + ex;                          /* my first bit */
+        const uint64_t w_lo = bitpos >> 5, w_hi = (bitpos + tile_bits) >> 5;   /* tile's finished words [w_lo, w_hi) */
+        const uintptr_t stage_addr = (uintptr_t)(g_w0 + w_lo) & ~(uintptr_t)15;
+        const uint32_t i_lo = (uint32_t)(((uintptr_t)(g_w0 + w_lo) - stage_addr) >> 2);
+        const uint32_t i_hi = i_lo + (uint32_t)(w_hi - w_lo);
+        const bool staged = i_hi + 2 <= PACK_STAGE_WORDS;        /* wave-uniform */
         PackAcc<CodeT> a;
         a.acc = 0;
         a.nacc = (uint32_t)(s & 31u);                            /* leading bits come from the left */
         a.have_first = false;
         a.first = 0;
-        a.gw = g_w0 + (s >> 5);
-        uint32_t *const first_gw = a.gw;
+        uint32_t *const g_first = g_w0 + (s >> 5);
+        uint32_t *const s_first = s_stage + (i_lo + (uint32_t)((s >> 5) - w_lo));
+        if (staged) {
+            a.gw = s_first;
 #pragma unroll
-        for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);      /* absent symbols have len 0 */
+            for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);  /* absent symbols have len 0 */
+        } else {
+            a.gw = g_first;
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);
+        }
+        const uint32_t nwords = (uint32_t)(a.gw - (staged ? s_first : g_first));   /* finished words of this lane */
         const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
 
         /* ---- tails hop one lane to the right ---- */
@@ -779,7 +799,9 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint32_t n_in = (uint32_t)(s & 31u);
         const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
         if (a.have_first) {
-            *first_gw = __builtin_bswap32(a.first | (n_in ? (in_tail << (32 - n_in)) : 0u));
+            const uint32_t word = __builtin_bswap32(a.first | (n_in ? (in_tail << (32 - n_in)) : 0u));
+            if (staged) *s_first = word;
+            else *g_first = word;
         }
         uint32_t out_tail = tail_val;
         if (!a.have_first && nsym > 0) {
@@ -792,17 +814,33 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
              * the next block */
             const uint32_t word = out_tail << (32 - a.nacc);
             const uint32_t nbytes = (a.nacc + 7) >> 3;
-            uint8_t *b = reinterpret_cast<uint8_t *>(a.gw);
+            uint8_t *b = reinterpret_cast<uint8_t *>(g_first + nwords);
             for (uint32_t k = 0; k < nbytes; k++) b[k] = (uint8_t)(word >> (24 - 8 * k));
         }
-        __syncthreads();                                         /* s_tail is rewritten next tile */
+        __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
         if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
+        if (staged) {
+            uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
+            for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
+                const uint32_t i0 = 4 * u;
+                if (i0 >= i_lo && i0 + 4 <= i_hi) {
+                    *reinterpret_cast<uint4 *>(g16 + 4 * i0) = *reinterpret_cast<const uint4 *>(s_stage + i0);
+                } else {
+                    for (uint32_t i = (i0 > i_lo ? i0 : i_lo); i < i0 + 4 && i < i_hi; i++)
+                        *reinterpret_cast<uint32_t *>(g16 + 4 * i) = s_stage[i];
+                }
+            }
+        }
         bitpos += tile_bits;
         (void)rec_hi;
     }
 }
 
-template <int THREADS>
+/* SHORT = true: the host guarantees that no code of this launch is longer than 24 bits (any
+ * Huffman merge order on n <= 121392 symbols gives depth <= 23, plus the wrap-root bit; the
+ * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
+ * registers, more waves. */
+template <int THREADS, bool SHORT>
 __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                        uint64_t blocksize,
                                                        const hufcode_t *__restrict__ codetab,
@@ -811,9 +849,10 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ offsets,
                                                        uint8_t *__restrict__ out)
 {
-    __shared__ hufcode_t s_code[HUF_NSYM];                       /* viewed as u32[256] on the short-code path */
+    __shared__ hufcode_t s_code[SHORT ? HUF_NSYM / 2 : HUF_NSYM];   /* u32[256] on the short-code path */
     __shared__ uint32_t s_part[THREADS / 64];
     __shared__ uint32_t s_tail[THREADS / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
 
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
@@ -821,12 +860,12 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
     const HufBlockMeta m = meta[blk];
     const hufcode_t *codes = codetab + blk * HUF_NSYM;
     const int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
-    if (m.max_len <= 24)
+    if (SHORT || m.max_len <= 24)
         pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
-                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail);
-    else
+                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage);
+    else if constexpr (!SHORT)
         pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
-                                       s_code, s_part, s_tail);
+                                       s_code, s_part, s_tail, s_stage);
 }
 
 /* ======================================================================================

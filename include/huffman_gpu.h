@@ -39,6 +39,9 @@ typedef struct hufgpu_ctx hufgpu_ctx_t;   /* per-device workspace + stream; not 
 #define HUFGPU_RELAXED_TREE 1u  /* accept the 1025-entry tree the encoder itself emits for blocks
                                    with all 256 byte values */
 
+#define HUFGPU_SEQUENTIAL   2u  /* hufgpu_decode_stream only: skip the parallel block discovery and take the
+                                   blocks strictly in order (diagnostics; results are identical) */
+
 /* Largest block the kernels take (bytes).  Larger blocks -> HUF_ERROR_INVALID_ARGUMENT. */
 #define HUFGPU_MAX_BLOCK ((uint64_t)1 << 30)
 
@@ -93,7 +96,11 @@ int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
 /*
  * Decode a raw stream (no index): `avail` bytes are readable at d_stream, `length` compressed
  * bytes drive the block loop exactly like config->length in src/decoder.c:218.  Block
- * boundaries are discovered on the device.  Synchronous.
+ * boundaries are discovered on the device: every byte offset is tested for a valid header,
+ * every candidate is decoded in count-only mode to find its end, the chain from offset 0 is
+ * followed, the validated blocks are decoded in parallel and anything else (errors, odd
+ * headers, tails) goes to an exact in-order decoder - results, errors and byte counts are those
+ * of the reference in every case.  Synchronous.
  */
 int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                          void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,

@@ -109,12 +109,13 @@ class GpuCodec:
         return int(raw.value)
 
     def decode_stream(self, stream: torch.Tensor, avail: int, length: int, out: torch.Tensor,
-                      relaxed: bool = False):
-        """Raw-stream decode (no index). Returns (err, bytes written, bytes consumed)."""
+                      relaxed: bool = False, sequential: bool = False):
+        """Raw-stream decode (no index). Returns (err, bytes written, bytes consumed).
+        sequential=True forces the in-order decoder (same results, for cross-checking)."""
         raw, used = C.c_uint64(0), C.c_uint64(0)
+        flags = (_native.RELAXED_TREE if relaxed else _native.STRICT_TREE) | (2 if sequential else 0)
         err = self.lib.hufgpu_decode_stream(self._ctx, stream.data_ptr() if stream.numel() else None,
-                                            avail, length, out.data_ptr(), out.numel(),
-                                            _native.RELAXED_TREE if relaxed else _native.STRICT_TREE,
+                                            avail, length, out.data_ptr(), out.numel(), flags,
                                             C.byref(raw), C.byref(used), self._stream())
         return int(err), int(raw.value), int(used.value)
 

@@ -48,6 +48,15 @@ struct hufgpu_ctx {
     uint64_t *d_out_offsets;
     int32_t *d_status;
 
+    /* raw-stream discovery workspace */
+    uint64_t disc_wgs, disc_cands;
+    uint32_t *d_wg_counts;
+    uint64_t *d_wg_base;
+    uint64_t *d_cand, *d_cand_end, *d_chain;
+    int32_t *d_cand_status;
+    uint32_t *d_nxt;
+    uint64_t *d_walk;             /* 4 result words of walk_kernel */
+
     uint64_t *d_result;           /* 4 words: err, raw_len, failing block, spare */
     uint64_t *h_result;           /* pinned mirror */
     uint64_t *d_zipf;             /* 255 cumulative weights */
@@ -149,6 +158,7 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     HIP_OK(NULL, hipSetDevice(device));
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 4 * sizeof(uint64_t)));
     HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(uint64_t), hipHostMallocDefault));
 
     /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
@@ -174,6 +184,15 @@ static void free_encode_ws(hufgpu_ctx *c)
     c->ws_blocks = 0;
 }
 
+static void free_disc_ws(hufgpu_ctx *c, int which)
+{
+    if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); c->d_wg_counts = NULL; c->d_wg_base = NULL; c->disc_wgs = 0; }
+    if (which & 2) {
+        (void)hipFree(c->d_cand); (void)hipFree(c->d_cand_end); (void)hipFree(c->d_chain); (void)hipFree(c->d_cand_status); (void)hipFree(c->d_nxt);
+        c->d_cand = c->d_cand_end = c->d_chain = NULL; c->d_cand_status = NULL; c->d_nxt = NULL; c->disc_cands = 0;
+    }
+}
+
 static void free_decode_ws(hufgpu_ctx *c)
 {
     (void)hipFree(c->d_dmeta);
@@ -190,6 +209,8 @@ extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_encode_ws(ctx);
     free_decode_ws(ctx);
+    free_disc_ws(ctx, 3);
+    (void)hipFree(ctx->d_walk);
     (void)hipFree(ctx->d_result);
     (void)hipFree(ctx->d_zipf);
     (void)hipHostFree(ctx->h_result);
@@ -435,6 +456,25 @@ extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t s
     return HUFE_OK;
 }
 
+#ifdef DISC_DEBUG
+#define DISC_TRACE(msg) do { (void)hipStreamSynchronize(s); fprintf(stderr, "disc: %s\n", msg); fflush(stderr); } while (0)
+#else
+#define DISC_TRACE(msg) do { } while (0)
+#endif
+
+/* The exact sequential decoder (one workgroup, blocks in order). */
+static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint8_t *out,
+                        uint64_t out_cap, int max_tree, hipStream_t s, uint64_t *raw, uint64_t *used)
+{
+    decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>(st, avail, length, max_tree, out, out_cap, ctx->d_result, NULL, 0);
+    HIP_OK(ctx, hipGetLastError());
+    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipStreamSynchronize(s));
+    *raw = ctx->h_result[1];
+    *used = ctx->h_result[2];
+    return (int)ctx->h_result[0];
+}
+
 extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                                     void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                                     uint64_t *consumed, void *stream)
@@ -447,16 +487,89 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
     HIP_OK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
     const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
-    STAGE_BEGIN(ctx, s, PROF_DECODE);
-    decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_stream, avail, length, max_tree,
-                                                                        (uint8_t *)d_out, out_cap, ctx->d_result, NULL, 0);
-    STAGE_MARK(ctx, s);
-    HIP_OK(ctx, hipGetLastError());
-    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_OK(ctx, hipStreamSynchronize(s));
-    if (raw_len) *raw_len = ctx->h_result[1];
-    if (consumed) *consumed = ctx->h_result[2];
-    const int err = (int)ctx->h_result[0];
+    const uint8_t *st = (const uint8_t *)d_stream;
+    uint8_t *out = (uint8_t *)d_out;
+    uint64_t raw = 0, used = 0;
+    int err = HUFE_OK;
+
+    /* ---- parallel path: discover the block chain, decode the validated prefix ---- */
+    uint64_t prefix_raw = 0, resume = 0;
+    bool complete = false;
+    const uint64_t scan_len = length < avail ? length : avail;
+    const bool try_parallel = (((uintptr_t)st & 15u) == 0) && scan_len >= 4096 && !(flags & HUFGPU_SEQUENTIAL);
+    if (try_parallel) {
+        const uint64_t nwg = (scan_len + DISC_CHUNK - 1) / DISC_CHUNK;
+        if (nwg > ctx->disc_wgs) {
+            HIP_OK(ctx, hipStreamSynchronize(s));
+            free_disc_ws(ctx, 1);
+            const uint64_t cap = nwg + nwg / 8 + 16;
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1) * sizeof(uint64_t)));
+            ctx->disc_wgs = cap;
+        }
+        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL);
+        DISC_TRACE("discover count done");
+        scan_counts_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base);
+        DISC_TRACE("scan done");
+        HIP_OK(ctx, hipGetLastError());
+        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_wg_base + nwg, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipStreamSynchronize(s));
+        const uint64_t ncand = ctx->h_result[0];
+#ifdef DISC_DEBUG
+        fprintf(stderr, "disc: ncand=%llu nwg=%llu\n", (unsigned long long)ncand, (unsigned long long)nwg);
+#endif
+        if (ncand > 0 && ncand < 0x7fffffffull) {
+            if (ncand > ctx->disc_cands) {
+                free_disc_ws(ctx, 2);
+                const uint64_t cap = ncand + ncand / 8 + 16;
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_end, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
+                ctx->disc_cands = cap;
+            }
+            discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand);
+            DISC_TRACE("discover write done");
+            probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status);
+            DISC_TRACE("probe done");
+            link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
+            DISC_TRACE("link done");
+            walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk);
+            DISC_TRACE("walk done");
+            HIP_OK(ctx, hipGetLastError());
+            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_OK(ctx, hipStreamSynchronize(s));
+            const uint64_t m = ctx->h_result[0];
+            complete = ctx->h_result[2] != 0;
+            resume = complete ? ctx->h_result[3] : ctx->h_result[1];
+            if (m > 0) {
+                err = hufgpu_decode(ctx, st, resume, ctx->d_chain, m, out, out_cap, flags, &prefix_raw, stream);
+                if (err != HUFE_OK) {                  /* cannot happen for probed blocks except for lack of room */
+                    if (err == HUFE_MEMORY) { if (raw_len) *raw_len = prefix_raw; return err; }
+                    prefix_raw = 0; resume = 0; complete = false;   /* start over, sequentially */
+                }
+            } else {
+                resume = 0; complete = false;
+            }
+        }
+    }
+    if (complete) {
+        raw = prefix_raw;
+        used = resume;
+        err = HUFE_OK;
+    } else {
+        /* ---- exact sequential decoder for what is left (all of it when nothing was validated) ---- */
+        uint64_t raw2 = 0, used2 = 0;
+        STAGE_BEGIN(ctx, s, PROF_DECODE);
+        err = decode_chain(ctx, st + resume, avail - resume, length - resume, out + prefix_raw,
+                           out_cap - prefix_raw, max_tree, s, &raw2, &used2);
+        STAGE_MARK(ctx, s);
+        raw = prefix_raw + raw2;
+        used = resume + used2;
+    }
+    if (raw_len) *raw_len = raw;
+    if (consumed) *consumed = used;
     if (err == HUFE_ARGUMENT) set_err(ctx, "a block is longer than the kernels support");
     if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small");
     return err;

@@ -1181,10 +1181,25 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
 
 /* Write pass: the lane's first `quota` symbols go to g[0..quota). Returns the position after
  * the last one.  The track has been validated by the count pass, so every codeword decodes. */
-template <int THREADS>
+template <int THREADS, bool STORE>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
 {
+    if (!STORE) {                       /* probe mode: only the position after the quota is wanted */
+        WordReader<DecShared<THREADS>::COLS> rd0;
+        rd0.pay = sh.pay;
+        rd0.load(start);
+        uint32_t p0 = start;
+        for (uint32_t c = 0; c < quota; c++) {
+            const uint32_t e = sh.lut[rd0.window(p0) >> (32 - DEC_LUT_BITS)];
+            uint32_t len = e >> 8;
+            if (e >= 0x4000u) len = (uint32_t)dec_rare_packed<THREADS>(sh, e, p0, pay_rel) - p0;
+            p0 += len;
+            const uint32_t ng = p0 >> 5;
+            if (ng != rd0.g) rd0.step_to(ng);
+        }
+        return p0;
+    }
     WordReader<DecShared<THREADS>::COLS> rd;
     rd.pay = sh.pay;
     rd.load(start);
@@ -1230,7 +1245,7 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
 /* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit
  * leaves the tree (src/decoder.c:69-71).  Scan the needed payload bits for a set bit, then the
  * output is a fill.  sh.firstone must be DEC_NO_BAD on entry. */
-template <int THREADS>
+template <int THREADS, bool STORE>
 __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const uint8_t *pay, uint64_t block_len,
                                   uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits, uint64_t *produced_out)
 {
@@ -1249,16 +1264,17 @@ __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const u
     __syncthreads();
     const uint32_t fo = sh.firstone;
     const uint64_t good = (fo != DEC_NO_BAD) ? (uint64_t)fo : have;
-    /* fill gout[0, good) */
-    const uint32_t rep = symv * 0x01010101u;
-    const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
-    if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
-    uint4 *q = reinterpret_cast<uint4 *>(gout + head);
-    const uint64_t nvec = (good - head) >> 4;
-    const uint4 v4 = make_uint4(rep, rep, rep, rep);
-    for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
-    const uint64_t tail0 = head + (nvec << 4);
-    if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
+    if (STORE) {                        /* fill gout[0, good) */
+        const uint32_t rep = symv * 0x01010101u;
+        const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
+        if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
+        uint4 *q = reinterpret_cast<uint4 *>(gout + head);
+        const uint64_t nvec = (good - head) >> 4;
+        const uint4 v4 = make_uint4(rep, rep, rep, rep);
+        for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
+        const uint64_t tail0 = head + (nvec << 4);
+        if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
+    }
     *produced_out = good;
     if (fo != DEC_NO_BAD) return HUFE_CORRUPTED;                     /* decoder.c:69-71 */
     if (have < block_len) return HUFE_RW;                            /* decoder.c:53-56 */
@@ -1270,7 +1286,7 @@ __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const u
  * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
  * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
  * symbol (valid on success); *produced_out = symbols delivered (also on failure). */
-template <int THREADS>
+template <int THREADS, bool STORE = true>
 __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
                             uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits,
                             uint64_t *produced_out)
@@ -1292,7 +1308,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             __syncthreads();
             if (tid == 0) sh.firstone = DEC_NO_BAD;
             __syncthreads();
-            return decode_single_leaf<THREADS>(sh, (uint32_t)(uint8_t)e5[1], tree + 10, block_len, pay_bytes, gout,
+            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)(uint8_t)e5[1], tree + 10, block_len, pay_bytes, gout,
                                                end_bits, produced_out);
         }
     }
@@ -1387,7 +1403,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     {
         const uint32_t l0 = sh.left[0];
         if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL)
-            return decode_single_leaf<THREADS>(sh, (uint32_t)(uint8_t)sh.ent[l0], pay, block_len, pay_bytes, gout,
+            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)(uint8_t)sh.ent[l0], pay, block_len, pay_bytes, gout,
                                                end_bits, produced_out);
     }
 
@@ -1493,9 +1509,14 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         quota = 0;
         if (tid == 0) sh.qend = sh.end[THREADS - 1] == DEC_EXH ? pay_rel : sh.end[THREADS - 1];
 #endif
-        if (quota) {
-            const uint32_t qe = dec_write<THREADS>(sh, tr.start, pay_rel, quota, gout + produced + ex);
-            if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
+        if (STORE) {
+            if (quota) {
+                const uint32_t qe = dec_write<THREADS, true>(sh, tr.start, pay_rel, quota, gout + produced + ex);
+                if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
+            }
+        } else if (quota && ex + quota == take && remaining <= good) {
+            /* probe: only the lane that holds the block's last symbol walks, to find where it ends */
+            sh.qend = dec_write<THREADS, false>(sh, tr.start, pay_rel, quota, nullptr);
         }
         const uint32_t last_end = sh.end[THREADS - 1];
         __syncthreads();
@@ -1594,6 +1615,205 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
         result[2] = rd;
         result[3] = nblk;
         if (block_offsets && nblk < max_index) block_offsets[nblk] = rd;
+    }
+}
+
+/* ======================================================================================
+ * Raw-stream block discovery (SURVEY §7.3-A option 2, §8f-2).
+ *
+ * The wire format stores no payload length, so the header of block i+1 is only found by
+ * decoding block i.  To break that chain without changing any result:
+ *   1. discover_kernel tests EVERY byte offset for a syntactically valid header
+ *      (block_len in range, tree_len in [1, max], a preorder tree that consumes exactly tree_len
+ *      entries, enough bytes left) - every real header passes, almost nothing else does;
+ *   2. probe_kernel decodes every candidate in count-only mode (decode_block<.., false>), which
+ *      yields the offset right behind its payload;
+ *   3. link_kernel / walk_kernel follow the chain offset 0 -> end(0) -> ... through the sorted
+ *      candidates; a false candidate can never be entered, because a real block's end is the
+ *      next real header;
+ *   4. the validated prefix is decoded by the indexed kernels; whatever the walk could not
+ *      validate (an erroring block, a header the strict test rejects, trailing garbage) is left
+ *      to decode_chain_kernel, the exact sequential restatement - so errors, partial output and
+ *      consumed-byte counts are those of src/decoder.c in every case.
+ * ==================================================================================== */
+#define DISC_THREADS 256
+#define DISC_PER 16
+#define DISC_CHUNK (DISC_THREADS * DISC_PER)
+#define LINK_BAD      0xfffffffdu
+#define LINK_TERMINAL 0xfffffffeu
+#define LINK_NOTFOUND 0xffffffffu
+
+__device__ __forceinline__ bool tree_grammar_complete(const uint8_t *t, int tl)
+{
+    int open = 1;                               /* child slots still to be filled */
+    for (int i = 0; i < tl; i++) {
+        if (open == 0) return false;            /* entries behind a complete tree */
+        const int16_t v = (int16_t)((uint16_t)t[2 * i] | ((uint16_t)t[2 * i + 1] << 8));
+        open += (v != -1) ? 1 : -1;
+    }
+    return open == 0;
+}
+
+/* stream must be 16-byte aligned.  WRITE = false: per-workgroup candidate counts;
+ * WRITE = true: candidates written in ascending order at wg_base[workgroup]. */
+template <bool WRITE>
+__global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
+                                                                uint64_t scan_len, int max_tree_len,
+                                                                uint32_t *__restrict__ wg_counts,
+                                                                const uint64_t *__restrict__ wg_base,
+                                                                uint64_t *__restrict__ cand)
+{
+    __shared__ uint32_t s_part[DISC_THREADS / 64];
+    const uint64_t p0 = (uint64_t)blockIdx.x * DISC_CHUNK + (uint64_t)threadIdx.x * DISC_PER;
+    uint32_t mask = 0;
+    if (p0 < scan_len) {
+        uint32_t w[8];
+        const uint4 a = *reinterpret_cast<const uint4 *>(stream + p0);          /* 16-byte unit that holds a valid byte */
+        uint4 b = make_uint4(0u, 0u, 0u, 0u);
+        if (p0 + 16 < avail) b = *reinterpret_cast<const uint4 *>(stream + p0 + 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+#pragma unroll
+        for (int k = 0; k < DISC_PER; k++) {
+            const uint64_t p = p0 + k;
+            /* little-endian fields at byte k of the window */
+            const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
+            if (hi != 0 || p >= scan_len || avail - p < HUF_HEADER_FIXED) continue;   /* block_len < 2^32 */
+            const uint32_t lo = __funnelshift_r(w[k >> 2], w[(k >> 2) + 1], 8 * (k & 3));
+            if (lo == 0) continue;
+            const uint32_t t16 = __funnelshift_r(w[(k + 8) >> 2], w[((k + 8) >> 2) + 1], 8 * ((k + 8) & 3)) & 0xffffu;
+            const int tl = (int)(int16_t)t16;
+            if (tl < 1 || tl > max_tree_len) continue;
+            const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+            if (hdr_end > avail) continue;
+            if ((uint64_t)lo > (avail - hdr_end) * 8ull) continue;               /* every symbol costs a bit */
+            if (!tree_grammar_complete(stream + p + HUF_HEADER_FIXED, tl)) continue;
+            mask |= 1u << k;
+        }
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<DISC_THREADS, uint32_t>((uint32_t)__popc(mask), s_part, total);
+    if (!WRITE) {
+        if (threadIdx.x == 0) wg_counts[blockIdx.x] = total;
+    } else {
+        uint64_t at = wg_base[blockIdx.x] + ex;
+        while (mask) {
+            const int k = __builtin_ctz(mask);
+            mask &= mask - 1;
+            cand[at++] = p0 + (uint64_t)k;
+        }
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                              uint64_t *__restrict__ base)
+{
+    const uint64_t total = chunked_excl_scan<THREADS>(n, base, [counts](uint64_t i) { return (uint64_t)counts[i]; });
+    if (threadIdx.x == 0) base[n] = total;
+}
+
+/* Count-only decode of one candidate: where does its payload end, and does it decode at all? */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void probe_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
+                                                        const uint64_t *__restrict__ cand,
+                                                        uint64_t *__restrict__ cand_end,
+                                                        int32_t *__restrict__ cand_status)
+{
+    __shared__ DecShared<THREADS> sh;
+    const uint64_t c = cand[blockIdx.x];
+    const uint64_t block_len = load_u64_unaligned(stream + c);
+    const int tl = (int)(int16_t)((uint16_t)stream[c + 8] | ((uint16_t)stream[c + 9] << 8));
+    const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+    uint64_t end_bits = 0, produced = 0;
+    const int err = decode_block<THREADS, false>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                                 nullptr, &end_bits, &produced);
+    if (threadIdx.x == 0) {
+        cand_status[blockIdx.x] = err;
+        cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
+    }
+}
+
+__global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *__restrict__ cand_end,
+                            const int32_t *__restrict__ cand_status, uint64_t ncand, uint64_t length,
+                            uint32_t *__restrict__ nxt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand) return;
+    uint32_t r;
+    if (cand_status[i] != HUFE_OK) r = LINK_BAD;
+    else {
+        const uint64_t e = cand_end[i];
+        if (e >= length) r = LINK_TERMINAL;                      /* src/decoder.c:218 loop condition */
+        else {
+            uint64_t lo = i + 1, hi = ncand;                     /* first candidate with offset >= e */
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (cand[mid] < e) lo = mid + 1; else hi = mid;
+            }
+            r = (lo < ncand && cand[lo] == e) ? (uint32_t)lo : LINK_NOTFOUND;
+        }
+    }
+    nxt[i] = r;
+}
+
+/* result: [0] validated blocks m, [1] offset where the sequential decoder must take over
+ * (meaningful when [2] == 0), [2] 1 = the chain reached `length`, [3] bytes consumed then.
+ * block_offsets[0..m] receives the validated block index.
+ * ONE wavefront: lane 0 follows the chain through an LDS copy of nxt[] (the chain only moves
+ * forward, so the copy is refilled chunk by chunk); every loop-control value lives in registers
+ * and is broadcast from lane 0 with a shuffle, so no flag is ever polled in memory. */
+#define WALK_CHUNK 8192
+__global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ cand,
+                                                  const uint64_t *__restrict__ cand_end,
+                                                  const uint32_t *__restrict__ nxt, uint64_t ncand,
+                                                  uint64_t *__restrict__ block_offsets,
+                                                  uint64_t *__restrict__ result)
+{
+    __shared__ uint32_t s_nxt[WALK_CHUNK];
+    __shared__ uint32_t s_list[WALK_CHUNK];
+    const int lane = (int)threadIdx.x;
+    uint64_t cur = 0, m = 0, resume = 0, consumed = 0;
+    int complete = 0;
+    bool stop = (ncand == 0) || (cand[0] != 0);       /* the stream must start with a header */
+    while (!stop) {
+        const uint64_t base = cur - (cur % WALK_CHUNK);
+        for (uint64_t i = (uint64_t)lane; i < WALK_CHUNK && base + i < ncand; i += 64) s_nxt[i] = nxt[base + i];
+        __syncthreads();
+        uint32_t cnt = 0, code = 0;                    /* code: 0 next chunk, 1 bad block, 2 terminal, 3 no header */
+        uint32_t ncur_lo = (uint32_t)cur, ncur_hi = (uint32_t)(cur >> 32);
+        if (lane == 0) {
+            uint64_t c = cur;
+            while (c < base + WALK_CHUNK) {
+                const uint32_t nx = s_nxt[c - base];
+                if (nx == LINK_BAD) { code = 1; break; }
+                s_list[cnt++] = (uint32_t)c;
+                if (nx == LINK_TERMINAL) { code = 2; break; }
+                if (nx == LINK_NOTFOUND) { code = 3; break; }
+                c = nx;                                /* nx > c: the chain only moves forward */
+            }
+            ncur_lo = (uint32_t)c;
+            ncur_hi = (uint32_t)(c >> 32);
+        }
+        cnt = (uint32_t)__shfl((int)cnt, 0);
+        code = (uint32_t)__shfl((int)code, 0);
+        ncur_lo = (uint32_t)__shfl((int)ncur_lo, 0);
+        ncur_hi = (uint32_t)__shfl((int)ncur_hi, 0);
+        const uint64_t ncur = ((uint64_t)ncur_hi << 32) | ncur_lo;
+        __syncthreads();                               /* s_list is complete */
+        for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) block_offsets[m + j] = cand[s_list[j]];
+        m += cnt;
+        if (code == 1) { resume = cand[ncur]; stop = true; }
+        else if (code == 2) { complete = 1; consumed = cand_end[ncur]; stop = true; }
+        else if (code == 3) { resume = cand_end[ncur]; stop = true; }
+        cur = ncur;
+        __syncthreads();                               /* before s_nxt / s_list are reused */
+    }
+    if (lane == 0) {
+        result[0] = m;
+        result[1] = resume;
+        result[2] = (uint64_t)complete;
+        result[3] = consumed;
+        block_offsets[m] = complete ? consumed : resume;   /* end of the validated prefix */
     }
 }
 

@@ -236,6 +236,56 @@ def test_decode_stream_error_goldens(torch_mod, codec, golden):
         assert out[:raw].cpu().numpy().tobytes().hex() == vec["output_hex"], vec["name"]
 
 
+@pytest.mark.parametrize("kind,n,bs", [("zipf255", 3 << 20, 65536), ("uniform256", 1 << 20, 65536),
+                                       ("const41", 4 << 20, 65536), ("logtext", 3 << 20, 1 << 20),
+                                       ("zipf255", 700000, 4097)])
+def test_decode_stream_parallel_discovery(torch_mod, codec, oracle, kind, n, bs):
+    """Raw streams large enough for the parallel block discovery: same bytes, same consumed count
+    as the sequential decoder and the oracle."""
+    torch = torch_mod
+    data = datagen.GENERATORS[kind](n)
+    stream = oracle.encode(data, bs)
+    s = to_dev(torch, stream)
+    for sequential in (False, True):
+        out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(s, stream.size, stream.size, out, relaxed=True, sequential=sequential)
+        assert (err, raw, used) == (0, n, stream.size), (kind, sequential)
+        assert np.array_equal(out[:raw].cpu().numpy(), data)
+
+
+def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
+    """Corruptions in the middle of a long stream: the parallel path hands the unvalidated rest to
+    the in-order decoder, so error code, delivered bytes and consumed count equal the oracle's."""
+    torch = torch_mod
+    rng = np.random.default_rng(4242)
+    data = datagen.zipf255(40 * 8192)
+    good, offs = oracle.encode(data, 8192, with_offsets=True)
+    cases = []
+    for blk in (0, 7, 20, 39):
+        o0, o1 = int(offs[blk]), int(offs[blk + 1])
+        b = good.copy(); b[o0 + 9] = 0x7f; cases.append(("tree_len_overflow", b, None))       # tree_len -> 0x7fxx
+        b = good.copy(); b[o0 + 12] ^= 0xff; b[o0 + 13] ^= 0xff; cases.append(("tree_entry_flip", b, None))
+        b = good.copy(); b[(o0 + o1) // 2] ^= 0x10; cases.append(("payload_bit_flip", b, None))
+        b = good.copy(); b[o0] ^= 0x01; cases.append(("block_len_changed", b, None))
+    cases.append(("truncated", good[: int(offs[33]) + 700].copy(), None))
+    cases.append(("trailing_garbage", np.concatenate([good, np.full(5, 0xee, np.uint8)]), None))
+    cases.append(("length_short", good.copy(), int(offs[11])))
+    cases.append(("length_mid_block", good.copy(), int(offs[11]) + 5))
+    for name, bad, length in cases:
+        oerr, oout, oused = oracle.decode(bad, data.size + 70000, 1024, length=length)
+        if oerr == 1:
+            continue                                            # larger than the oracle's test buffer
+        out = torch.zeros(data.size + 70000, dtype=torch.uint8, device="cuda")
+        ln = bad.size if length is None else length
+        for sequential in (False, True):
+            err, raw, used = codec.decode_stream(to_dev(torch, bad), bad.size, ln, out, sequential=sequential)
+            assert err == oerr, (name, sequential, err, oerr)
+            assert raw == oout.size, (name, sequential, raw, oout.size)
+            assert np.array_equal(out[:raw].cpu().numpy(), oout), (name, sequential)
+            if oerr == 0:
+                assert used == oused, (name, sequential)
+
+
 def test_self_synchronisation_worst_cases(torch_mod, codec, oracle):
     """Inputs on which speculative starts do not re-synchronise by themselves: long runs of
     one symbol whose code is longer than a bit, and fixed-length codes."""

@@ -974,7 +974,7 @@ __device__ unsigned long long g_dec_prof[16];
 
 template <int THREADS>
 struct DecShared {
-    static constexpr int ENT = HUF_TREE_STRIDE;
+    static constexpr int ENT = HUF_TREE_MAX + 1;
     static constexpr int COLS = THREADS + DEC_XCOLS;
     int16_t ent[ENT];
     uint16_t left[ENT];
@@ -982,7 +982,7 @@ struct DecShared {
     uint16_t lut[1 << DEC_LUT_BITS];
     uint32_t pay[DEC_SUB_WORDS][COLS];   /* pay[w][l] = word w of lane l's subsequence */
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
-    uint32_t end[THREADS];               /* end position of each lane, bits relative to the segment */
+    uint32_t wend[THREADS / 64];         /* end position of the last lane of each wave (neighbours use shuffles) */
     uint32_t part[THREADS / 64];
     int efflen;
     uint32_t badsym;                     /* segment symbol index of the first walk that left the tree */
@@ -1456,7 +1456,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         const bool far_from_end = pay_rel >= (uint32_t)(THREADS * DEC_SUB_BITS + DEC_LUT_BITS);
         if (far_from_end) dec_scan<THREADS, false, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
         else dec_scan<THREADS, false, true>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
-        sh.end[tid] = tr.end;
+        if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
         __syncthreads();
         DPROF_ADD(3, pt); pt = DPROF_T();
 #if defined(DEC_ABLATE) && DEC_ABLATE == 5
@@ -1466,14 +1466,16 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 #if defined(DEC_ABLATE) && DEC_ABLATE == 3
             break;
 #endif
-            const uint32_t ns = (tid == 0) ? first_start : sh.end[tid - 1];
+            /* left neighbour's end: a shuffle inside the wave, LDS across the wave seams */
+            uint32_t ns = (uint32_t)__shfl_up((int)tr.end, 1);
+            if ((tid & 63) == 0) ns = (tid == 0) ? first_start : sh.wend[(tid >> 6) - 1];
             const int changed = (ns != tr.start);
-            __syncthreads();                               /* everyone has read sh.end */
+            __syncthreads();                               /* everyone has read sh.wend */
             if (changed) {
                 if (far_from_end) dec_scan<THREADS, true, false>(sh, tr, ns, sub_lo, pay_rel);
                 else dec_scan<THREADS, true, true>(sh, tr, ns, sub_lo, pay_rel);
-                sh.end[tid] = tr.end;
             }
+            if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
 #if defined(DEC_ABLATE) && DEC_ABLATE == 5
             dbg_rounds++;
             dbg_changed_total += __syncthreads_count(changed);
@@ -1507,7 +1509,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         DPROF_ADD(5, pt); pt = DPROF_T();
 #if defined(DEC_ABLATE) && DEC_ABLATE == 4
         quota = 0;
-        if (tid == 0) sh.qend = sh.end[THREADS - 1] == DEC_EXH ? pay_rel : sh.end[THREADS - 1];
+        if (tid == 0) sh.qend = sh.wend[THREADS / 64 - 1] == DEC_EXH ? pay_rel : sh.wend[THREADS / 64 - 1];
 #endif
         if (STORE) {
             if (quota) {
@@ -1518,7 +1520,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             /* probe: only the lane that holds the block's last symbol walks, to find where it ends */
             sh.qend = dec_write<THREADS, false>(sh, tr.start, pay_rel, quota, nullptr);
         }
-        const uint32_t last_end = sh.end[THREADS - 1];
+        const uint32_t last_end = sh.wend[THREADS / 64 - 1];
         __syncthreads();
         DPROF_ADD(6, pt);
         produced += take;
@@ -1536,8 +1538,11 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 }
 
 /* Indexed decode: one workgroup per block, block extents from the in-process index. */
+#ifndef DEC_WAVES_PER_SIMD
+#define DEC_WAVES_PER_SIMD 8      /* 4 workgroups of 512 per CU: caps the kernel at 64 VGPRs (a 48-byte spill), +15 % */
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void decode_kernel(const uint8_t *__restrict__ stream,
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(const uint8_t *__restrict__ stream,
                                                          uint64_t stream_len,
                                                          const uint64_t *__restrict__ offsets,
                                                          const HufDecodeMeta *__restrict__ dmeta,

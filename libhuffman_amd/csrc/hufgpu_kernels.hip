@@ -1407,13 +1407,18 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                                                end_bits, produced_out);
     }
 
-    /* ---- 3. lookup table ---- */
-    for (int idx = tid; idx < (1 << DEC_LUT_BITS); idx += THREADS) {
-        uint32_t node = 0, e = 2u << 14;
+    /* ---- 3. lookup table ----
+     * Two hops of DEC_LUT_BITS/2 bits: first the node (or verdict) reached after the high half
+     * of the index, kept in the low 64 table slots for a moment, then every entry continues
+     * from there - half the dependent LDS steps of walking all 12 bits per entry. */
+    constexpr int HALF = DEC_LUT_BITS / 2;
+    uint32_t hop1 = 0;
+    if (tid < (1 << HALF)) {
+        uint32_t node = 0, e = 0;
         bool done = false;
 #pragma unroll 1
-        for (int b = 0; b < DEC_LUT_BITS; b++) {
-            const uint32_t bit = (idx >> (DEC_LUT_BITS - 1 - b)) & 1u;
+        for (int b = 0; b < HALF; b++) {
+            const uint32_t bit = ((uint32_t)tid >> (HALF - 1 - b)) & 1u;
             const uint32_t nx = bit ? sh.right[node] : sh.left[node];
             if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); done = true; break; }
             node = nx;
@@ -1423,11 +1428,43 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 break;
             }
         }
-        if (!done) e = (1u << 14) | node;
-        sh.lut[idx] = (uint16_t)e;
+        hop1 = done ? e : ((1u << 14) | node);           /* type 1 here: "continue from node" */
+    }
+    __syncthreads();                                      /* nobody reads the LUT region yet: reuse the end of it */
+    uint16_t *s_hop = sh.lut + (1 << DEC_LUT_BITS) - (1 << HALF);
+    if (tid < (1 << HALF)) s_hop[tid] = (uint16_t)hop1;
+    __syncthreads();
+    {
+        constexpr int PERL = (1 << DEC_LUT_BITS) / THREADS;
+        uint16_t mine[PERL > 0 ? PERL : 1];
+#pragma unroll
+        for (int k = 0; k < PERL; k++) {
+            const int idx = tid + k * THREADS;
+            uint32_t e = s_hop[idx >> HALF];
+            if ((e >> 14) == 1u) {                         /* still inside the tree after the first hop */
+                uint32_t node = e & 0x7ffu;
+                bool done = false;
+#pragma unroll 1
+                for (int b = HALF; b < DEC_LUT_BITS; b++) {
+                    const uint32_t bit = ((uint32_t)idx >> (DEC_LUT_BITS - 1 - b)) & 1u;
+                    const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+                    if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); done = true; break; }
+                    node = nx;
+                    if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) {
+                        e = ((uint32_t)(b + 1) << 8) | ((uint32_t)(uint8_t)sh.ent[node]);
+                        done = true;
+                        break;
+                    }
+                }
+                if (!done) e = (1u << 14) | node;
+            }
+            mine[k] = (uint16_t)e;
+        }
+        __syncthreads();                                  /* all reads of s_hop are done */
+#pragma unroll
+        for (int k = 0; k < PERL; k++) sh.lut[tid + k * THREADS] = mine[k];
     }
     __syncthreads();
-
     DPROF_ADD(1, pt);
 #if defined(DEC_ABLATE) && DEC_ABLATE == 2
     *end_bits = 0; return HUFE_OK;

@@ -18,7 +18,9 @@
 
 using namespace hufgpu;
 
+#ifndef HIST_THREADS
 #define HIST_THREADS 256
+#endif
 #define PACK_THREADS 256
 #ifndef DEC_THREADS
 #define DEC_THREADS 512
@@ -369,13 +371,17 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     const uint8_t *in = (const uint8_t *)d_in;
 
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
-    hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
-    STAGE_MARK(ctx, s);
-    if (blocksize < (1ull << 22))
-        tree_fast_kernel<<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
-    else
+    if (blocksize < (1ull << 22)) {
+        /* counts and tree in one launch (the profile's "tree" stage is then empty) */
+        hist_tree_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        STAGE_MARK(ctx, s);
+        STAGE_MARK(ctx, s);
+    } else {
+        hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
+        STAGE_MARK(ctx, s);
         tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
-    STAGE_MARK(ctx, s);
+        STAGE_MARK(ctx, s);
+    }
     scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
     STAGE_MARK(ctx, s);
     if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */

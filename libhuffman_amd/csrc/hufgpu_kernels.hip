@@ -380,29 +380,40 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restrict__ hist,
-                                                       hufcode_t *__restrict__ codetab,
-                                                       int16_t *__restrict__ treebuf,
-                                                       HufBlockMeta *__restrict__ meta)
-{
-    __shared__ int16_t s_left[HUF_NSLOT];
-    __shared__ int16_t s_right[HUF_NSLOT];
-    __shared__ uint16_t s_lcnt[HUF_NSLOT];    /* leaves below each slot, 0xffff = not known yet */
-    __shared__ uint16_t s_depth[HUF_NSLOT];   /* 0xffff = not reached */
-    __shared__ uint16_t s_pos[HUF_NSLOT];     /* preorder position */
-    __shared__ uint64_t s_code[HUF_NSLOT];
-    __shared__ int16_t s_tree[HUF_TREE_STRIDE];
+struct TreeLds {
+    uint64_t code[HUF_NSLOT];
+    int16_t left[HUF_NSLOT];
+    int16_t right[HUF_NSLOT];
+    uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot, 0xffff = not known yet */
+    uint16_t depth[HUF_NSLOT];    /* 0xffff = not reached */
+    uint16_t pos[HUF_NSLOT];      /* preorder position */
+    int16_t tree[HUF_TREE_STRIDE];
+};
 
+/* Single-wave synchronisation: LDS operations of one wave are in order, so only the compiler and
+ * the LDS counter have to be fenced.  (The fused kernel calls this after its other waves have
+ * retired, so a workgroup barrier must not be used here.) */
+#define TREE_WAVE_SYNC()                                        \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+/* Executed by ONE wavefront; rate[j] = count of byte (lane + 64 j) in the block. */
+__device__ __forceinline__ void tree_fast_wave(const uint32_t (&rate)[4], TreeLds &L, uint64_t blk,
+                                               hufcode_t *__restrict__ codetab, int16_t *__restrict__ treebuf,
+                                               HufBlockMeta *__restrict__ meta)
+{
+    int16_t *s_left = L.left, *s_right = L.right, *s_tree = L.tree;
+    uint16_t *s_lcnt = L.lcnt, *s_depth = L.depth, *s_pos = L.pos;
+    uint64_t *s_code = L.code;
     const uint32_t KMAX = 0xffffffffu;
     const int lane = lane_id();
-    const uint64_t blk = blockIdx.x;
-    const uint32_t *h = hist + blk * HUF_NSYM;
 
-    uint32_t k[4], rate[4];
+    uint32_t k[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int slot = lane + 64 * j;
-        rate[j] = h[slot];
         k[j] = rate[j] ? ((rate[j] << 9) | (uint32_t)(511 - slot)) : KMAX;
         s_lcnt[slot] = rate[j] ? 1 : 0;
         s_lcnt[256 + slot] = 0xffffu;
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
         }
         node++;
     }
-    __syncthreads();
+    TREE_WAVE_SYNC();
     const int nodes = node;
 
     /* leaves below every internal node: children always have smaller indices, so a few rounds of
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
                 else pending = true;
             }
         }
-        __syncthreads();
+        TREE_WAVE_SYNC();
         if (!__any(pending)) break;
     }
     const int nleaves = (root >= 0) ? (int)s_lcnt[root] : 0;
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
         s_code[root] = 0;
         s_pos[root] = 0;
     }
-    __syncthreads();
+    TREE_WAVE_SYNC();
 
     /* level sweep: codes, depths, preorder positions (see tree_kernel) */
     for (int d = 0; d < HUF_NSLOT; d++) {
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
                 }
             }
         }
-        __syncthreads();
+        TREE_WAVE_SYNC();
         if (!__any(any)) break;
     }
 
@@ -534,6 +545,80 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
  * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
  * Single workgroup; offsets[nblocks] = stream length.
  * ==================================================================================== */
+__global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restrict__ hist,
+                                                       hufcode_t *__restrict__ codetab,
+                                                       int16_t *__restrict__ treebuf,
+                                                       HufBlockMeta *__restrict__ meta)
+{
+    __shared__ TreeLds L;
+    const uint32_t *h = hist + (uint64_t)blockIdx.x * HUF_NSYM;
+    uint32_t rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rate[j] = h[lane_id() + 64 * j];
+    tree_fast_wave(rate, L, blockIdx.x, codetab, treebuf, meta);
+}
+
+#ifndef HT_COPIES
+#define HT_COPIES 2
+#endif
+
+/* hist256 + tree in one launch: the block's byte counts never leave the CU.  All waves count;
+ * then waves 1.. retire and wave 0 builds the tree in the LDS the histogram copies occupied.
+ * The tree rounds are latency bound and the counting is memory bound, so on a CU the tree of
+ * one block runs under the counting of the next ones. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                            uint64_t blocksize, hufcode_t *__restrict__ codetab,
+                                                            int16_t *__restrict__ treebuf,
+                                                            HufBlockMeta *__restrict__ meta)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr int COPIES = WAVES * HT_COPIES;   /* 8 KiB of copies <= the tree's 11 KiB: 13 workgroups per CU */
+    constexpr size_t HBYTES = (size_t)COPIES * HUF_NSYM * sizeof(uint32_t);
+    constexpr size_t UBYTES = HBYTES > sizeof(TreeLds) ? HBYTES : sizeof(TreeLds);
+    __shared__ __attribute__((aligned(16))) uint8_t s_union[UBYTES];
+    __shared__ uint32_t s_tot[HUF_NSYM];
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_union);
+
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    const int tid = (int)threadIdx.x;
+
+    for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
+    __syncthreads();
+    uint32_t *mine = s_hist + ((tid >> 6) * HT_COPIES + (tid & (HT_COPIES - 1))) * HUF_NSYM;
+    const uint8_t *p = in + base;
+    const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
+    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
+    const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
+    const uint64_t nvec = (len - head) >> 4;
+    uint64_t i = (uint64_t)tid;
+    for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
+        const uint4 v0 = q[i], v1 = q[i + THREADS], v2 = q[i + 2 * THREADS], v3 = q[i + 3 * THREADS];
+        hist_add_chunk(mine, v0);
+        hist_add_chunk(mine, v1);
+        hist_add_chunk(mine, v2);
+        hist_add_chunk(mine, v3);
+    }
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
+    __syncthreads();
+    for (int b = tid; b < HUF_NSYM; b += THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < COPIES; w++) sum += s_hist[w * HUF_NSYM + b];
+        s_tot[b] = sum;
+    }
+    __syncthreads();                     /* copies are dead from here on; s_tot is complete */
+    if (tid >= 64) return;               /* ended waves do not take part in anything below */
+    uint32_t rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rate[j] = s_tot[tid + 64 * j];
+    tree_fast_wave(rate, *reinterpret_cast<TreeLds *>(s_union), blk, codetab, treebuf, meta);
+}
+
 /* Exclusive prefix sum of f(i), i < n, by ONE workgroup (n is the block count: 16 384 per GiB).
  * Per chunk of THREADS*PER elements: coalesced loads into an LDS tile (padded one word per 32
  * against bank conflicts), every lane sums PER consecutive elements, one workgroup scan, the

@@ -130,6 +130,38 @@ def test_encode_random_vs_oracle(torch_mod, codec, oracle, seed):
     assert np.array_equal(offs, woffs)
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_fuzz_small_shapes_vs_oracle(torch_mod, codec, oracle, chunk):
+    """Many random shapes: odd block sizes, tiny and ragged inputs, every alphabet size, skewed and
+    flat distributions.  Encode must equal the oracle's stream; indexed and raw-stream decode
+    must give the input back."""
+    torch = torch_mod
+    rng = np.random.default_rng(9000 + chunk)
+    for case in range(60):
+        n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 20000, 70000]))
+        n = max(1, n + int(rng.integers(-3, 4)))
+        k = int(rng.choice([1, 2, 3, 5, 16, 64, 200, 256]))
+        alphabet = rng.choice(256, size=k, replace=False)
+        alpha = float(rng.choice([0.02, 0.2, 1.0, 50.0]))
+        data = alphabet[rng.choice(k, size=n, p=rng.dirichlet(np.full(k, alpha)))].astype(np.uint8)
+        if rng.random() < 0.3:                                   # long runs
+            data = np.repeat(data[: max(1, n // 50)], 50)[:n]
+            n = data.size
+        bs = int(rng.choice([0, 1, 2, 5, 31, 64, 100, 1023, 4096, 65536, 65537]))
+        if bs and n // bs > 600:
+            bs = n // 600 + 1
+        want, woffs = oracle.encode(data, bs, with_offsets=True)
+        out, offs = gpu_encode(torch, codec, data, bs)
+        assert np.array_equal(out, want), (chunk, case, n, k, bs, first_diff(out, want))
+        assert np.array_equal(offs, woffs), (chunk, case, n, k, bs)
+        back = gpu_decode_indexed(torch, codec, out, offs, n, relaxed=True)
+        assert np.array_equal(back, data), (chunk, case, n, k, bs, first_diff(back, data))
+        o = torch.empty(n + 8, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(to_dev(torch, out), out.size, out.size, o, relaxed=True)
+        assert (err, raw, used) == (0, n, out.size), (chunk, case, n, k, bs)
+        assert np.array_equal(o[:raw].cpu().numpy(), data), (chunk, case, n, k, bs)
+
+
 def test_one_symbol_blocks_any_alignment(torch_mod, codec, oracle):
     """Blocks of one distinct byte take dedicated paths in pack (zero payload) and decode (fill);
     exercise them at odd block sizes, odd stream offsets and next to ordinary blocks."""

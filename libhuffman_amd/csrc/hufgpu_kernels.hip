@@ -23,6 +23,13 @@ namespace hufgpu {
  * ==================================================================================== */
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+/* Values every lane of the wave holds identically: tell the compiler, so they live in SGPRs. */
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+    return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
+}
+
 template <typename T>
 __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
 template <typename T>
@@ -1436,7 +1443,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         }
     }
     __syncthreads();
-    const int eff = sh.efflen;
+    const int eff = (int)uni32((uint32_t)sh.efflen);
     /* Child links from subtree sizes: size(marker) = 1, size(node) = 1 + size(left) + size(right),
      * left child of node j is entry j+1, right child is entry j+1+size(j+1); entries at or past
      * `eff` do not exist (size 0, NULL).  Sizes become known bottom-up, one tree level per round
@@ -1618,7 +1625,8 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
          * Symbols decoded before it are still delivered, like the reference's writer does. */
         if (tr.bad_pos != DEC_NO_BAD && (uint64_t)ex + tr.bad_at < remaining) atomicMin(&sh.badsym, ex + tr.bad_at);
         __syncthreads();
-        const uint32_t badsym = sh.badsym;
+        const uint32_t badsym = uni32(sh.badsym);
+        seg_total = uni32(seg_total);
         const uint32_t good = (badsym != DEC_NO_BAD) ? badsym : seg_total;
         const uint32_t take = (uint32_t)dmin<uint64_t>(good, remaining);
         /* (plain ifs: the select/min form of this was observed to misbehave when compiled inside
@@ -1642,7 +1650,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             /* probe: only the lane that holds the block's last symbol walks, to find where it ends */
             sh.qend = dec_write<THREADS, false>(sh, tr.start, pay_rel, quota, nullptr);
         }
-        const uint32_t last_end = sh.wend[THREADS / 64 - 1];
+        const uint32_t last_end = uni32(sh.wend[THREADS / 64 - 1]);
         __syncthreads();
         DPROF_ADD(6, pt);
         produced += take;
@@ -1651,7 +1659,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             if (last_end == DEC_EXH) { err = HUFE_RW; break; }
             true_start = seg0 + last_end;
         } else {
-            true_start = seg0 + sh.qend;
+            true_start = seg0 + uni32(sh.qend);
         }
     }
     if (err == HUFE_OK) *end_bits = true_start;

@@ -1072,7 +1072,8 @@ struct DecShared {
     uint16_t left[ENT];
     uint16_t right[ENT];
     uint16_t lut[1 << DEC_LUT_BITS];
-    uint32_t pay[DEC_SUB_WORDS][COLS];   /* pay[w][l] = word w of lane l's subsequence */
+    uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
+                                            (a padded linear layout has a cheaper address but costs 2 KiB = one workgroup per CU) */
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
     uint32_t wend[THREADS / 64];         /* end position of the last lane of each wave (neighbours use shuffles) */
     uint32_t part[THREADS / 64];
@@ -1103,11 +1104,14 @@ __device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, 
 /* Two-word MSB-first window over the staged segment: w0 = word g, w1 = word g+1.  A table
  * codeword is at most DEC_LUT_BITS long, so after it the position is in word g or g+1. */
 template <int COLS>
+__device__ __forceinline__ uint32_t pay_slot(uint32_t i) { return (i & (DEC_SUB_WORDS - 1)) * COLS + i / DEC_SUB_WORDS; }
+
+template <int COLS>
 struct WordReader {
-    const uint32_t (*pay)[COLS];
+    const uint32_t *pay;
     uint32_t w0, w1, g;
 
-    __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[i & (DEC_SUB_WORDS - 1)][i / DEC_SUB_WORDS]; }
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[pay_slot<COLS>(i)]; }
     __device__ __forceinline__ void load(uint32_t pos)
     {
         g = pos >> 5;
@@ -1119,12 +1123,11 @@ struct WordReader {
     {
         return (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - (pos & 31u)));   /* one 64-bit shift, no branch */
     }
-    __device__ __forceinline__ void step_to(uint32_t ng)      /* ng > g */
+    __device__ __forceinline__ void step_next()               /* the position moved into word g + 1 */
     {
-        if (ng == g + 1) w0 = w1;
-        else w0 = word(ng);
-        w1 = word(ng + 1);
-        g = ng;
+        w0 = w1;
+        g++;
+        w1 = word(g + 1);
     }
 };
 
@@ -1143,7 +1146,7 @@ __device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, u
     uint32_t p = pos + DEC_LUT_BITS;
     for (;;) {
         if (p >= pay_rel) return (uint64_t)CW_EXH << 40;
-        const uint32_t w = sh.pay[(p >> 5) & (DEC_SUB_WORDS - 1)][(p >> 5) / DEC_SUB_WORDS];
+        const uint32_t w = sh.pay[pay_slot<DecShared<THREADS>::COLS>(p >> 5)];
         const uint32_t bit = (w >> (31u - (p & 31u))) & 1u;
         p++;
         const uint32_t nx = bit ? sh.right[node] : sh.left[node];
@@ -1226,22 +1229,29 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
                             if (nbad_pos == DEC_NO_BAD) { nbad_pos = pos; nbad_at = c; }
                             len = 1;
                         } else len = DEC_EXH - pos;                   /* needs bits past the payload (decoder.c:53-56) */
+                        /* a walk may jump over whole words: the words it skips are never visited,
+                         * and the window is reloaded so that the common path below only ever
+                         * moves to the next word */
+                        const uint32_t np = pos + len;
+                        if (np < limit && (np >> 5) > rd.g + 1) {
+                            const uint32_t nlw = (np >> 5) - sub_w0;
+                            for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
+                            lw = nlw - 1;
+                            rd.load(np - 32);                          /* so that rd.g + 1 == np >> 5 */
+                        }
                     }
                 }
                 c += ok;
                 pos += len;
                 if (pos >= limit) break;
-                const uint32_t ng = pos >> 5;
-                if (ng != rd.g) {                              /* the track enters a new word */
-                    const uint32_t nlw = ng - sub_w0;
-                    for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
-                    lw = nlw;
+                if ((pos >> 5) != rd.g) {                      /* the track enters the next word */
+                    lw++;
                     if (MERGE) {
                         const uint32_t old = sh.mark[lw][tid];
                         if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; break; }
                     }
                     sh.mark[lw][tid] = dec_mark(c, pos);
-                    rd.step_to(ng);
+                    rd.step_next();
                 }
             }
         }
@@ -1287,8 +1297,7 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
             uint32_t len = e >> 8;
             if (e >= 0x4000u) len = (uint32_t)dec_rare_packed<THREADS>(sh, e, p0, pay_rel) - p0;
             p0 += len;
-            const uint32_t ng = p0 >> 5;
-            if (ng != rd0.g) rd0.step_to(ng);
+            if ((p0 >> 5) != rd0.g) rd0.load(p0);
         }
         return p0;
     }
@@ -1312,8 +1321,10 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
             }
         }
         pos += len;
-        const uint32_t ng = pos >> 5;
-        if (ng != rd.g) rd.step_to(ng);
+        if ((pos >> 5) != rd.g) {
+            if (__builtin_expect((pos >> 5) == rd.g + 1, 1)) rd.step_next();
+            else rd.load(pos);                      /* only behind a long rare codeword */
+        }
         wacc |= sym << (8 * fill);
         if (++fill == 4) {
             if (lo == 0) *gw = wacc;
@@ -1407,7 +1418,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 
     /* ---- 1. tree ---- */
     __syncthreads();           /* previous user of sh is done */
-    uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0][0]);   /* S(i); payload not staged yet */
+    uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0]);   /* S(i); payload not staged yet */
     static_assert(sizeof(sh.pay) >= ENT * sizeof(uint16_t), "S(i) scratch must fit");
     for (int i = tid; i < ENT; i += THREADS) {
         int16_t v = -1;
@@ -1574,7 +1585,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         const uint64_t seg0 = true_start & ~31ull;
         const uint64_t byte0 = seg0 >> 3;
         for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
-            sh.pay[i & (DEC_SUB_WORDS - 1)][i / DEC_SUB_WORDS] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
+            sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
         __syncthreads();
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
         const uint32_t first_start = (uint32_t)(true_start - seg0);

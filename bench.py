@@ -182,20 +182,27 @@ def main() -> None:
         # per-launch algorithmic bytes: encode reads N writes C, decode reads C writes N
         alg = {"pack": n + comp_len, "decode": comp_len + n, "hist256": n, "tree": nb * (1024 + 2048 + 2064),
                "scan_sizes": nb * 24, "decode_prepare": nb * 26, "scan_lens": nb * 24}
+        # blocks below 4 MiB take the fused histogram+tree kernel: its time is reported once
+        fused = bs < (1 << 22)
+        if fused:
+            enc_prof = dict(enc_prof)
+            enc_prof["hist_tree"] = enc_prof.pop("hist256") + enc_prof.pop("tree")
+            alg["hist_tree"] = n
         kernels = {}
         for name, ms in list(enc_prof.items()) + list(dec_prof.items()):
             calls = enc_calls if name in enc_prof else dec_calls
             avg_ms = ms / max(calls, 1)
             kernels[name] = {"avg_ms": round(avg_ms, 4),
                              "alg_GBps": round(alg[name] / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None}
-        dom = max(("pack", "decode", "hist256", "tree"), key=lambda k: kernels[k]["avg_ms"])
+        dom = max((k for k in ("pack", "decode", "hist256", "tree", "hist_tree") if k in kernels),
+                  key=lambda k: kernels[k]["avg_ms"])
         achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
         # HBM bytes of that kernel from the TCC counters (separate rocprofv3 --pmc passes of this same
         # command, tools/gpu_traffic.sh -> profiles/traffic.json); null when not collected for the workload
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                t = json.load(f)["workloads"][args.workload][dom]
+                t = json.load(f)["workloads"][args.workload]["hist256" if dom == "hist_tree" else dom]
             if n == (1 << 30) and bs == 65536:
                 traffic = round(t["hbm"])
         except Exception:

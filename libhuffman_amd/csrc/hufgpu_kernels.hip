@@ -417,6 +417,35 @@ __device__ __forceinline__ void tree_fast_wave(const uint32_t (&rate)[4], TreeLd
     const uint32_t KMAX = 0xffffffffu;
     const int lane = lane_id();
 
+    /* one distinct byte: the tree is [256, s, -1, -1, -1] and the code of s is the single bit 0
+     * (tree.c:410-413 on the first round) - no need for the general machinery */
+    {
+        const unsigned long long nz0 = __ballot(rate[0] != 0), nz1 = __ballot(rate[1] != 0);
+        const unsigned long long nz2 = __ballot(rate[2] != 0), nz3 = __ballot(rate[3] != 0);
+        if (__popcll(nz0) + __popcll(nz1) + __popcll(nz2) + __popcll(nz3) == 1) {
+            const int j1 = nz0 ? 0 : (nz1 ? 1 : (nz2 ? 2 : 3));
+            const unsigned long long m1 = nz0 | nz1 | nz2 | nz3;
+            const int sym = __builtin_ctzll(m1) + 64 * j1;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += rate[j];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+            /* pack_kernel never looks codes up for a 5-entry tree (all-zero payload), so the 2 KiB
+             * code table of this block is not written */
+            int16_t *tb1 = treebuf + blk * HUF_TREE_STRIDE;
+            if (lane < 5) tb1[lane] = (lane == 0) ? (int16_t)256 : (lane == 1 ? (int16_t)sym : (int16_t)-1);
+            if (lane == 0) {
+                HufBlockMeta mm;
+                mm.tree_len = 5;
+                mm.max_len = 1;
+                mm.payload_bits = cnt;
+                meta[blk] = mm;
+            }
+            return;
+        }
+    }
+
     uint32_t k[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {

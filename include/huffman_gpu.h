@@ -120,11 +120,13 @@ int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_
 int hufgpu_synchronize(hufgpu_ctx_t *ctx);
 
 /* Per-kernel timing. While enabled, every hufgpu_encode/hufgpu_decode call records HIP
- * events around each of its kernels on the stream it launches on (up to 256 calls are kept;
- * enabling resets the record).  hufgpu_get_profile() then returns, for kind 0 = encode or
- * 1 = decode, the per-kernel time summed over the recorded calls, in launch order:
- *   encode: [hist256, tree, scan_sizes, pack]     decode: [prepare, scan_lens, decode]
- * No host synchronisation happens until hufgpu_get_profile() is called. */
+ * events around each of its kernels on the stream it launches on (up to 256 calls are kept).
+ * enabled: 1 = start a new record, 0 = pause (the record is kept), 2 = resume the record - so a
+ * timed loop can sample every n-th call (an event costs ~5 us).  hufgpu_get_profile() returns, for
+ * kind 0 = encode or 1 = decode, the per-stage time summed over the recorded calls, in launch order:
+ *   encode: [hist256, tree, scan_sizes, pack]     decode: [prepare, decode]
+ * (blocks shorter than 4 MiB run hist256 + tree + scan_sizes as ONE kernel: its time is stage 0,
+ * stages 1 and 2 are empty).  No host synchronisation happens until hufgpu_get_profile(). */
 int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled);
 int hufgpu_get_profile(hufgpu_ctx_t *ctx, int kind, float *ms_sum, int max_stages,
                        int *n_stages, int *n_calls);

@@ -125,11 +125,12 @@ class GpuCodec:
                                          seed, first, self._stream()), "fill failed")
         return out
 
-    def set_profiling(self, on: bool):
-        self.lib.hufgpu_set_profiling(self._ctx, 1 if on else 0)
+    def set_profiling(self, on: bool, resume: bool = False):
+        """on: record HIP events around every kernel; resume=True keeps what was recorded so far."""
+        self.lib.hufgpu_set_profiling(self._ctx, (2 if resume else 1) if on else 0)
 
     ENCODE_KERNELS = ("hist256", "tree", "scan_sizes", "pack")
-    DECODE_KERNELS = ("decode_prepare", "scan_lens", "decode")
+    DECODE_KERNELS = ("prepare_scan", "decode")
 
     def profile(self, kind: str):
         """Per-kernel milliseconds summed over the profiled calls -> (dict name->ms, calls)."""

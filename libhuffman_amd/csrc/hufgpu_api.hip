@@ -43,12 +43,14 @@ struct hufgpu_ctx {
     int16_t *d_treebuf;
     HufBlockMeta *d_meta;
     uint64_t *d_offsets;          /* used when the caller passes no index buffer */
+    TwoLevel enc_sizes;           /* two-level prefix sums of the encoded block sizes */
 
     /* decode workspace */
     uint64_t dws_blocks;
     HufDecodeMeta *d_dmeta;
     uint64_t *d_out_offsets;
     int32_t *d_status;
+    TwoLevel dec_lens;            /* two-level prefix sums of the block lengths */
 
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
@@ -175,8 +177,11 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     return HUFE_OK;
 }
 
+static void free_two_level(TwoLevel *t);
+
 static void free_encode_ws(hufgpu_ctx *c)
 {
+    free_two_level(&c->enc_sizes);
     (void)hipFree(c->d_hist);
     (void)hipFree(c->d_codetab);
     (void)hipFree(c->d_treebuf);
@@ -197,6 +202,7 @@ static void free_disc_ws(hufgpu_ctx *c, int which)
 
 static void free_decode_ws(hufgpu_ctx *c)
 {
+    free_two_level(&c->dec_lens);
     (void)hipFree(c->d_dmeta);
     (void)hipFree(c->d_out_offsets);
     (void)hipFree(c->d_status);
@@ -225,6 +231,30 @@ extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
     return HUFE_OK;
 }
 
+/* workspace of a two-level prefix sum over `cap` blocks; counters start (and are left) at zero */
+static int alloc_two_level(hufgpu_ctx *c, TwoLevel *t, uint64_t cap, bool with_min)
+{
+    const uint64_t groups = cap / SCAN_GROUP + 2;
+    memset(t, 0, sizeof(*t));
+    HIP_OK(c, hipMalloc((void **)&t->vals, cap * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&t->local, cap * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&t->gsum, groups * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&t->gprefix, groups * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&t->gcount, groups * SCAN_TICKET_STRIDE * sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&t->done, sizeof(uint32_t)));
+    if (with_min) HIP_OK(c, hipMalloc((void **)&t->gmin, groups * sizeof(uint64_t)));
+    HIP_OK(c, hipMemset(t->gcount, 0, groups * SCAN_TICKET_STRIDE * sizeof(uint32_t)));
+    HIP_OK(c, hipMemset(t->done, 0, sizeof(uint32_t)));
+    return HUFE_OK;
+}
+
+static void free_two_level(TwoLevel *t)
+{
+    (void)hipFree(t->vals); (void)hipFree(t->local); (void)hipFree(t->gsum); (void)hipFree(t->gprefix);
+    (void)hipFree(t->gcount); (void)hipFree(t->done); (void)hipFree(t->gmin);
+    memset(t, 0, sizeof(*t));
+}
+
 static int ensure_encode_ws(hufgpu_ctx *c, uint64_t nblocks)
 {
     if (nblocks <= c->ws_blocks) return HUFE_OK;
@@ -236,6 +266,8 @@ static int ensure_encode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipMalloc((void **)&c->d_treebuf, cap * HUF_TREE_STRIDE * sizeof(int16_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_meta, cap * sizeof(HufBlockMeta)));
     HIP_OK(c, hipMalloc((void **)&c->d_offsets, (cap + 1) * sizeof(uint64_t)));
+    int rc2 = alloc_two_level(c, &c->enc_sizes, cap, false);
+    if (rc2) return rc2;
     c->ws_blocks = cap;
     return HUFE_OK;
 }
@@ -249,6 +281,8 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipMalloc((void **)&c->d_dmeta, cap * sizeof(HufDecodeMeta)));
     HIP_OK(c, hipMalloc((void **)&c->d_out_offsets, (cap + 1) * sizeof(uint64_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
+    int rc2 = alloc_two_level(c, &c->dec_lens, cap, true);
+    if (rc2) return rc2;
     c->dws_blocks = cap;
     return HUFE_OK;
 }
@@ -286,7 +320,7 @@ extern "C" int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled)
             for (int i = 0; i <= MAX_STAGES; i++) HIP_OK(ctx, hipEventCreate(&ctx->ev[k][i]));
     }
     ctx->profiling = enabled ? 1 : 0;
-    ctx->prof_used = 0;
+    if (enabled == 1) ctx->prof_used = 0;        /* 1 = start a new record, 2 = resume, 0 = pause (record kept) */
     ctx->cur_slot = -1;
     return HUFE_OK;
 }
@@ -371,9 +405,13 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     const uint8_t *in = (const uint8_t *)d_in;
 
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
+    TwoLevel sizes = ctx->enc_sizes;
     if (blocksize < (1ull << 22)) {
-        /* counts and tree in one launch (the profile's "tree" stage is then empty) */
-        hist_tree_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        /* counts, tree and the sums of the encoded sizes in one launch (the profile's "tree" and
+         * "scan_sizes" stages are then empty) */
+        sizes.total = offs + nb;
+        hist_tree_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
+        STAGE_MARK(ctx, s);
         STAGE_MARK(ctx, s);
         STAGE_MARK(ctx, s);
     } else {
@@ -381,13 +419,14 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
         STAGE_MARK(ctx, s);
         tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
         STAGE_MARK(ctx, s);
+        scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
+        STAGE_MARK(ctx, s);
+        sizes.local = NULL;              /* pack reads the finished index */
     }
-    scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
-    STAGE_MARK(ctx, s);
     if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
-        pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
+        pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out);
     else
-        pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, (uint8_t *)d_out);
+        pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out);
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
 
@@ -448,12 +487,14 @@ extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t s
 
     STAGE_BEGIN(ctx, s, PROF_DECODE);
     unsigned long long *res = (unsigned long long *)ctx->d_result;
-    HIP_OK(ctx, hipMemsetAsync(ctx->d_result, 0xff, 4 * sizeof(uint64_t), s));   /* [2] = no failing block */
-    decode_prepare_kernel<<<dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta, ctx->d_status, res);
+    /* header parse + two-level sums of the block lengths; also (re)initialises result[1] and [2] */
+    TwoLevel lens = ctx->dec_lens;
+    lens.total = (uint64_t *)res + 1;
+    lens.total2 = ctx->d_out_offsets + nblocks;
+    lens.min_out = (uint64_t *)res + 2;
+    decode_prepare_kernel<<<dim3((unsigned)((nblocks + SCAN_GROUP - 1) / SCAN_GROUP)), dim3(SCAN_GROUP), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta, ctx->d_status, lens);
     STAGE_MARK(ctx, s);
-    scan_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_dmeta, nblocks, ctx->d_out_offsets, res);
-    STAGE_MARK(ctx, s);
-    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, (uint8_t *)d_out, out_cap, ctx->d_status, res);
+    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res);
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
     ctx->decode_pending = 1;

@@ -5,8 +5,8 @@
  * parallelism everywhere: blocks never exchange data, so every kernel maps blocks to
  * workgroups and the grid is simply the block count.
  *
- *   encode:  hist256_kernel  ->  tree_kernel  ->  scan_sizes_kernel  ->  pack_kernel
- *   decode:  decode_prepare_kernel -> scan_lens_kernel -> decode_kernel -> decode_status_kernel
+ *   encode:  hist_tree_kernel -> pack_kernel      (blocks >= 4 MiB: hist256 -> tree -> scan_sizes -> pack)
+ *   decode:  decode_prepare_kernel -> decode_kernel
  *            (block index known), or decode_chain_kernel (raw stream, blocks in order)
  *
  * Wave size is 64 throughout (hard-coded, gfx950 only).  All arithmetic is integer.
@@ -34,6 +34,45 @@ template <typename T>
 __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
 template <typename T>
 __device__ __forceinline__ T dmax(T a, T b) { return a > b ? a : b; }
+
+/* block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128) */
+__device__ __forceinline__ uint64_t encoded_block_bytes(const HufBlockMeta &m)
+{
+    return (uint64_t)HUF_HEADER_FIXED + 2ull * m.tree_len + ((m.payload_bits + 7) >> 3);
+}
+
+/* streaming accesses: the input of a pass is read once and its output written once */
+__device__ __forceinline__ uint4 load_stream16(const uint4 *p)
+{
+#ifndef HUF_NO_NT_LOAD     /* measured: histogram of 1 GiB 0.202 -> 0.169 ms, pack 0.043 -> 0.030 ms */
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void store_stream16(uint4 *p, uint4 v)
+{
+#ifndef HUF_NO_NT_STORE    /* measured: one-symbol decode (a fill) 0.260 -> 0.204 ms per GiB */
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
+#else
+    *p = v;
+#endif
+}
+/* The compressed stream is written with the default policy: it is what a decode that follows
+ * reads, and a stream that fits the 256 MiB Infinity Cache is then served from there (measured on
+ * config 2: decode 0.250 -> 0.21 ms when the 128 MiB stream is still cached). */
+__device__ __forceinline__ void store_pack16(uint4 *p, uint4 v)
+{
+#ifdef HUF_PACK_NT_STORE
+    store_stream16(p, v);
+#else
+    *p = v;
+#endif
+}
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
 {
@@ -153,13 +192,14 @@ __global__ __launch_bounds__(THREADS) void hist256_kernel(const uint8_t *__restr
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = (uint64_t)tid;
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
-        const uint4 v0 = q[i], v1 = q[i + THREADS], v2 = q[i + 2 * THREADS], v3 = q[i + 3 * THREADS];
+        const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
+                    v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
         hist_add_chunk(mine, v0);
         hist_add_chunk(mine, v1);
         hist_add_chunk(mine, v2);
         hist_add_chunk(mine, v3);
     }
-    for (; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i));
 
     const uint64_t tail0 = head + (nvec << 4);
     if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
@@ -406,8 +446,9 @@ struct TreeLds {
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 
-/* Executed by ONE wavefront; rate[j] = count of byte (lane + 64 j) in the block. */
-__device__ __forceinline__ void tree_fast_wave(const uint32_t (&rate)[4], TreeLds &L, uint64_t blk,
+/* Executed by ONE wavefront; rate[j] = count of byte (lane + 64 j) in the block.  Returns the
+ * encoded size of the block in bytes (every lane). */
+__device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], TreeLds &L, uint64_t blk,
                                                hufcode_t *__restrict__ codetab, int16_t *__restrict__ treebuf,
                                                HufBlockMeta *__restrict__ meta)
 {
@@ -435,14 +476,12 @@ __device__ __forceinline__ void tree_fast_wave(const uint32_t (&rate)[4], TreeLd
              * code table of this block is not written */
             int16_t *tb1 = treebuf + blk * HUF_TREE_STRIDE;
             if (lane < 5) tb1[lane] = (lane == 0) ? (int16_t)256 : (lane == 1 ? (int16_t)sym : (int16_t)-1);
-            if (lane == 0) {
-                HufBlockMeta mm;
-                mm.tree_len = 5;
-                mm.max_len = 1;
-                mm.payload_bits = cnt;
-                meta[blk] = mm;
-            }
-            return;
+            HufBlockMeta mm;
+            mm.tree_len = 5;
+            mm.max_len = 1;
+            mm.payload_bits = cnt;
+            if (lane == 0) meta[blk] = mm;
+            return encoded_block_bytes(mm);
         }
     }
 
@@ -567,20 +606,14 @@ __device__ __forceinline__ void tree_fast_wave(const uint32_t (&rate)[4], TreeLd
     }
     int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
     for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
-    if (lane == 0) {
-        HufBlockMeta mm;
-        mm.tree_len = (uint32_t)tree_len;
-        mm.max_len = maxlen;
-        mm.payload_bits = bits;
-        meta[blk] = mm;
-    }
+    HufBlockMeta mm;
+    mm.tree_len = (uint32_t)tree_len;
+    mm.max_len = maxlen;
+    mm.payload_bits = bits;
+    if (lane == 0) meta[blk] = mm;
+    return encoded_block_bytes(mm);
 }
 
-/* ======================================================================================
- * scan_sizes_kernel - byte offset of every block header in the output stream.
- * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
- * Single workgroup; offsets[nblocks] = stream length.
- * ==================================================================================== */
 __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restrict__ hist,
                                                        hufcode_t *__restrict__ codetab,
                                                        int16_t *__restrict__ treebuf,
@@ -594,6 +627,219 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
     tree_fast_wave(rate, L, blockIdx.x, codetab, treebuf, meta);
 }
 
+/* ======================================================================================
+ * scan_sizes_kernel - byte offset of every block header in the output stream.
+ * block bytes = 10 + 2*tree_len + ceil(payload_bits/8)   (src/encoder.c:325-348,123-128)
+ * Single workgroup; offsets[nblocks] = stream length.
+ * ==================================================================================== */
+/* Exclusive prefix sum of f(i), i < n, by ONE workgroup (n is the block count: 16 384 per GiB).
+ * A chunk is THREADS * 16 elements.  Wave w owns a contiguous run of 1 024 of them, swept in
+ * SCAN_PASSES passes in which a lane owns SCAN_LANE consecutive elements.  Every f() of a chunk is
+ * evaluated before the first use, so a chunk costs ONE memory round trip (two when f chases a
+ * pointer), then SCAN_PASSES independent wave scans, one barrier for the wave totals, and 32-byte
+ * stores - the whole of 16 384 elements in a few microseconds; it sits between two kernels that
+ * cannot overlap with it. */
+#define SCAN_LANE 4
+#define SCAN_PASSES 4
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = (uint64_t)__shfl_up((unsigned long long)v, d);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+template <int THREADS, typename F>
+__device__ __forceinline__ uint64_t chunked_excl_scan(uint64_t n, uint64_t *__restrict__ out, F f)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr int PASS_ELEMS = 64 * SCAN_LANE;
+    constexpr int WAVE_ELEMS = PASS_ELEMS * SCAN_PASSES;
+    constexpr int CH = WAVES * WAVE_ELEMS;
+    __shared__ uint64_t s_wave[2][WAVES];          /* double buffered: one barrier per chunk */
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x >> 6);
+    const bool vec = (((uintptr_t)out) & 15u) == 0;
+    uint64_t carry = 0;
+    int buf = 0;
+    for (uint64_t base = 0; base < n; base += CH, buf ^= 1) {
+        const uint64_t first = base + (uint64_t)(w * WAVE_ELEMS + lane * SCAN_LANE);
+        uint64_t v[SCAN_PASSES][SCAN_LANE];
+#pragma unroll
+        for (int p = 0; p < SCAN_PASSES; p++)
+#pragma unroll
+            for (int k = 0; k < SCAN_LANE; k++) {
+                const uint64_t i = first + (uint64_t)(p * PASS_ELEMS + k);
+                v[p][k] = (i < n) ? f(i) : 0ull;
+            }
+        uint64_t incl[SCAN_PASSES], own[SCAN_PASSES];
+#pragma unroll
+        for (int p = 0; p < SCAN_PASSES; p++) {
+            own[p] = 0;
+#pragma unroll
+            for (int k = 0; k < SCAN_LANE; k++) own[p] += v[p][k];
+            incl[p] = wave_incl_scan_u64(own[p]);
+        }
+        uint64_t before[SCAN_PASSES], wsum = 0;
+#pragma unroll
+        for (int p = 0; p < SCAN_PASSES; p++) {
+            before[p] = wsum;
+            wsum += (uint64_t)__shfl((unsigned long long)incl[p], 63);
+        }
+        if (lane == 0) s_wave[buf][w] = wsum;
+        __syncthreads();
+        uint64_t wpre = 0, total = 0;
+#pragma unroll
+        for (int x = 0; x < WAVES; x++) {
+            const uint64_t t = s_wave[buf][x];
+            if (x < w) wpre += t;
+            total += t;
+        }
+#pragma unroll
+        for (int p = 0; p < SCAN_PASSES; p++) {
+            const uint64_t i0 = first + (uint64_t)(p * PASS_ELEMS);
+            uint64_t run = carry + wpre + before[p] + incl[p] - own[p];
+            uint64_t r[SCAN_LANE];
+#pragma unroll
+            for (int k = 0; k < SCAN_LANE; k++) {
+                r[k] = run;
+                run += v[p][k];
+            }
+            if (vec && i0 + SCAN_LANE <= n) {
+#pragma unroll
+                for (int k = 0; k < SCAN_LANE; k += 2)
+                    *reinterpret_cast<uint4 *>(out + i0 + k) =
+                        make_uint4((uint32_t)r[k], (uint32_t)(r[k] >> 32), (uint32_t)r[k + 1], (uint32_t)(r[k + 1] >> 32));
+            } else {
+#pragma unroll
+                for (int k = 0; k < SCAN_LANE; k++)
+                    if (i0 + k < n) out[i0 + k] = r[k];
+            }
+        }
+        carry += total;
+    }
+    return carry;
+}
+
+/* --------------------------------------------------------------------------------------
+ * Two-level prefix sums without a launch of their own.  A one-workgroup scan between two big
+ * kernels costs ~20 us of an otherwise ~450 us step (config 2), nearly all of it launch + drain.
+ * Instead the kernel that produces the per-block values also sums them: blocks form groups of
+ * SCAN_GROUP; whoever finishes LAST in a group (a ticket from an atomic counter - nobody waits)
+ * scans the group (local[b] = sum of the group's earlier blocks, gsum[g] = group total), and
+ * whoever finishes the last group scans the group totals (gprefix[g]).  The consumer kernel adds
+ * gprefix[b / SCAN_GROUP] + local[b].  Counters are left at zero for the next launch.
+ *
+ * Ordering inside the producing kernel.  What one wave hands to another (vals, gsum, gmin) is
+ * written and read with device-scope atomic stores / loads, which are performed at the coherence
+ * point past the per-XCD L2s, and the writer waits for them (s_waitcnt, __threadfence_block)
+ * before it takes its ticket.  A device-scope __threadfence() would be correct too but on gfx950
+ * it writes back and invalidates the whole L2 of the XCD: one per block made the fused
+ * histogram kernel 6x slower (0.17 -> 1.02 ms per GiB).
+ * ------------------------------------------------------------------------------------ */
+#define SCAN_GROUP 256
+#define SCAN_TICKET_STRIDE 64       /* one ticket counter per 256 bytes: neighbours in one line serialise in one L2 channel */
+
+struct TwoLevel {
+    uint64_t *vals;       /* [nblocks] the values, as handed over by their producers       */
+    uint64_t *local;      /* [nblocks] exclusive sum inside the block's group              */
+    uint64_t *gsum;       /* [ngroups] group totals                                        */
+    uint64_t *gprefix;    /* [ngroups] exclusive sum of the group totals                   */
+    uint32_t *gcount;     /* [ngroups * SCAN_TICKET_STRIDE] tickets, zero between launches */
+    uint32_t *done;       /* [1] groups finished, zero between launches                    */
+    uint64_t *total;      /* where the grand total goes (index[nblocks] / result word)     */
+    uint64_t *total2;     /* optional second copy of the grand total                        */
+    uint64_t *gmin;       /* optional [ngroups]: a minimum to combine along (first failing block) */
+    uint64_t *min_out;    /* where that minimum goes                                       */
+};
+
+__device__ __forceinline__ void handover_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t handover_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* Scan of the group totals by the wave that completed the last group.  The caller has stored
+ * gsum[g] (and gmin[g]) of its group with handover_store(). */
+__device__ __forceinline__ void two_level_finish(const TwoLevel &t, uint64_t ngroups)
+{
+    const int lane = lane_id();
+    uint32_t k = 0;
+    __threadfence_block();                           /* the handover stores have been performed */
+    if (lane == 0) k = atomicAdd(t.done, 1u);
+    k = uni32(k);
+    if ((uint64_t)k != ngroups - 1) return;
+    if (lane == 0) *t.done = 0;
+    uint64_t carry = 0, low = ~0ull;
+    for (uint64_t base = 0; base < ngroups; base += 64) {
+        const uint64_t i = base + (uint64_t)lane;
+        const uint64_t x = (i < ngroups) ? handover_load(t.gsum + i) : 0ull;
+        const uint64_t incl = wave_incl_scan_u64(x);
+        if (i < ngroups) t.gprefix[i] = carry + incl - x;
+        carry += (uint64_t)__shfl((unsigned long long)incl, 63);
+        if (t.gmin && i < ngroups) low = dmin(low, handover_load(t.gmin + i));
+    }
+    if (t.gmin) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) low = dmin(low, shfl_xor_u64(low, o));
+    }
+    if (lane == 0) {
+        *t.total = carry;
+        if (t.total2) *t.total2 = carry;
+        if (t.gmin) *t.min_out = low;
+    }
+}
+
+/* Called by ONE full wavefront with the value of its block. */
+__device__ __forceinline__ void two_level_arrive(const TwoLevel &t, uint64_t b, uint64_t nblocks, uint64_t value)
+{
+    static_assert(SCAN_GROUP == 256, "a lane scans four blocks of its group");
+    const int lane = lane_id();
+    const uint64_t g = b / SCAN_GROUP;
+    const uint64_t g0 = g * SCAN_GROUP;
+    const uint32_t members = (uint32_t)dmin<uint64_t>(SCAN_GROUP, nblocks - g0);
+    uint32_t k = 0;
+    if (lane == 0) handover_store(t.vals + b, value);
+    __threadfence_block();
+    if (lane == 0) k = atomicAdd(&t.gcount[g * SCAN_TICKET_STRIDE], 1u);
+    k = uni32(k);
+    if (k != members - 1) return;
+    if (lane == 0) t.gcount[g * SCAN_TICKET_STRIDE] = 0;
+    uint64_t v[4], own = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = (uint32_t)(lane * 4 + j);
+        v[j] = (i < members) ? handover_load(t.vals + g0 + i) : 0ull;
+        own += v[j];
+    }
+    const uint64_t incl = wave_incl_scan_u64(own);
+    uint64_t run = incl - own;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = (uint32_t)(lane * 4 + j);
+        if (i < members) t.local[g0 + i] = run;
+        run += v[j];
+    }
+    if (lane == 63) handover_store(t.gsum + g, incl);
+    two_level_finish(t, (nblocks + SCAN_GROUP - 1) / SCAN_GROUP);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta *__restrict__ meta,
+                                                             uint64_t nblocks, uint64_t *__restrict__ offsets)
+{
+    const uint64_t total = chunked_excl_scan<THREADS>(nblocks, offsets, [meta](uint64_t i) {
+        return encoded_block_bytes(meta[i]);
+    });
+    if (threadIdx.x == 0) offsets[nblocks] = total;
+}
+
 #ifndef HT_COPIES
 #define HT_COPIES 2
 #endif
@@ -601,12 +847,13 @@ __global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restric
 /* hist256 + tree in one launch: the block's byte counts never leave the CU.  All waves count;
  * then waves 1.. retire and wave 0 builds the tree in the LDS the histogram copies occupied.
  * The tree rounds are latency bound and the counting is memory bound, so on a CU the tree of
- * one block runs under the counting of the next ones. */
+ * one block runs under the counting of the next ones.  The wave that finishes a group of blocks
+ * last also prefix-sums the group's encoded sizes (no scan launch between this kernel and pack). */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                             uint64_t blocksize, hufcode_t *__restrict__ codetab,
                                                             int16_t *__restrict__ treebuf,
-                                                            HufBlockMeta *__restrict__ meta)
+                                                            HufBlockMeta *__restrict__ meta, TwoLevel sizes)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr int COPIES = WAVES * HT_COPIES;   /* 8 KiB of copies <= the tree's 11 KiB: 13 workgroups per CU */
@@ -631,13 +878,14 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = (uint64_t)tid;
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
-        const uint4 v0 = q[i], v1 = q[i + THREADS], v2 = q[i + 2 * THREADS], v3 = q[i + 3 * THREADS];
+        const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
+                    v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
         hist_add_chunk(mine, v0);
         hist_add_chunk(mine, v1);
         hist_add_chunk(mine, v2);
         hist_add_chunk(mine, v3);
     }
-    for (; i < nvec; i += THREADS) hist_add_chunk(mine, q[i]);
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i));
     const uint64_t tail0 = head + (nvec << 4);
     if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
     __syncthreads();
@@ -652,69 +900,11 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     uint32_t rate[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) rate[j] = s_tot[tid + 64 * j];
-    tree_fast_wave(rate, *reinterpret_cast<TreeLds *>(s_union), blk, codetab, treebuf, meta);
+    const uint64_t bytes = tree_fast_wave(rate, *reinterpret_cast<TreeLds *>(s_union), blk, codetab, treebuf, meta);
+    /* stream offsets (the reference's running file position): summed here, see two_level_arrive */
+    two_level_arrive(sizes, blk, gridDim.x, bytes);
 }
 
-/* Exclusive prefix sum of f(i), i < n, by ONE workgroup (n is the block count: 16 384 per GiB).
- * Per chunk of THREADS*PER elements: coalesced loads into an LDS tile (padded one word per 32
- * against bank conflicts), every lane sums PER consecutive elements, one workgroup scan, the
- * per-element prefixes go back through the tile and out with coalesced stores - 5 barriers per
- * chunk instead of 2 per THREADS elements. */
-#define SCAN_PER 4
-template <int THREADS, typename F>
-__device__ __forceinline__ uint64_t chunked_excl_scan(uint64_t n, uint64_t *__restrict__ out, F f)
-{
-    constexpr int CH = THREADS * SCAN_PER;
-    __shared__ uint64_t s_tile[CH + CH / 32 + 1];
-    __shared__ uint64_t s_part[THREADS / 64];
-    const int tid = (int)threadIdx.x;
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < n; base += CH) {
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t k = (uint32_t)(j * THREADS + tid);
-            const uint64_t i = base + k;
-            s_tile[k + (k >> 5)] = (i < n) ? f(i) : 0ull;
-        }
-        __syncthreads();
-        uint64_t local[SCAN_PER], sum = 0;
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t k = (uint32_t)(tid * SCAN_PER + j);
-            local[j] = s_tile[k + (k >> 5)];
-            sum += local[j];
-        }
-        uint64_t total;
-        uint64_t run = block_excl_scan<THREADS, uint64_t>(sum, s_part, total);
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t k = (uint32_t)(tid * SCAN_PER + j);
-            s_tile[k + (k >> 5)] = run;
-            run += local[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t k = (uint32_t)(j * THREADS + tid);
-            const uint64_t i = base + k;
-            if (i < n) out[i] = carry + s_tile[k + (k >> 5)];
-        }
-        carry += total;
-        __syncthreads();
-    }
-    return carry;
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta *__restrict__ meta,
-                                                             uint64_t nblocks, uint64_t *__restrict__ offsets)
-{
-    const uint64_t total = chunked_excl_scan<THREADS>(nblocks, offsets, [meta](uint64_t i) {
-        const HufBlockMeta m = meta[i];
-        return (uint64_t)HUF_HEADER_FIXED + 2ull * m.tree_len + ((m.payload_bits + 7) >> 3);
-    });
-    if (threadIdx.x == 0) offsets[nblocks] = total;
-}
 
 /* ======================================================================================
  * pack_kernel - replaces the header emission (src/encoder.c:322-339) and __huf_encode_block
@@ -838,7 +1028,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         for (uint64_t bp = z0 + tid; bp < b0; bp += THREADS) g_a0[bp] = 0;
         uint4 *q = reinterpret_cast<uint4 *>(g_a0 + b0);
         const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-        for (uint64_t i = (uint64_t)tid; i < ((b1 - b0) >> 4); i += THREADS) q[i] = zero4;
+        for (uint64_t i = (uint64_t)tid; i < ((b1 - b0) >> 4); i += THREADS) store_pack16(q + i, zero4);
         for (uint64_t bp = b1 + tid; bp < z1; bp += THREADS) g_a0[bp] = 0;
         return;
     }
@@ -862,8 +1052,8 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
             nsym = (uint32_t)dmin<uint64_t>(PACK_SPT, len - my0);
             const uint8_t *p = src + my0;
             if (nsym == PACK_SPT && (((uintptr_t)p) & 15u) == 0) {
-                const uint4 v0 = reinterpret_cast<const uint4 *>(p)[0];
-                const uint4 v1 = reinterpret_cast<const uint4 *>(p)[1];
+                const uint4 v0 = load_stream16(reinterpret_cast<const uint4 *>(p));
+                const uint4 v1 = load_stream16(reinterpret_cast<const uint4 *>(p) + 1);
                 const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int k = 0; k < PACK_SPT; k++) code[k] = s_code[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
@@ -945,7 +1135,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
             for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
                 const uint32_t i0 = 4 * u;
                 if (i0 >= i_lo && i0 + 4 <= i_hi) {
-                    *reinterpret_cast<uint4 *>(g16 + 4 * i0) = *reinterpret_cast<const uint4 *>(s_stage + i0);
+                    store_pack16(reinterpret_cast<uint4 *>(g16 + 4 * i0), *reinterpret_cast<const uint4 *>(s_stage + i0));
                 } else {
                     for (uint32_t i = (i0 > i_lo ? i0 : i_lo); i < i0 + 4 && i < i_hi; i++)
                         *reinterpret_cast<uint32_t *>(g16 + 4 * i) = s_stage[i];
@@ -967,7 +1157,7 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
                                                        const hufcode_t *__restrict__ codetab,
                                                        const int16_t *__restrict__ treebuf,
                                                        const HufBlockMeta *__restrict__ meta,
-                                                       const uint64_t *__restrict__ offsets,
+                                                       uint64_t *__restrict__ offsets, TwoLevel sizes,
                                                        uint8_t *__restrict__ out)
 {
     __shared__ hufcode_t s_code[SHORT ? HUF_NSYM / 2 : HUF_NSYM];   /* u32[256] on the short-code path */
@@ -981,16 +1171,25 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
     const HufBlockMeta m = meta[blk];
     const hufcode_t *codes = codetab + blk * HUF_NSYM;
     const int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    uint64_t o0, o1;
+    if (sizes.local) {                   /* sizes were summed by hist_tree_kernel: publish the index entry */
+        o0 = sizes.gprefix[blk / SCAN_GROUP] + sizes.local[blk];
+        o1 = o0 + encoded_block_bytes(m);
+        if (threadIdx.x == 0) offsets[blk] = o0;
+    } else {
+        o0 = offsets[blk];
+        o1 = offsets[blk + 1];
+    }
     if (SHORT || m.max_len <= 24)
-        pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
+        pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                       reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage);
     else if constexpr (!SHORT)
-        pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, offsets[blk], offsets[blk + 1],
+        pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                        s_code, s_part, s_tail, s_stage);
 }
 
 /* ======================================================================================
- * decode_prepare_kernel - header parse of src/decoder.c:218-252 for every indexed block.
+ * header parse of src/decoder.c:218-252 for every indexed block + output offsets
  * ==================================================================================== */
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
 {
@@ -1000,50 +1199,79 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
     return v;
 }
 
-/* result words: [0] unused, [1] total raw bytes (sum of block_len), [2] first failing block in
- * stream order (~0 = none), [3] unused.  Word [2] is reset here and lowered with atomicMin by
- * whoever finds an error: first error in stream order wins, like the reference's abort. */
-__global__ void decode_prepare_kernel(const uint8_t *__restrict__ stream, uint64_t stream_len,
-                                      const uint64_t *__restrict__ offsets, uint64_t nblocks,
-                                      int max_tree_len, HufDecodeMeta *__restrict__ dmeta,
-                                      int32_t *__restrict__ status, unsigned long long *__restrict__ result)
+/* first 10 bytes of a block header at stream + o0, by aligned 32-bit loads (the words that hold
+ * at least one stream byte are readable) */
+__device__ __forceinline__ void load_header10(const uint8_t *stream, uint64_t stream_len, uint64_t o0,
+                                              uint64_t &block_len, int16_t &tree_len)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    const uint64_t o0 = offsets[b];
-    const uint64_t o1 = dmin<uint64_t>(offsets[b + 1], stream_len);
+    const uintptr_t a = (uintptr_t)(stream + o0);
+    const uint32_t m = (uint32_t)(a & 3u);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a - m);
+    const uintptr_t end = (uintptr_t)(stream + stream_len);
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = ((uintptr_t)(q + k) < end) ? q[k] : 0u;
+    const uint32_t sh = 8u * m;
+    uint32_t d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = m ? ((w[k] >> sh) | (w[k + 1] << (32u - sh))) : w[k];
+    block_len = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    tree_len = (int16_t)(d[2] & 0xffffu);
+}
+
+/* decode_prepare_kernel - header parse of src/decoder.c:218-252 for every indexed block, one block
+ * per thread, and the sums of the block lengths (= where each block's output starts) as a
+ * two-level prefix: a workgroup is one SCAN_GROUP.  result words: [0] unused, [1] total raw
+ * bytes (sum of block_len), [2] first failing block in stream order (~0 = none), [3] unused.
+ * Word [2] is written here (minimum over the header errors) and lowered with atomicMin by the
+ * decode kernel: first error in stream order wins, like the reference's abort. */
+__global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_t *__restrict__ stream,
+                                                                    uint64_t stream_len,
+                                                                    const uint64_t *__restrict__ offsets,
+                                                                    uint64_t nblocks, int max_tree_len,
+                                                                    HufDecodeMeta *__restrict__ dmeta,
+                                                                    int32_t *__restrict__ status, TwoLevel lens)
+{
+    __shared__ uint64_t s_part[SCAN_GROUP / 64];
+    __shared__ unsigned long long s_bad;
+    if (threadIdx.x == 0) s_bad = ~0ull;
+    const uint64_t b = (uint64_t)blockIdx.x * SCAN_GROUP + threadIdx.x;
     HufDecodeMeta m;
     m.block_len = 0;
     m.tree_len = 0;
     m.status = HUFE_OK;
-    if (o0 > o1 || o1 - o0 < HUF_HEADER_FIXED) {
-        m.status = HUFE_RW;                                /* decoder.c:220-234 short read */
-    } else {
-        const uint64_t bl = load_u64_unaligned(stream + o0);
-        const int16_t tl = (int16_t)((uint16_t)stream[o0 + 8] | ((uint16_t)stream[o0 + 9] << 8));
-        if (tl < 0 || tl > max_tree_len) m.status = HUFE_OVERFLOW;          /* decoder.c:237-239 */
-        else if (o1 - o0 < HUF_HEADER_FIXED + 2ull * (uint64_t)tl) m.status = HUFE_RW;   /* :248-252 */
-        else if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;              /* beyond kernel limits */
-        else {
-            m.block_len = bl;
-            m.tree_len = tl;
+    if (b < nblocks) {
+        const uint64_t o0 = offsets[b];
+        const uint64_t o1 = dmin<uint64_t>(offsets[b + 1], stream_len);
+        if (o0 > o1 || o1 - o0 < HUF_HEADER_FIXED) {
+            m.status = HUFE_RW;                                /* decoder.c:220-234 short read */
+        } else {
+            uint64_t bl;
+            int16_t tl;
+            load_header10(stream, stream_len, o0, bl, tl);
+            if (tl < 0 || tl > max_tree_len) m.status = HUFE_OVERFLOW;          /* decoder.c:237-239 */
+            else if (o1 - o0 < HUF_HEADER_FIXED + 2ull * (uint64_t)tl) m.status = HUFE_RW;   /* :248-252 */
+            else if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;              /* beyond kernel limits */
+            else {
+                m.block_len = bl;
+                m.tree_len = tl;
+            }
         }
+        dmeta[b] = m;
+        status[b] = m.status;
     }
-    dmeta[b] = m;
-    status[b] = m.status;
-    if (m.status != HUFE_OK) atomicMin(&result[2], (unsigned long long)b);
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void scan_lens_kernel(const HufDecodeMeta *__restrict__ dmeta,
-                                                            uint64_t nblocks, uint64_t *__restrict__ out_offsets,
-                                                            unsigned long long *__restrict__ result)
-{
-    const uint64_t total = chunked_excl_scan<THREADS>(nblocks, out_offsets, [dmeta](uint64_t i) { return dmeta[i].block_len; });
+    __syncthreads();
+    if (m.status != HUFE_OK) atomicMin(&s_bad, (unsigned long long)b);
+    uint64_t total;
+    const uint64_t ex = block_excl_scan<SCAN_GROUP, uint64_t>(m.block_len, s_part, total);
+    if (b < nblocks) lens.local[b] = ex;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
     if (threadIdx.x == 0) {
-        out_offsets[nblocks] = total;
-        result[1] = total;
+        handover_store(lens.gsum + blockIdx.x, total);
+        handover_store(lens.gmin + blockIdx.x, s_bad);
     }
+    two_level_finish(lens, gridDim.x);
 }
 
 /* ======================================================================================
@@ -1356,7 +1584,11 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
         }
         wacc |= sym << (8 * fill);
         if (++fill == 4) {
+#ifdef HUF_NT_WORD
+            if (lo == 0) __builtin_nontemporal_store(wacc, gw);
+#else
             if (lo == 0) *gw = wacc;
+#endif
             else {
                 uint8_t *b = reinterpret_cast<uint8_t *>(gw);
                 for (uint32_t k = lo; k < 4; k++) b[k] = (uint8_t)(wacc >> (8 * k));
@@ -1403,7 +1635,7 @@ __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const u
         uint4 *q = reinterpret_cast<uint4 *>(gout + head);
         const uint64_t nvec = (good - head) >> 4;
         const uint4 v4 = make_uint4(rep, rep, rep, rep);
-        for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) q[i] = v4;
+        for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) store_stream16(q + i, v4);
         const uint64_t tail0 = head + (nvec << 4);
         if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
     }
@@ -1716,7 +1948,7 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(con
                                                          uint64_t stream_len,
                                                          const uint64_t *__restrict__ offsets,
                                                          const HufDecodeMeta *__restrict__ dmeta,
-                                                         const uint64_t *__restrict__ out_offsets,
+                                                         uint64_t *__restrict__ out_offsets, TwoLevel lens,
                                                          uint8_t *__restrict__ out, uint64_t out_cap,
                                                          int32_t *__restrict__ status,
                                                          unsigned long long *__restrict__ result)
@@ -1726,10 +1958,11 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(con
     const uint64_t blk = blockIdx.x;
     const HufDecodeMeta m = dmeta[blk];
     int err = m.status;
+    const uint64_t obase = lens.gprefix[blk / SCAN_GROUP] + lens.local[blk];
+    if (tid == 0) out_offsets[blk] = obase;          /* hufgpu_decode_result: bytes before a failing block */
     if (err == HUFE_OK && m.block_len > 0) {
         const uint64_t o0 = offsets[blk];
         const uint64_t o1 = dmin<uint64_t>(offsets[blk + 1], stream_len);
-        const uint64_t obase = out_offsets[blk];
         if (obase + m.block_len > out_cap) {
             err = HUFE_MEMORY;
         } else {

@@ -1363,42 +1363,67 @@ __device__ __forceinline__ uint32_t load_be32(const uint8_t *pay, uint64_t off, 
 template <int COLS>
 __device__ __forceinline__ uint32_t pay_slot(uint32_t i) { return (i & (DEC_SUB_WORDS - 1)) * COLS + i / DEC_SUB_WORDS; }
 
+/* Two-word MSB-first window over the staged segment, kept so that a symbol costs as few vector
+ * instructions as possible (the decode kernel is bound by VALU issue, 4 cycles per wave64
+ * instruction): the pair is held delayed by one bit, {d0,d1} = {word g, word g+1} >> 1, and the
+ * position inside word g as s = 31 - (pos & 31).  Then the 32 bits at the position are ONE
+ * v_alignbit_b32 (shift amounts 0..31, no 64-bit shift and no special case at a word start),
+ * a codeword of len bits is s -= len, and s < 0 says "moved into word g + 1". */
 template <int COLS>
-struct WordReader {
+struct BitReader {
     const uint32_t *pay;
-    uint32_t w0, w1, g;
+    uint32_t d0, d1;     /* ({word g, word g+1} >> 1): the bit above word g is never looked at */
+    uint32_t wl;         /* word g + 1 as staged */
+    uint32_t g;
+    int32_t s;
 
     __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[pay_slot<COLS>(i)]; }
     __device__ __forceinline__ void load(uint32_t pos)
     {
         g = pos >> 5;
-        w0 = word(g);
-        w1 = word(g + 1);
+        s = (int32_t)(31u - (pos & 31u));
+        const uint32_t w0 = word(g);
+        wl = word(g + 1);
+        d0 = w0 >> 1;
+        d1 = __builtin_amdgcn_alignbit(w0, wl, 1);
     }
-    /* the 32 bits that start at pos (pos >> 5 == g) */
-    __device__ __forceinline__ uint32_t window(uint32_t pos) const
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(d0, d1, (uint32_t)s); }
+    __device__ __forceinline__ uint32_t pos() const { return (g << 5) + (31u - (uint32_t)s); }
+    __device__ __forceinline__ void step_next()               /* s has been brought back into 0..31 */
     {
-        return (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - (pos & 31u)));   /* one 64-bit shift, no branch */
-    }
-    __device__ __forceinline__ void step_next()               /* the position moved into word g + 1 */
-    {
-        w0 = w1;
         g++;
-        w1 = word(g + 1);
+        const uint32_t wn = word(g + 1);
+        d0 = d1;
+        d1 = __builtin_amdgcn_alignbit(wl, wn, 1);
+        wl = wn;
     }
 };
 
 enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
-/* Rare paths of a table lookup (entry type != 0), bit-serial on the staged words.
+/* Table entries (uint16):
+ *   leaf    (len << 8) | symbol                     len = 1..DEC_LUT_BITS
+ *   bad     0x4000 | (skip << 8) | bits             the walk leaves the tree at bit `bits` of the
+ *                                                   window; a speculative track resumes `skip` bits on
+ *   long    0xC000 | node                           still inside the tree after DEC_LUT_BITS bits
+ * so bits 8..13 are "advance by" for leaf and bad alike.  Every code of an encoder-made tree
+ * starts with 0 (the wrap root has no right child, src/tree.c:410-413), so a lane that starts
+ * its subsequence in the middle of a codeword runs into `bad` all the time until it has
+ * synchronised: that path has to be as cheap as a symbol, and `skip` jumps over a whole run of
+ * bits that would fail the same way (bits == 1: the run of equal leading bits). */
+#define DEC_E_BAD  0x4000u
+#define DEC_E_LONG 0xC000u
+__device__ __forceinline__ uint32_t dec_e_adv(uint32_t e) { return (e >> 8) & 0x3fu; }
+
+/* Bit-serial walk for `long` entries (and the verdict of a `bad` one), on the staged words.
  * CW_OK: sym, npos = position after the codeword.  CW_BAD: the walk left the tree, npos =
- * position after the failing bit.  CW_EXH: the walk needs bits past the readable payload. */
-/* result packed in registers (no stack): bits 0-31 npos, 32-39 sym, 40-41 status */
+ * position after the failing bit.  CW_EXH: the walk needs bits past the readable payload.
+ * Result packed in registers (no stack): bits 0-31 npos, 32-39 sym, 40-41 status. */
 template <int THREADS>
 __device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
 {
-    if ((e >> 14) != 1u)                         /* the table walk already left the tree */
-        return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + ((e >> 8) & 0xfu));
+    if (e < DEC_E_LONG)                          /* the table walk already left the tree */
+        return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + (e & 0xffu));
     uint32_t node = e & 0x7ffu;
     uint32_t p = pos + DEC_LUT_BITS;
     for (;;) {
@@ -1414,16 +1439,6 @@ __device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, u
     return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
 }
 
-template <int THREADS>
-__device__ __forceinline__ int dec_rare(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel,
-                                        uint32_t &npos, uint32_t &sym)
-{
-    const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
-    npos = (uint32_t)r;
-    sym = (uint32_t)(r >> 32) & 0xffu;
-    return (int)(r >> 40);
-}
-
 /* Per-lane decode state that survives the synchronisation rounds.  The lane's track is also
  * summarised in sh.mark: for every 32-bit word of the subsequence, where the track first
  * visited it and how many codewords it had decoded before that visit. */
@@ -1431,36 +1446,41 @@ struct LaneTrack {
     uint32_t start;    /* first codeword of this lane (segment bits) */
     uint32_t end;      /* first codeword at/after the lane's limit, or DEC_EXH */
     uint32_t cnt;      /* codewords that start inside the lane's subsequence */
-    uint32_t bad_pos;  /* position of the first walk that left the tree, DEC_NO_BAD if none */
-    uint32_t bad_at;   /* codewords decoded before it */
+    uint32_t badmask;  /* bit k: a walk that started in word k of the subsequence left the tree */
 };
 
 #define DEC_NO_MARK 0xffffu
 __device__ __forceinline__ uint16_t dec_mark(uint32_t count, uint32_t pos) { return (uint16_t)((count << 5) | (pos & 31u)); }
 
 /* Count pass.  A track is the sequence of positions the decoder visits from `start` (a walk
- * that leaves the tree resumes one bit later - only speculative starts ever do that).
+ * that leaves the tree resumes a bit - or a run of such bits - later; only speculative starts
+ * ever do that on a valid stream).
  * MERGE = false: decode everything.  MERGE = true: tr/sh.mark describe the lane's previous
  * track; decode from the new `start` only until the new track enters a word at exactly the
  * position where the previous track entered it - from there on the two are identical, so the
  * old end stays valid and the counts differ by a constant.
  * CHECK = false when no table codeword that starts before the lane's limit can reach the end of
- * the readable payload (the common case): the per-symbol bound test is dropped.
- * Rare table entries sit behind a wave-uniform ballot, so the common iteration has no
- * divergent branch besides the word change and the loop exit. */
+ * the readable payload (all lanes but one or two per block): no per-symbol bound test, and a
+ * `bad` entry costs two extra instructions.
+ * The common iteration is v_alignbit, 2 x index, table read, special test, s -= advance, sign
+ * test.  The subsequence limit is only looked at on a word change (it is word aligned), and the
+ * codeword count is the wave-uniform iteration count minus the lane's non-codeword lookups.
+ * Only WHERE walks left the tree is remembered (per word); the exact first one of the final
+ * track is searched afterwards, by dec_first_bad, on corrupt streams only. */
 template <int THREADS, bool MERGE, bool CHECK>
-__device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
-                                         uint32_t sub_lo, uint32_t pay_rel)
+__device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
+                                              uint32_t sub_lo, uint32_t pay_rel)
 {
     const int tid = (int)threadIdx.x;
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
     const uint32_t sub_w0 = sub_lo >> 5;
-    uint32_t c = 0, nbad_pos = DEC_NO_BAD, nbad_at = 0, pos = start;
+    const uint32_t limit_w = sub_w0 + DEC_SUB_WORDS;
+    uint32_t c = 0, nbad = 0, pos = start;
     uint32_t lw = DEC_SUB_WORDS;  /* word of the latest mark; DEC_SUB_WORDS = none written */
     uint32_t old_c = 0;
     bool merged = false;
     if (pos < limit) {
-        WordReader<DecShared<THREADS>::COLS> rd;
+        BitReader<DecShared<THREADS>::COLS> rd;
         rd.pay = sh.pay;
         rd.load(pos);
         lw = rd.g - sub_w0;
@@ -1470,140 +1490,170 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
             if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; }
         }
         if (!merged) {
-            sh.mark[lw][tid] = dec_mark(c, pos);
+            sh.mark[lw][tid] = dec_mark(0, pos);
+            uint32_t it = 0;      /* table lookups done: the same in every lane that is still in the loop */
+            uint32_t miss = 0;    /* lookups of this lane that were not codewords */
             for (;;) {
-                const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
-                uint32_t len = e >> 8, ok = 1u;
-                if (CHECK && pos + len > pay_rel) { len = DEC_EXH - pos; ok = 0; }   /* also catches rare entries: fixed below */
-                if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
-                    if (e >= 0x4000u) {
-                        const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
-                        const uint32_t npos = (uint32_t)r;
-                        const int st = (int)(r >> 40);
-                        ok = 0;
-                        if (st == CW_OK && npos <= pay_rel) { len = npos - pos; ok = 1u; }
-                        else if (st == CW_BAD && npos <= pay_rel) {   /* a real payload bit left the tree */
-                            if (nbad_pos == DEC_NO_BAD) { nbad_pos = pos; nbad_at = c; }
-                            len = 1;
-                        } else len = DEC_EXH - pos;                   /* needs bits past the payload (decoder.c:53-56) */
-                        /* a walk may jump over whole words: the words it skips are never visited,
-                         * and the window is reloaded so that the common path below only ever
-                         * moves to the next word */
-                        const uint32_t np = pos + len;
-                        if (np < limit && (np >> 5) > rd.g + 1) {
+                uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
+                bool slow = e >= DEC_E_LONG;
+                if (CHECK) slow = (e >= DEC_E_BAD) || (rd.pos() + dec_e_adv(e) > pay_rel);
+                if (__builtin_expect(__ballot(e >= DEC_E_BAD || slow) != 0ull, 0)) {
+                    if (slow) {
+                        const uint32_t p = rd.pos();
+                        uint32_t np = DEC_EXH;                        /* needs bits past the payload (decoder.c:53-56) */
+                        bool codeword = false;
+                        if (e >= DEC_E_LONG) {
+                            const uint64_t r = dec_rare_packed<THREADS>(sh, e, p, pay_rel);
+                            const uint32_t npos = (uint32_t)r;
+                            const int st = (int)(r >> 40);
+                            if (st == CW_OK && npos <= pay_rel) { np = npos; codeword = true; }
+                            else if (st == CW_BAD && npos <= pay_rel) { nbad |= 1u << lw; np = p + 1; }
+                        } else if (CHECK && e >= DEC_E_BAD) {
+                            if (p + (e & 0xffu) <= pay_rel) { nbad |= 1u << lw; np = p + 1; }   /* a real payload bit left the tree */
+                        }
+                        if (!codeword) miss++;
+                        if (np >= limit) { pos = np; c = it + 1 - miss; break; }
+                        if ((np >> 5) != rd.g) {                      /* words a long walk jumps over are never visited */
                             const uint32_t nlw = (np >> 5) - sub_w0;
                             for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
-                            lw = nlw - 1;
-                            rd.load(np - 32);                          /* so that rd.g + 1 == np >> 5 */
+                            lw = nlw;
+                            if (MERGE) {
+                                const uint32_t old = sh.mark[lw][tid];
+                                if (old != DEC_NO_MARK && (old & 31u) == (np & 31u)) {
+                                    merged = true; old_c = old >> 5; pos = np; c = it + 1 - miss; break;
+                                }
+                            }
+                            sh.mark[lw][tid] = dec_mark(it + 1 - miss, np);
                         }
+                        rd.load(np);
+                        e = 0;                                        /* the common part has nothing left to do */
+                    } else if (e >= DEC_E_BAD) {                      /* not a codeword: resume after the run */
+                        nbad |= 1u << lw;
+                        miss++;
                     }
                 }
-                c += ok;
-                pos += len;
-                if (pos >= limit) break;
-                if ((pos >> 5) != rd.g) {                      /* the track enters the next word */
+                it++;
+                rd.s -= (int32_t)dec_e_adv(e);
+                if (rd.s < 0) {                                       /* the track enters the next word */
+                    rd.s += 32;
+                    const uint32_t off = 31u - (uint32_t)rd.s;
+                    if (rd.g + 1 == limit_w) { pos = limit + off; c = it - miss; break; }
                     lw++;
                     if (MERGE) {
                         const uint32_t old = sh.mark[lw][tid];
-                        if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; break; }
+                        if (old != DEC_NO_MARK && (old & 31u) == off) {
+                            merged = true; old_c = old >> 5; pos = ((rd.g + 1) << 5) + off; c = it - miss; break;
+                        }
                     }
-                    sh.mark[lw][tid] = dec_mark(c, pos);
+                    sh.mark[lw][tid] = (uint16_t)(((it - miss) << 5) | off);
                     rd.step_next();
                 }
             }
         }
     }
     if (MERGE && merged) {
-        /* identical from `pos` on: later marks keep their positions, their counts shift */
+        /* identical from `pos` on: later marks keep their positions, their counts shift; what the
+         * old track met from word lw on, the new one meets too */
         const uint32_t delta = c - old_c;                      /* modulo 2^32, may be "negative" */
         for (uint32_t k = lw + 1; k < DEC_SUB_WORDS; k++) {
             const uint32_t r = sh.mark[k][tid];
             if (r != DEC_NO_MARK) sh.mark[k][tid] = (uint16_t)(r + (delta << 5));
         }
         sh.mark[lw][tid] = dec_mark(c, pos);
-        if (nbad_pos != DEC_NO_BAD) { tr.bad_pos = nbad_pos; tr.bad_at = nbad_at; }        /* on the new prefix */
-        else if (tr.bad_pos != DEC_NO_BAD) {
-            if (tr.bad_pos < pos) tr.bad_pos = DEC_NO_BAD;                                  /* was on the dead prefix */
-            else tr.bad_at += delta;
-        }
+        tr.badmask = nbad | (tr.badmask & ~((1u << lw) - 1u));
         tr.cnt += delta;
         /* tr.end unchanged */
     } else {
         for (uint32_t k = (lw == DEC_SUB_WORDS ? 0u : lw + 1); k < DEC_SUB_WORDS; k++) sh.mark[k][tid] = DEC_NO_MARK;
         tr.cnt = c;
         tr.end = pos;
-        tr.bad_pos = nbad_pos;
-        tr.bad_at = nbad_at;
+        tr.badmask = nbad;
     }
     tr.start = start;
 }
 
-/* Write pass: the lane's first `quota` symbols go to g[0..quota). Returns the position after
- * the last one.  The track has been validated by the count pass, so every codeword decodes. */
+/* Lanes near the end of the payload (one or two per block) take the bound-checked loop. */
+template <int THREADS, bool MERGE>
+__device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
+                                         uint32_t sub_lo, uint32_t pay_rel)
+{
+    if (sub_lo + DEC_SUB_BITS + DEC_LUT_BITS <= pay_rel) dec_scan_impl<THREADS, MERGE, false>(sh, tr, start, sub_lo, pay_rel);
+    else dec_scan_impl<THREADS, MERGE, true>(sh, tr, start, sub_lo, pay_rel);
+}
+
+/* Codewords a (final) track decodes from `start` before the first walk that leaves the tree
+ * on a real payload bit (src/decoder.c:69-71); DEC_NO_BAD if it reaches `limit` or the end of
+ * the payload first.  Only run for lanes whose badmask is set: corrupt streams. */
+template <int THREADS>
+__device__ __noinline__ uint32_t dec_first_bad(const DecShared<THREADS> &sh, uint32_t start, uint32_t limit, uint32_t pay_rel)
+{
+    uint32_t pos = start, c = 0;
+    while (pos < limit) {
+        const uint32_t g = pos >> 5, off = pos & 31u;
+        const uint32_t w0 = sh.pay[pay_slot<DecShared<THREADS>::COLS>(g)];
+        const uint32_t w1 = sh.pay[pay_slot<DecShared<THREADS>::COLS>(g + 1)];
+        const uint32_t win = off ? ((w0 << off) | (w1 >> (32u - off))) : w0;
+        const uint32_t e = sh.lut[win >> (32 - DEC_LUT_BITS)];
+        if (e < DEC_E_BAD) {
+            if (pos + dec_e_adv(e) > pay_rel) return DEC_NO_BAD;
+            pos += dec_e_adv(e);
+        } else {
+            const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
+            const uint32_t npos = (uint32_t)r;
+            const int st = (int)(r >> 40);
+            if (st == CW_BAD && npos <= pay_rel) return c;
+            if (st != CW_OK || npos > pay_rel) return DEC_NO_BAD;
+            pos = npos;
+        }
+        c++;
+    }
+    return DEC_NO_BAD;
+}
+
+/* Write pass: the lane's first `quota` symbols go to g[0..quota) (STORE) or nowhere (probe).
+ * Returns the position after the last one.  The track has been validated by the count pass:
+ * every lookup is a codeword.  Bytes up to the first 4-byte boundary of the output, then whole
+ * words (four table entries folded into one register with v_alignbit, one 32-bit store), then
+ * the bytes that are left. */
 template <int THREADS, bool STORE>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
 {
-    if (!STORE) {                       /* probe mode: only the position after the quota is wanted */
-        WordReader<DecShared<THREADS>::COLS> rd0;
-        rd0.pay = sh.pay;
-        rd0.load(start);
-        uint32_t p0 = start;
-        for (uint32_t c = 0; c < quota; c++) {
-            const uint32_t e = sh.lut[rd0.window(p0) >> (32 - DEC_LUT_BITS)];
-            uint32_t len = e >> 8;
-            if (e >= 0x4000u) len = (uint32_t)dec_rare_packed<THREADS>(sh, e, p0, pay_rel) - p0;
-            p0 += len;
-            if ((p0 >> 5) != rd0.g) rd0.load(p0);
-        }
-        return p0;
-    }
-    WordReader<DecShared<THREADS>::COLS> rd;
+    BitReader<DecShared<THREADS>::COLS> rd;
     rd.pay = sh.pay;
     rd.load(start);
-    uint32_t pos = start;
-    const uintptr_t ga = (uintptr_t)g;
-    uint32_t lo = (uint32_t)(ga & 3u);                    /* first byte of the current word that is ours */
-    uint32_t fill = lo;
-    uint32_t *gw = reinterpret_cast<uint32_t *>(ga - lo);
-    uint32_t wacc = 0;
-    for (uint32_t c = 0; c < quota; c++) {
-        const uint32_t e = sh.lut[rd.window(pos) >> (32 - DEC_LUT_BITS)];
-        uint32_t sym = e & 0xffu, len = e >> 8;
-        if (__builtin_expect(__ballot(e >= 0x4000u) != 0ull, 0)) {
-            if (e >= 0x4000u) {
-                const uint64_t r = dec_rare_packed<THREADS>(sh, e, pos, pay_rel);
-                sym = (uint32_t)(r >> 32) & 0xffu;
-                len = (uint32_t)r - pos;
+    auto next = [&]() -> uint32_t {              /* table entry of the next codeword: low byte = symbol */
+        uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
+        if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
+            if (e >= DEC_E_BAD) {
+                const uint64_t r = dec_rare_packed<THREADS>(sh, e, rd.pos(), pay_rel);
+                rd.load((uint32_t)r);
+                e = (uint32_t)(r >> 32) & 0xffu;
             }
         }
-        pos += len;
-        if ((pos >> 5) != rd.g) {
-            if (__builtin_expect((pos >> 5) == rd.g + 1, 1)) rd.step_next();
-            else rd.load(pos);                      /* only behind a long rare codeword */
+        rd.s -= (int32_t)dec_e_adv(e);
+        if (rd.s < 0) {
+            rd.s += 32;
+            rd.step_next();
         }
-        wacc |= sym << (8 * fill);
-        if (++fill == 4) {
-#ifdef HUF_NT_WORD
-            if (lo == 0) __builtin_nontemporal_store(wacc, gw);
-#else
-            if (lo == 0) *gw = wacc;
-#endif
-            else {
-                uint8_t *b = reinterpret_cast<uint8_t *>(gw);
-                for (uint32_t k = lo; k < 4; k++) b[k] = (uint8_t)(wacc >> (8 * k));
-            }
-            gw++;
-            wacc = 0;
-            fill = 0;
-            lo = 0;
-        }
+        return e;
+    };
+    if (!STORE) {                       /* probe mode: only the position after the quota is wanted */
+        for (uint32_t c = 0; c < quota; c++) (void)next();
+        return rd.pos();
     }
-    if (fill > lo) {
-        uint8_t *b = reinterpret_cast<uint8_t *>(gw);
-        for (uint32_t k = lo; k < fill; k++) b[k] = (uint8_t)(wacc >> (8 * k));
+    const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
+    for (uint32_t c = 0; c < head; c++) g[c] = (uint8_t)next();
+    uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
+    const uint32_t words = (quota - head) >> 2;
+    for (uint32_t k = 0; k < words; k++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        gw[k] = acc;
     }
-    return pos;
+    for (uint32_t c = head + 4u * words; c < quota; c++) g[c] = (uint8_t)next();
+    return rd.pos();
 }
 
 /* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit
@@ -1822,6 +1872,18 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 }
                 if (!done) e = (1u << 14) | node;
             }
+            if ((e >> 14) == 1u) e = DEC_E_LONG | (e & 0x7ffu);
+            else if ((e >> 14) == 2u) {
+                /* bad: resume one bit on; when the very first bit fails, every bit of the run of
+                 * equal bits after it fails the same way */
+                const uint32_t bits = (e >> 8) & 0xfu;
+                uint32_t skip = 1;
+                if (bits == 1u) {
+                    const uint32_t top = (uint32_t)idx << (32 - DEC_LUT_BITS);
+                    skip = dmin<uint32_t>((uint32_t)__clz((int)((top >> 31) ? ~top : top)), (uint32_t)DEC_LUT_BITS);
+                }
+                e = DEC_E_BAD | (skip << 8) | bits;
+            }
             mine[k] = (uint16_t)e;
         }
         __syncthreads();                                  /* all reads of s_hop are done */
@@ -1848,15 +1910,21 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
             sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
         __syncthreads();
+#if defined(DEC_DUP) && DEC_DUP == 1     /* cost of a phase = time with the phase done twice - time */
+        for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
+            sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
+        __syncthreads();
+#endif
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
         const uint32_t first_start = (uint32_t)(true_start - seg0);
         DPROF_ADD(2, pt); pt = DPROF_T();
 
         LaneTrack tr;
-        /* wave-uniform: the whole segment (plus the longest table codeword) lies inside the payload */
-        const bool far_from_end = pay_rel >= (uint32_t)(THREADS * DEC_SUB_BITS + DEC_LUT_BITS);
-        if (far_from_end) dec_scan<THREADS, false, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
-        else dec_scan<THREADS, false, true>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+        dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+#if defined(DEC_DUP) && DEC_DUP == 2
+        __syncthreads();
+        dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
+#endif
         if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
         __syncthreads();
         DPROF_ADD(3, pt); pt = DPROF_T();
@@ -1873,8 +1941,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             const int changed = (ns != tr.start);
             __syncthreads();                               /* everyone has read sh.wend */
             if (changed) {
-                if (far_from_end) dec_scan<THREADS, true, false>(sh, tr, ns, sub_lo, pay_rel);
-                else dec_scan<THREADS, true, true>(sh, tr, ns, sub_lo, pay_rel);
+                dec_scan<THREADS, true>(sh, tr, ns, sub_lo, pay_rel);
             }
             if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
 #if defined(DEC_ABLATE) && DEC_ABLATE == 5
@@ -1895,7 +1962,10 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         /* the first walk that left the tree, in stream order, is a real error if it happens
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
          * Symbols decoded before it are still delivered, like the reference's writer does. */
-        if (tr.bad_pos != DEC_NO_BAD && (uint64_t)ex + tr.bad_at < remaining) atomicMin(&sh.badsym, ex + tr.bad_at);
+        if (tr.badmask != 0u && (uint64_t)ex < remaining) {
+            const uint32_t bad_at = dec_first_bad<THREADS>(sh, tr.start, sub_lo + DEC_SUB_BITS, pay_rel);
+            if (bad_at != DEC_NO_BAD && (uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
+        }
         __syncthreads();
         const uint32_t badsym = uni32(sh.badsym);
         seg_total = uni32(seg_total);
@@ -1915,6 +1985,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 #endif
         if (STORE) {
             if (quota) {
+#if defined(DEC_DUP) && DEC_DUP == 3
+                (void)dec_write<THREADS, true>(sh, tr.start, pay_rel, quota, gout + produced + ex);
+#endif
                 const uint32_t qe = dec_write<THREADS, true>(sh, tr.start, pay_rel, quota, gout + produced + ex);
                 if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
             }

@@ -318,6 +318,39 @@ def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
                 assert used == oused, (name, sequential)
 
 
+@pytest.mark.parametrize("kind", ["zipf255", "uniform255"])
+def test_payload_walk_leaves_tree_mid_block(torch_mod, codec, oracle, kind):
+    """A byte of ones in the payload: some codeword then starts with 1, which leaves an
+    encoder-made tree at the wrap root (src/decoder.c:69-71 -> error 6, bytes before it delivered).
+    Every speculative lane of the GPU decoder meets such bits all the time, so the real one has to
+    be told apart wherever it sits: any lane, any segment, before or after a lane's false alarms."""
+    torch = torch_mod
+    bs = 65536
+    data = datagen.GENERATORS[kind](3 * bs + 1234)
+    good, offs = oracle.encode(data, bs, with_offsets=True)
+    rng = np.random.default_rng(77)
+    spots = []
+    for blk in (0, 1, 2, 3):
+        o0, o1 = int(offs[blk]) + 10 + 2 * 1021, int(offs[blk + 1])
+        span = o1 - o0
+        spots += [o0 + 3, o0 + span // 2, o1 - 2, o0 + 16384 - 1, o0 + 16384 + 5]      # incl. around a segment seam
+        spots += [o0 + int(x) for x in rng.integers(0, span, size=6)]
+    out = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+    seen = set()
+    for spot in spots:
+        if not (0 <= spot < good.size):
+            continue
+        bad = good.copy()
+        bad[spot] = 0xff
+        oerr, oout, oused = oracle.decode(bad, data.size + 64, 1024)
+        seen.add(oerr)
+        for sequential in (False, True):
+            err, raw, used = codec.decode_stream(to_dev(torch, bad), bad.size, bad.size, out, sequential=sequential)
+            assert (err, raw) == (oerr, oout.size), (kind, spot, sequential, err, oerr, raw, oout.size)
+            assert np.array_equal(out[:raw].cpu().numpy(), oout), (kind, spot, sequential)
+    assert 6 in seen
+
+
 def test_self_synchronisation_worst_cases(torch_mod, codec, oracle):
     """Inputs on which speculative starts do not re-synchronise by themselves: long runs of
     one symbol whose code is longer than a bit, and fixed-length codes."""

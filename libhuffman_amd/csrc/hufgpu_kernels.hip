@@ -1491,9 +1491,10 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
         }
         if (!merged) {
             sh.mark[lw][tid] = dec_mark(0, pos);
-            uint32_t it = 0;      /* table lookups done: the same in every lane that is still in the loop */
+            uint32_t it = 0;      /* table lookups done: the same in every lane that is still in the loop (an SGPR) */
             uint32_t miss = 0;    /* lookups of this lane that were not codewords */
-            for (;;) {
+            uint32_t left = limit_w - rd.g;   /* words up to the limit; 0 = this lane is done (the loop's only exit test) */
+            do {
                 uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
                 bool slow = e >= DEC_E_LONG;
                 if (CHECK) slow = (e >= DEC_E_BAD) || (rd.pos() + dec_e_adv(e) > pay_rel);
@@ -1512,43 +1513,45 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             if (p + (e & 0xffu) <= pay_rel) { nbad |= 1u << lw; np = p + 1; }   /* a real payload bit left the tree */
                         }
                         if (!codeword) miss++;
-                        if (np >= limit) { pos = np; c = it + 1 - miss; break; }
-                        if ((np >> 5) != rd.g) {                      /* words a long walk jumps over are never visited */
-                            const uint32_t nlw = (np >> 5) - sub_w0;
-                            for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
-                            lw = nlw;
-                            if (MERGE) {
-                                const uint32_t old = sh.mark[lw][tid];
-                                if (old != DEC_NO_MARK && (old & 31u) == (np & 31u)) {
-                                    merged = true; old_c = old >> 5; pos = np; c = it + 1 - miss; break;
-                                }
-                            }
-                            sh.mark[lw][tid] = dec_mark(it + 1 - miss, np);
-                        }
-                        rd.load(np);
                         e = 0;                                        /* the common part has nothing left to do */
+                        if (np >= limit) { pos = np; c = it + 1 - miss; left = 0; }
+                        else {
+                            if ((np >> 5) != rd.g) {                  /* words a long walk jumps over are never visited */
+                                const uint32_t nlw = (np >> 5) - sub_w0;
+                                for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
+                                lw = nlw;
+                                left = limit_w - (np >> 5);
+                                const uint32_t old = sh.mark[lw][tid];
+                                if (MERGE && old != DEC_NO_MARK && (old & 31u) == (np & 31u)) {
+                                    merged = true; old_c = old >> 5; pos = np; c = it + 1 - miss; left = 0;
+                                } else sh.mark[lw][tid] = dec_mark(it + 1 - miss, np);
+                            }
+                            if (left) rd.load(np);
+                        }
                     } else if (e >= DEC_E_BAD) {                      /* not a codeword: resume after the run */
                         nbad |= 1u << lw;
                         miss++;
                     }
                 }
-                it++;
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(it) : : "scc");
                 rd.s -= (int32_t)dec_e_adv(e);
-                if (rd.s < 0) {                                       /* the track enters the next word */
+                if (rd.s < 0) {                                       /* the track enters the next word (never after the slow path: it advanced by 0) */
                     rd.s += 32;
                     const uint32_t off = 31u - (uint32_t)rd.s;
-                    if (rd.g + 1 == limit_w) { pos = limit + off; c = it - miss; break; }
-                    lw++;
-                    if (MERGE) {
-                        const uint32_t old = sh.mark[lw][tid];
-                        if (old != DEC_NO_MARK && (old & 31u) == off) {
-                            merged = true; old_c = old >> 5; pos = ((rd.g + 1) << 5) + off; c = it - miss; break;
+                    left--;
+                    if (left == 0) { pos = limit + off; c = it - miss; }      /* lw stays: the word of the last mark */
+                    else {
+                        lw++;
+                        const uint32_t old = MERGE ? (uint32_t)sh.mark[lw][tid] : (uint32_t)DEC_NO_MARK;
+                        if (MERGE && old != DEC_NO_MARK && (old & 31u) == off) {
+                            merged = true; old_c = old >> 5; pos = ((rd.g + 1) << 5) + off; c = it - miss; left = 0;
+                        } else {
+                            sh.mark[lw][tid] = (uint16_t)(((it - miss) << 5) | off);
+                            rd.step_next();
                         }
                     }
-                    sh.mark[lw][tid] = (uint16_t)(((it - miss) << 5) | off);
-                    rd.step_next();
                 }
-            }
+            } while (left);
         }
     }
     if (MERGE && merged) {
@@ -1612,9 +1615,7 @@ __device__ __noinline__ uint32_t dec_first_bad(const DecShared<THREADS> &sh, uin
 
 /* Write pass: the lane's first `quota` symbols go to g[0..quota) (STORE) or nowhere (probe).
  * Returns the position after the last one.  The track has been validated by the count pass:
- * every lookup is a codeword.  Bytes up to the first 4-byte boundary of the output, then whole
- * words (four table entries folded into one register with v_alignbit, one 32-bit store), then
- * the bytes that are left. */
+ * every lookup is a codeword. */
 template <int THREADS, bool STORE>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
@@ -1642,6 +1643,9 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
         for (uint32_t c = 0; c < quota; c++) (void)next();
         return rd.pos();
     }
+#ifndef DEC_UNALIGNED_WRITE
+    /* bytes up to the first 4-byte boundary of the output, whole words (four table entries folded
+     * into one register with v_alignbit, one 32-bit store), the bytes that are left */
     const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
     for (uint32_t c = 0; c < head; c++) g[c] = (uint8_t)next();
     uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
@@ -1653,6 +1657,19 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
         gw[k] = acc;
     }
     for (uint32_t c = head + 4u * words; c < quota; c++) g[c] = (uint8_t)next();
+#else
+    /* whole words first (four table entries folded into one register with v_alignbit, one 32-bit
+     * store at whatever byte address the lane's output starts - gfx950 global stores need no
+     * alignment), then the 0-3 bytes that are left */
+    const uint32_t words = quota >> 2;
+    for (uint32_t k = 0; k < words; k++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        __builtin_memcpy(g + 4u * k, &acc, 4);
+    }
+    for (uint32_t c = 4u * words; c < quota; c++) g[c] = (uint8_t)next();
+#endif
     return rd.pos();
 }
 

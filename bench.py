@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Huffman block-codec hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload const41|zipf255|uniform256|uniform255]
+    python bench.py --gpus N --steps K --warmup W [--workload const41|zipf255|uniform256|uniform255|logtext]
 
 One "step" = one encode + one decode of the rank's shard (default 1 GiB, 64 KiB blocks) with
 the input already resident in HBM.  N > 1 is launched by torch.distributed.run with one rank
@@ -36,6 +36,7 @@ WORKLOADS = {
     "zipf255": "configs[2]: 1 GiB Zipf-distributed bytes (zipf255 seed 3), blocksize=64KiB",
     "uniform256": "configs[3] per-GPU share: uniform-random bytes (uniform256 seed 1), blocksize=64KiB, relaxed-tree decode",
     "uniform255": "config 4b: uniform over 255 symbols (seed 2), blocksize=64KiB",
+    "logtext": "configs[4] per-GPU share: synthetic log text (16 MiB generator tile repeated), blocksize=1MiB",
 }
 
 
@@ -45,7 +46,7 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
     from libhuffman_amd import datagen
     from oracle.oracle import Oracle, Reference
     sample_bytes = {"const41": 256 << 20, "zipf255": 64 << 20, "uniform255": 64 << 20,
-                    "uniform256": 64 << 20}[workload]
+                    "uniform256": 64 << 20, "logtext": 64 << 20}[workload]
     data = datagen.GENERATORS[workload](sample_bytes)
     kind = "reference"
     try:
@@ -88,7 +89,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="const41", choices=sorted(WORKLOADS))
     ap.add_argument("--bytes-per-gpu", type=int, default=1 << 30)
-    ap.add_argument("--blocksize", type=int, default=65536)
+    ap.add_argument("--blocksize", type=int, default=None, help="default 64 KiB (1 MiB for logtext)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -115,7 +116,7 @@ def main() -> None:
     from libhuffman_amd.sharding import shard_range
 
     codec = GpuCodec(local_rank)
-    bs = args.blocksize
+    bs = args.blocksize or ((1 << 20) if args.workload == "logtext" else 65536)
     n_total = args.bytes_per_gpu * world
     lo, hi = shard_range(n_total, bs, rank, world)          # contiguous block range of this rank
     n = hi - lo
@@ -123,8 +124,14 @@ def main() -> None:
     relaxed = args.workload == "uniform256"
 
     dev = torch.device("cuda", local_rank)
-    data = torch.empty(n, dtype=torch.uint8, device=dev)
-    codec.fill(data, args.workload, first=lo)
+    if args.workload == "logtext":
+        # the text generator runs on the host: one 16 MiB tile, repeated on the device
+        from libhuffman_amd import datagen
+        tile = torch.from_numpy(datagen.logtext(16 << 20)).to(dev)
+        data = tile.repeat((n + tile.numel() - 1) // tile.numel())[:n].contiguous()
+    else:
+        data = torch.empty(n, dtype=torch.uint8, device=dev)
+        codec.fill(data, args.workload, first=lo)
     out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
     offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
     back = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -208,7 +215,7 @@ def main() -> None:
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                t = json.load(f)["workloads"][args.workload]["hist256" if dom == "hist_tree" else dom]
+                t = json.load(f)["workloads"][args.workload][dom]
             if n == (1 << 30) and bs == 65536:
                 traffic = round(t["hbm"])
         except Exception:
@@ -216,7 +223,7 @@ def main() -> None:
         pipeline_bytes = 2 * (n + comp_len)
         gpu_ms = ev0.elapsed_time(ev1) / K
         result = {
-            "metric": "encode+decode GiB/s (uncompressed) on 64KiB blocks",
+            "metric": "encode+decode GiB/s (uncompressed) on %s blocks" % ("64KiB" if bs == 65536 else "%dKiB" % (bs >> 10)),
             "value": round(value, 3),
             "unit": "GiB/s",
             "n_gpus": world,

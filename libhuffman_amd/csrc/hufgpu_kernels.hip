@@ -1924,17 +1924,22 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         pt = DPROF_T();
         const uint64_t seg0 = true_start & ~31ull;
         const uint64_t byte0 = seg0 >> 3;
+        /* (the lane index is laundered so that the staging addresses are recomputed per segment:
+         * hoisted out of this loop they do not fit in 64 VGPRs and are spilled to scratch, which
+         * showed up as +20 % HBM traffic of the kernel) */
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         if (byte0 + 4ull * (DEC_SUB_WORDS * COLS) + 8ull <= pay_bytes) {
             /* the whole staged window lies inside the payload: two aligned loads and ONE v_perm per
              * word (byte order and the payload's byte misalignment in one selector, same for all) */
-            const uintptr_t a = (uintptr_t)(pay + byte0);
-            const uint32_t m = uni32((uint32_t)(a & 3u));
+            const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));   /* block-uniform: SGPR base */
+            const uint32_t m = (uint32_t)(a & 3u);
             const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
             const uint32_t *q = reinterpret_cast<const uint32_t *>(a - m);
-            for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
+            for (int i = tl; i < DEC_SUB_WORDS * COLS; i += THREADS)
                 sh.pay[pay_slot<COLS>((uint32_t)i)] = __builtin_amdgcn_perm(q[i + 1], q[i], sel);
         } else {
-            for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
+            for (int i = tl; i < DEC_SUB_WORDS * COLS; i += THREADS)
                 sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
         }
         __syncthreads();

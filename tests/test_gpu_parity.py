@@ -318,6 +318,27 @@ def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
                 assert used == oused, (name, sequential)
 
 
+@pytest.mark.parametrize("nblocks,bs", [(255, 512), (256, 512), (257, 512), (601, 1000), (1024, 300), (5000, 64)])
+def test_block_offsets_across_groups(torch_mod, codec, oracle, nblocks, bs):
+    """The stream offsets are summed inside the kernels in groups of 256 blocks (two-level
+    prefix): group edges, a short last group, a short last block, and repeated calls (the
+    ticket counters must be back at zero)."""
+    torch = torch_mod
+    n = (nblocks - 1) * bs + max(1, bs // 3)
+    rng = np.random.default_rng(nblocks * 7 + bs)
+    # blocks of very different entropy, so that the sizes differ a lot from block to block
+    data = np.where(rng.random(n) < 0.5, rng.integers(0, 4, n), rng.integers(0, 256, n)).astype(np.uint8)
+    data[: n // 3] = 65
+    want, woffs = oracle.encode(data, bs, with_offsets=True)
+    for rep in range(2):
+        got, offs = gpu_encode(torch, codec, data, bs)
+        assert offs.size == nblocks + 1
+        assert np.array_equal(offs, woffs), first_diff(offs.view(np.uint8), woffs.astype(np.uint64).view(np.uint8))
+        assert np.array_equal(got, want), first_diff(got, want)
+        back = gpu_decode_indexed(torch, codec, got, offs, n, relaxed=True)
+        assert np.array_equal(back, data), first_diff(back, data)
+
+
 @pytest.mark.parametrize("kind", ["zipf255", "uniform255"])
 def test_payload_walk_leaves_tree_mid_block(torch_mod, codec, oracle, kind):
     """A byte of ones in the payload: some codeword then starts with 1, which leaves an

@@ -393,7 +393,8 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
 }
 
 /* ======================================================================================
- * tree_fast_kernel - same algorithm and outputs as tree_kernel<uint32_t>, tuned for the wave.
+ * tree_fast_wave - same algorithm and outputs as tree_kernel<uint32_t>, tuned for the wave (it runs
+ * as the tail of hist_tree_kernel).
  *   - At most 256 items are alive at any time (k leaves, one fewer after every merge), so the
  *     live keys fit a pool of 4 registers per lane; the node created by a merge takes over the
  *     pool position of the smaller of the two items it replaces.  A key still carries the
@@ -614,18 +615,6 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
     return encoded_block_bytes(mm);
 }
 
-__global__ __launch_bounds__(64) void tree_fast_kernel(const uint32_t *__restrict__ hist,
-                                                       hufcode_t *__restrict__ codetab,
-                                                       int16_t *__restrict__ treebuf,
-                                                       HufBlockMeta *__restrict__ meta)
-{
-    __shared__ TreeLds L;
-    const uint32_t *h = hist + (uint64_t)blockIdx.x * HUF_NSYM;
-    uint32_t rate[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) rate[j] = h[lane_id() + 64 * j];
-    tree_fast_wave(rate, L, blockIdx.x, codetab, treebuf, meta);
-}
 
 /* ======================================================================================
  * scan_sizes_kernel - byte offset of every block header in the output stream.
@@ -1042,6 +1031,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
 
     uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
 
+
     for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
         /* ---- load + look up ---- */
         const uint64_t my0 = t0 + (uint64_t)tid * PACK_SPT;
@@ -1403,8 +1393,10 @@ enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
 /* Table entries (uint16):
  *   leaf    (len << 8) | symbol                     len = 1..DEC_LUT_BITS
- *   bad     0x4000 | (skip << 8) | bits             the walk leaves the tree at bit `bits` of the
- *                                                   window; a speculative track resumes `skip` bits on
+ *   bad     0x4000 | (skip << 8) | flag | bits      the walk leaves the tree at bit `bits` (7 bits) of
+ *                                                   the window; a speculative track resumes `skip` bits
+ *                                                   on; flag 0x80: skip also covers the codeword that
+ *                                                   follows the failing run
  *   long    0xC000 | node                           still inside the tree after DEC_LUT_BITS bits
  * so bits 8..13 are "advance by" for leaf and bad alike.  Every code of an encoder-made tree
  * starts with 0 (the wrap root has no right child, src/tree.c:410-413), so a lane that starts
@@ -1423,7 +1415,7 @@ template <int THREADS>
 __device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
 {
     if (e < DEC_E_LONG)                          /* the table walk already left the tree */
-        return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + (e & 0xffu));
+        return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + (e & 0x7fu));
     uint32_t node = e & 0x7ffu;
     uint32_t p = pos + DEC_LUT_BITS;
     for (;;) {
@@ -1510,7 +1502,7 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             if (st == CW_OK && npos <= pay_rel) { np = npos; codeword = true; }
                             else if (st == CW_BAD && npos <= pay_rel) { nbad |= 1u << lw; np = p + 1; }
                         } else if (CHECK && e >= DEC_E_BAD) {
-                            if (p + (e & 0xffu) <= pay_rel) { nbad |= 1u << lw; np = p + 1; }   /* a real payload bit left the tree */
+                            if (p + (e & 0x7fu) <= pay_rel) { nbad |= 1u << lw; np = p + 1; }   /* a real payload bit left the tree */
                         }
                         if (!codeword) miss++;
                         e = 0;                                        /* the common part has nothing left to do */
@@ -1528,9 +1520,9 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             }
                             if (left) rd.load(np);
                         }
-                    } else if (e >= DEC_E_BAD) {                      /* not a codeword: resume after the run */
+                    } else if (e >= DEC_E_BAD) {                      /* left the tree: resume after the run */
                         nbad |= 1u << lw;
-                        miss++;
+                        miss += 1u - ((e >> 7) & 1u);                 /* ... unless the entry also took the codeword behind it */
                     }
                 }
                 asm volatile("s_add_u32 %0, %0, 1" : "+s"(it) : : "scc");
@@ -1552,6 +1544,16 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                     }
                 }
             } while (left);
+#ifdef DEC_PHASE_PROF
+            {   /* loop iterations executed by this wave (max over its lanes) */
+                uint32_t mx = it;
+                for (int o = 1; o < 64; o <<= 1) mx = dmax(mx, (uint32_t)__shfl_xor((int)mx, o));
+                if ((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == 0u) {
+                    atomicAdd(&g_dec_prof[MERGE ? 9 : 8], (unsigned long long)mx);
+                    atomicAdd(&g_dec_prof[MERGE ? 11 : 10], 1ull);
+                }
+            }
+#endif
         }
     }
     if (MERGE && merged) {
@@ -1906,6 +1908,23 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         __syncthreads();                                  /* all reads of s_hop are done */
 #pragma unroll
         for (int k = 0; k < PERL; k++) sh.lut[tid + k * THREADS] = mine[k];
+#ifndef DEC_NO_FOLD
+        /* A speculative lane that meets a run of failing bits decodes the codeword behind the run
+         * in its next iteration; when run + codeword fit the window, one entry does both (flag
+         * 0x80: "and a codeword"), which takes a third off the count pass's iterations. */
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PERL; k++) {
+            const uint32_t e = mine[k];
+            if (e >= DEC_E_BAD && e < DEC_E_LONG && (e & 0x7fu) == 1u) {
+                const uint32_t run = dec_e_adv(e);
+                const uint32_t idx = (uint32_t)(tid + k * THREADS);
+                const uint32_t e2 = sh.lut[(idx << run) & ((1u << DEC_LUT_BITS) - 1u)];
+                if (run < (uint32_t)DEC_LUT_BITS && e2 < DEC_E_BAD && run + (e2 >> 8) <= (uint32_t)DEC_LUT_BITS)
+                    sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 0x80u | 1u);
+            }
+        }
+#endif
     }
     __syncthreads();
     DPROF_ADD(1, pt);

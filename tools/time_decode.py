@@ -30,3 +30,6 @@ if hasattr(c.lib, "hufgpu_debug_phase_cycles"):
     names = ["tree", "lut", "stage", "passA", "rounds", "scan", "write"]
     tot = sum(arr[i] for i in range(7))
     print({n: round(arr[i] / nb) for i, n in enumerate(names)}, "cycles per block; total", round(tot / nb))
+    if arr[10]:
+        print("count pass: %.1f loop iterations per wave call (%d calls/block); rounds: %.1f per call (%.1f calls/block)" % (
+            arr[8] / arr[10], arr[10] / nb, arr[9] / max(arr[11], 1), arr[11] / nb))

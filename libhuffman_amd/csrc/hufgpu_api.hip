@@ -410,7 +410,10 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
         /* counts, tree and the sums of the encoded sizes in one launch (the profile's "tree" and
          * "scan_sizes" stages are then empty) */
         sizes.total = offs + nb;
-        hist_tree_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
+        if (blocksize <= HT_PACKED_MAX_BLOCK)
+            hist_tree_kernel<HIST_THREADS, true><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
+        else
+            hist_tree_kernel<HIST_THREADS, false><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
         STAGE_MARK(ctx, s);
         STAGE_MARK(ctx, s);
         STAGE_MARK(ctx, s);

@@ -133,15 +133,16 @@ __device__ __forceinline__ T block_excl_scan(T v, T *s_part, T &total)
 #define HIST_COPIES 4
 #endif
 
-__device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w)
+/* `one` is what a single occurrence adds: 1, or 1 << 16 when two 16-bit counters share a word */
+__device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w, uint32_t one)
 {
-    atomicAdd(&h[w & 0xffu], 1u);
-    atomicAdd(&h[(w >> 8) & 0xffu], 1u);
-    atomicAdd(&h[(w >> 16) & 0xffu], 1u);
-    atomicAdd(&h[w >> 24], 1u);
+    atomicAdd(&h[w & 0xffu], one);
+    atomicAdd(&h[(w >> 8) & 0xffu], one);
+    atomicAdd(&h[(w >> 16) & 0xffu], one);
+    atomicAdd(&h[w >> 24], one);
 }
 
-__device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v)
+__device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t one = 1u)
 {
     const uint32_t b = v.x & 0xffu;
     const uint32_t rep = b * 0x01010101u;
@@ -151,17 +152,17 @@ __device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v)
     const unsigned long long same = __ballot(uni && b == b0);
     if (same == act) {                       /* the whole wave step holds one byte value */
         if ((unsigned)lane_id() == (unsigned)__builtin_ctzll(act))
-            atomicAdd(&h[b0], 16u * (uint32_t)__popcll(act));
+            atomicAdd(&h[b0], one * 16u * (uint32_t)__popcll(act));
         return;
     }
     if (uni) {
-        atomicAdd(&h[b], 16u);
+        atomicAdd(&h[b], one * 16u);
         return;
     }
-    hist_add_bytes(h, v.x);
-    hist_add_bytes(h, v.y);
-    hist_add_bytes(h, v.z);
-    hist_add_bytes(h, v.w);
+    hist_add_bytes(h, v.x, one);
+    hist_add_bytes(h, v.y, one);
+    hist_add_bytes(h, v.z, one);
+    hist_add_bytes(h, v.w, one);
 }
 
 template <int THREADS>
@@ -428,14 +429,13 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-struct TreeLds {
-    uint64_t code[HUF_NSLOT];
+struct TreeLds {                  /* 7 KiB: what bounds the tree waves a CU holds (they are latency bound) */
+    uint32_t code[HUF_NSLOT];     /* blocks shorter than 2^22 bytes: depth <= 32 */
     int16_t left[HUF_NSLOT];
     int16_t right[HUF_NSLOT];
     uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot, 0xffff = not known yet */
     uint16_t depth[HUF_NSLOT];    /* 0xffff = not reached */
     uint16_t pos[HUF_NSLOT];      /* preorder position */
-    int16_t tree[HUF_TREE_STRIDE];
 };
 
 /* Single-wave synchronisation: LDS operations of one wave are in order, so only the compiler and
@@ -453,9 +453,9 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                                                hufcode_t *__restrict__ codetab, int16_t *__restrict__ treebuf,
                                                HufBlockMeta *__restrict__ meta)
 {
-    int16_t *s_left = L.left, *s_right = L.right, *s_tree = L.tree;
+    int16_t *s_left = L.left, *s_right = L.right;
     uint16_t *s_lcnt = L.lcnt, *s_depth = L.depth, *s_pos = L.pos;
-    uint64_t *s_code = L.code;
+    uint32_t *s_code = L.code;
     const uint32_t KMAX = 0xffffffffu;
     const int lane = lane_id();
 
@@ -498,7 +498,6 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         s_left[256 + slot] = -1;
         s_right[256 + slot] = -1;
     }
-    for (int i = lane; i < HUF_TREE_STRIDE; i += 64) s_tree[i] = -1;
 
     int node = HUF_NSYM;
     int root = -1;
@@ -557,7 +556,11 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
     }
     TREE_WAVE_SYNC();
 
-    /* level sweep: codes, depths, preorder positions (see tree_kernel) */
+    /* level sweep: codes, depths, preorder positions (see tree_kernel).  The serialized tree goes
+     * straight to HBM: a node at position p writes its index there, a leaf also the two -1 of its
+     * absent children behind it, and a node without a right child (the wrap root) the -1 where
+     * that child would start - together exactly the 4k+1 entries, each written once. */
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
     for (int d = 0; d < HUF_NSLOT; d++) {
         bool any = false;
 #pragma unroll
@@ -566,19 +569,21 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
             if (slot < nodes && s_depth[slot] == (uint16_t)d) {
                 any = true;
                 const int l = s_left[slot], r = s_right[slot];
-                const uint64_t c = s_code[slot];
+                const uint32_t c = s_code[slot];
                 const int p = s_pos[slot];
-                s_tree[p] = (int16_t)slot;
+                tb[p] = (int16_t)slot;
                 s_depth[l] = (uint16_t)(d + 1);
                 s_code[l] = c << 1;
                 s_pos[l] = (uint16_t)(p + 1);
-                if (l < HUF_NSYM) s_tree[p + 1] = (int16_t)l;
+                if (l < HUF_NSYM) { tb[p + 1] = (int16_t)l; tb[p + 2] = -1; tb[p + 3] = -1; }
+                const int pr = p + 4 * (int)s_lcnt[l];
                 if (r >= 0) {
-                    const int pr = p + 1 + 4 * (int)s_lcnt[l] - 1;
                     s_depth[r] = (uint16_t)(d + 1);
                     s_code[r] = (c << 1) | 1u;
                     s_pos[r] = (uint16_t)pr;
-                    if (r < HUF_NSYM) s_tree[pr] = (int16_t)r;
+                    if (r < HUF_NSYM) { tb[pr] = (int16_t)r; tb[pr + 1] = -1; tb[pr + 2] = -1; }
+                } else {
+                    tb[pr] = -1;
                 }
             }
         }
@@ -594,7 +599,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         hufcode_t e = 0;
         if (rate[j]) {
             const uint32_t len = s_depth[slot];
-            e = (s_code[slot] << 8) | (hufcode_t)len;
+            e = ((hufcode_t)s_code[slot] << 8) | (hufcode_t)len;
             bits += (uint64_t)rate[j] * len;
             maxlen = dmax(maxlen, len);
         }
@@ -605,8 +610,6 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         bits += shfl_xor_u64(bits, o);
         maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
     }
-    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
-    for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
     HufBlockMeta mm;
     mm.tree_len = (uint32_t)tree_len;
     mm.max_len = maxlen;
@@ -838,19 +841,35 @@ __global__ __launch_bounds__(THREADS) void scan_sizes_kernel(const HufBlockMeta 
  * The tree rounds are latency bound and the counting is memory bound, so on a CU the tree of
  * one block runs under the counting of the next ones.  The wave that finishes a group of blocks
  * last also prefix-sums the group's encoded sizes (no scan launch between this kernel and pack). */
-template <int THREADS>
+#ifndef HTP_ARRAYS
+#define HTP_ARRAYS 2        /* packed mode: 256-word arrays per wave, each holding two 16-bit copies (1: 0.79, 2: 0.71, 4: 0.86 ms on Zipf) */
+#endif
+#define HT_PACKED_MAX_BLOCK 131072u     /* a wave counts a quarter of the block: < 65 536 per 16-bit counter */
+
+/* PACKED: the block is at most HT_PACKED_MAX_BLOCK bytes, so the private histograms use 16-bit
+ * counters, two per word (lane parity picks the half): four copies per wave in the LDS of two
+ * (hot symbols of skewed data collide half as often).  The totals are accumulated in place in the
+ * last array, which lies behind the 7 KiB TreeLds: 8 KiB per workgroup = 20 resident groups per
+ * CU instead of 13, and the latency-bound tree waves are what the kernel waits for on
+ * multi-symbol data (uniform bytes 0.68 -> 0.60 ms, Zipf 0.77 -> 0.71 ms per GiB). */
+template <int THREADS, bool PACKED>
 __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                             uint64_t blocksize, hufcode_t *__restrict__ codetab,
                                                             int16_t *__restrict__ treebuf,
                                                             HufBlockMeta *__restrict__ meta, TwoLevel sizes)
 {
     constexpr int WAVES = THREADS / 64;
-    constexpr int COPIES = WAVES * HT_COPIES;   /* 8 KiB of copies <= the tree's 11 KiB: 13 workgroups per CU */
+    constexpr int COPIES = WAVES * (PACKED ? HTP_ARRAYS : HT_COPIES);   /* 256-word arrays */
     constexpr size_t HBYTES = (size_t)COPIES * HUF_NSYM * sizeof(uint32_t);
-    constexpr size_t UBYTES = HBYTES > sizeof(TreeLds) ? HBYTES : sizeof(TreeLds);
+    constexpr size_t TBYTES = HUF_NSYM * sizeof(uint32_t);
+    /* totals: the last histogram array when that lies behind the tree's area (summed in place:
+     * a thread reads and writes only its own bin there), else right behind the tree's area */
+    constexpr size_t TOT_OFF = (HBYTES >= sizeof(TreeLds) + TBYTES) ? HBYTES - TBYTES : sizeof(TreeLds);
+    constexpr size_t UBYTES = (HBYTES > TOT_OFF + TBYTES) ? HBYTES : TOT_OFF + TBYTES;
+    static_assert(TOT_OFF >= sizeof(TreeLds) && TOT_OFF % 16 == 0, "totals must survive the tree's initialisation");
     __shared__ __attribute__((aligned(16))) uint8_t s_union[UBYTES];
-    __shared__ uint32_t s_tot[HUF_NSYM];
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_union);
+    uint32_t *s_tot = reinterpret_cast<uint32_t *>(s_union + TOT_OFF);
 
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
@@ -859,29 +878,39 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
 
     for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
     __syncthreads();
-    uint32_t *mine = s_hist + ((tid >> 6) * HT_COPIES + (tid & (HT_COPIES - 1))) * HUF_NSYM;
+    uint32_t *mine;
+    uint32_t one = 1u;
+    if (PACKED) {
+        mine = s_hist + ((tid >> 6) * HTP_ARRAYS + ((tid >> 1) & (HTP_ARRAYS - 1))) * HUF_NSYM;
+        one = (tid & 1) ? 0x10000u : 1u;
+    } else {
+        mine = s_hist + ((tid >> 6) * HT_COPIES + (tid & (HT_COPIES - 1))) * HUF_NSYM;
+    }
     const uint8_t *p = in + base;
     const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
-    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
+    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], one);
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = (uint64_t)tid;
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
         const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                     v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-        hist_add_chunk(mine, v0);
-        hist_add_chunk(mine, v1);
-        hist_add_chunk(mine, v2);
-        hist_add_chunk(mine, v3);
+        hist_add_chunk(mine, v0, one);
+        hist_add_chunk(mine, v1, one);
+        hist_add_chunk(mine, v2, one);
+        hist_add_chunk(mine, v3, one);
     }
-    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i));
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i), one);
     const uint64_t tail0 = head + (nvec << 4);
-    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
+    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], one);   /* < 16 bytes */
     __syncthreads();
     for (int b = tid; b < HUF_NSYM; b += THREADS) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < COPIES; w++) sum += s_hist[w * HUF_NSYM + b];
+        for (int w = 0; w < COPIES; w++) {
+            const uint32_t x = s_hist[w * HUF_NSYM + b];
+            sum += PACKED ? ((x & 0xffffu) + (x >> 16)) : x;
+        }
         s_tot[b] = sum;
     }
     __syncthreads();                     /* copies are dead from here on; s_tot is complete */

@@ -1418,6 +1418,49 @@ struct BitReader {
     }
 };
 
+/* Buffered reader: up to 64 payload bits left-aligned in a register pair.  The table index is one
+ * shift of the high half, a codeword is one 64-bit shift, and - what it is for - a refill is
+ * only ever needed every SECOND codeword (a refill leaves >= 33 bits, two table codewords take
+ * <= 24).  A wave executes the word-change code whenever ANY of its lanes crosses a word, i.e.
+ * practically every iteration, so halving how often that code runs is worth more than anything
+ * inside the per-codeword path (issue cost, MI355X, 8 waves/SIMD, tools/calib: simple VOP2 ~2.5
+ * cycles, VOP3 / v_cmp ~4.5, scalar ~4.5). */
+template <int COLS>
+struct BufReader {
+    const uint32_t *pay;
+    uint32_t hi, lo;     /* bit buffer: the next stream bit is bit 31 of hi; bits past `avail` are 0 */
+    int32_t avail;       /* valid bits */
+    uint32_t gf;         /* staged word that the next refill appends */
+
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[pay_slot<COLS>(i)]; }
+    __device__ __forceinline__ void load(uint32_t pos)
+    {
+        const uint32_t g = pos >> 5, off = pos & 31u;
+        const uint64_t b = (((uint64_t)word(g) << 32) | word(g + 1)) << off;
+        hi = (uint32_t)(b >> 32);
+        lo = (uint32_t)b;
+        avail = (int32_t)(64u - off);
+        gf = g + 2;
+    }
+    __device__ __forceinline__ uint32_t index() const { return hi >> (32 - DEC_LUT_BITS); }
+    __device__ __forceinline__ uint32_t pos() const { return (gf << 5) - (uint32_t)avail; }
+    __device__ __forceinline__ void consume(uint32_t adv)
+    {
+        const uint64_t b = (((uint64_t)hi << 32) | lo) << adv;
+        hi = (uint32_t)(b >> 32);
+        lo = (uint32_t)b;
+        avail -= (int32_t)adv;
+    }
+    __device__ __forceinline__ void refill()                   /* needs avail <= 32 */
+    {
+        const uint64_t t = (uint64_t)word(gf) << (32 - avail);
+        hi |= (uint32_t)(t >> 32);
+        lo |= (uint32_t)t;
+        avail += 32;
+        gf++;
+    }
+};
+
 enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
 /* Table entries (uint16):
@@ -1436,12 +1479,17 @@ enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 #define DEC_E_LONG 0xC000u
 __device__ __forceinline__ uint32_t dec_e_adv(uint32_t e) { return (e >> 8) & 0x3fu; }
 
+#ifdef DEC_RARE_NOINLINE
+#define DEC_RARE_ATTR __noinline__
+#else
+#define DEC_RARE_ATTR __forceinline__
+#endif
 /* Bit-serial walk for `long` entries (and the verdict of a `bad` one), on the staged words.
  * CW_OK: sym, npos = position after the codeword.  CW_BAD: the walk left the tree, npos =
  * position after the failing bit.  CW_EXH: the walk needs bits past the readable payload.
  * Result packed in registers (no stack): bits 0-31 npos, 32-39 sym, 40-41 status. */
 template <int THREADS>
-__device__ __noinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
+__device__ DEC_RARE_ATTR uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
 {
     if (e < DEC_E_LONG)                          /* the table walk already left the tree */
         return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + (e & 0x7fu));
@@ -1651,6 +1699,7 @@ template <int THREADS, bool STORE>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
 {
+#ifdef DEC_OLD_WRITE
     BitReader<DecShared<THREADS>::COLS> rd;
     rd.pay = sh.pay;
     rd.load(start);
@@ -1702,6 +1751,55 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
     for (uint32_t c = 4u * words; c < quota; c++) g[c] = (uint8_t)next();
 #endif
     return rd.pos();
+#else
+    BufReader<DecShared<THREADS>::COLS> rd;
+    rd.pay = sh.pay;
+    rd.load(start);
+    auto next = [&]() -> uint32_t {              /* table entry of the next codeword: low byte = symbol */
+        uint32_t e = sh.lut[rd.index()];
+        if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
+            if (e >= DEC_E_BAD) {
+                const uint64_t r = dec_rare_packed<THREADS>(sh, e, rd.pos(), pay_rel);
+                rd.load((uint32_t)r);
+                e = (uint32_t)(r >> 32) & 0xffu;
+            }
+        }
+        rd.consume(e >> 8);
+        return e;
+    };
+    if (!STORE) {                       /* probe mode: only the position after the quota is wanted */
+        for (uint32_t c = 0; c < quota; c++) {
+            (void)next();
+            if (rd.avail <= 32) rd.refill();
+        }
+        return rd.pos();
+    }
+    /* bytes up to the first 4-byte boundary of the output, whole words (four table entries folded
+     * into one register with v_alignbit, one 32-bit store, a refill check per two codewords), the
+     * bytes that are left */
+    const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
+    for (uint32_t c = 0; c < head; c++) {
+        g[c] = (uint8_t)next();
+        if (rd.avail <= 32) rd.refill();
+    }
+    uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
+    const uint32_t words = (quota - head) >> 2;
+    for (uint32_t k = 0; k < words; k++) {
+        uint32_t acc = 0;
+        acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        if (rd.avail <= 32) rd.refill();
+        acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        acc = __builtin_amdgcn_alignbit(next(), acc, 8);
+        if (rd.avail <= 32) rd.refill();
+        gw[k] = acc;
+    }
+    for (uint32_t c = head + 4u * words; c < quota; c++) {
+        g[c] = (uint8_t)next();
+        if (rd.avail <= 32) rd.refill();
+    }
+    return rd.pos();
+#endif
 }
 
 /* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit

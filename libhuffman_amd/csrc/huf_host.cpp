@@ -13,6 +13,8 @@
  * Environment (huf_config_t's 48-byte layout is ABI, so switches live outside it):
  *   HUF_GPU_DEVICE        device ordinal (default 0)
  *   HUF_GPU_BATCH_MB      input bytes staged per GPU round in huf_encode (default 256)
+ *   HUF_GPU_ZERO_COPY     0 = always go through the streams' read/write callbacks (default 1:
+ *                         huf_memopen() streams are copied to/from the device directly)
  *   HUF_GPU_RELAXED_TREE  1 = accept 1025-entry trees on decode
  */
 #include <errno.h>
@@ -83,10 +85,9 @@ typedef struct {
     size_t cap;
 } membuf_t;
 
-huf_error_t memwrite(void *stream, const void *buf, size_t count)
+/* room for `count` more bytes behind the stream's contents */
+static huf_error_t mem_reserve(membuf_t *m, size_t count)
 {
-    membuf_t *m = (membuf_t *)stream;
-    if (!m || (!buf && count)) return HUF_ERROR_INVALID_ARGUMENT;
     if (m->cap - m->len < count) {
         /* growth policy of src/io.c:79-84 (double, or twice the request), but never smaller
          * than what is needed - the reference under-allocates here */
@@ -100,6 +101,14 @@ huf_error_t memwrite(void *stream, const void *buf, size_t count)
         *m->buf = grown;
         m->cap = want;
     }
+    return HUF_ERROR_SUCCESS;
+}
+
+huf_error_t memwrite(void *stream, const void *buf, size_t count)
+{
+    membuf_t *m = (membuf_t *)stream;
+    if (!m || (!buf && count)) return HUF_ERROR_INVALID_ARGUMENT;
+    TRY(mem_reserve(m, count));
     if (count) memcpy((char *)*m->buf + m->len, buf, count);
     m->len += count;
     return HUF_ERROR_SUCCESS;
@@ -772,6 +781,18 @@ huf_error_t huf_decoder_free(huf_decoder_t **self)
     return HUF_ERROR_SUCCESS;
 }
 
+/* A stream made by huf_memopen() is this library's own object: the codec then copies between
+ * its buffer and the device directly instead of through read()/write() and a staging buffer
+ * (one host memcpy less per direction; the stream's cursor and length move exactly as the
+ * callbacks would have moved them).  Any other stream goes through its callbacks. */
+static membuf_t *own_memstream_reader(const huf_read_writer_t *rw) { return (rw && rw->read == memread) ? (membuf_t *)rw->stream : NULL; }
+static membuf_t *own_memstream_writer(const huf_read_writer_t *rw) { return (rw && rw->write == memwrite) ? (membuf_t *)rw->stream : NULL; }
+static int zero_copy_enabled(void)
+{
+    const char *e = getenv("HUF_GPU_ZERO_COPY");
+    return !(e && atoi(e) == 0);
+}
+
 /* ------------------------------------------------------------------ huf_encode (src/encoder.c:261-388) */
 static huf_error_t encode_locked(huf_encoder_t *enc)
 {
@@ -791,8 +812,10 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
     if (batch > length) batch = length;
 
     const uint64_t bound = hufgpu_encode_bound(batch, blocksize);
-    TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, batch));
-    TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, bound));
+    membuf_t *rmem = zero_copy_enabled() ? own_memstream_reader(enc->config->reader) : NULL;
+    membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(enc->config->writer) : NULL;
+    if (!rmem) TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, batch));
+    if (!wmem) TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, bound));
     TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, batch));
     TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound));
 
@@ -800,13 +823,28 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
         const uint64_t take = (length - done < batch) ? length - done : batch;
         /* one large read per round; a short read is an error exactly like the reference's
          * block read (src/encoder.c:296, src/bufio.c:251-253) */
-        TRY(huf_bufio_read(enc->bufio_reader, g_stage.h_a, take));
-        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take));
+        if (rmem) {
+            if (rmem->len - rmem->off < take) {
+                rmem->off = rmem->len;                          /* what a failed read would have consumed */
+                return HUF_ERROR_READ_WRITE;
+            }
+            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, (const char *)*rmem->buf + rmem->off, take));
+            rmem->off += take;
+        } else {
+            TRY(huf_bufio_read(enc->bufio_reader, g_stage.h_a, take));
+            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take));
+        }
         uint64_t out_len = 0;
         int rc = hufgpu_encode(g_ctx, g_stage.d_a, take, blocksize, g_stage.d_b, g_stage.d_b_cap, NULL, &out_len, NULL);
         if (rc != HUF_ERROR_SUCCESS) return (huf_error_t)rc;
-        TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, out_len));
-        TRY(huf_bufio_write(enc->bufio_writer, g_stage.h_b, out_len));
+        if (wmem) {
+            TRY(mem_reserve(wmem, out_len));
+            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, out_len));
+            wmem->len += out_len;
+        } else {
+            TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, out_len));
+            TRY(huf_bufio_write(enc->bufio_writer, g_stage.h_b, out_len));
+        }
         done += take;
     }
     return huf_bufio_read_writer_flush(enc->bufio_writer);   /* encoder.c:377 */
@@ -850,23 +888,38 @@ static huf_error_t decode_locked(huf_decoder_t *dec)
     /* The reference pulls bytes on demand and may run past `length` to finish the last block
      * (src/decoder.c:218); here: take `length` bytes, and if the device reports that a block
      * needs more input, ask the reader for more and decode again. */
-    size_t cap_in = (size_t)length + 4096;
-    TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, cap_in));
+    membuf_t *rmem = zero_copy_enabled() ? own_memstream_reader(dec->config->reader) : NULL;
+    membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(dec->config->writer) : NULL;
     size_t avail = 0;
-    TRY(read_upto(dec->config->reader, (uint8_t *)g_stage.h_a, (size_t)length, &avail));
+    const char *in_ptr = NULL;              /* host bytes [0, avail) of the input */
+    if (rmem) {
+        const size_t left = rmem->len - rmem->off;
+        in_ptr = (const char *)*rmem->buf + rmem->off;
+        avail = (size_t)length < left ? (size_t)length : left;
+        rmem->off += avail;
+    } else {
+        size_t cap_in = (size_t)length + 4096;
+        TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, cap_in));
+        TRY(read_upto(dec->config->reader, (uint8_t *)g_stage.h_a, (size_t)length, &avail));
+    }
 
     uint64_t out_cap = (uint64_t)avail * 8 + (1u << 20);
     for (;;) {
         TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, avail + 16));
         TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, out_cap));
-        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, avail));
+        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rmem ? (const void *)in_ptr : (const void *)g_stage.h_a, avail));
         uint64_t raw = 0, used = 0;
         int rc = hufgpu_decode_stream(g_ctx, g_stage.d_a, avail, length, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
         if (rc == HUF_ERROR_MEMORY_ALLOCATION && out_cap < ((uint64_t)1 << 40)) {   /* output did not fit: enlarge */
             out_cap *= 4;
             continue;
         }
-        if (rc == HUF_ERROR_READ_WRITE) {          /* maybe the reader has more than `length` */
+        if (rc == HUF_ERROR_READ_WRITE && rmem) {  /* maybe the stream holds more than `length` */
+            const size_t more_want = avail < 65536 ? 65536 : avail;
+            const size_t left = rmem->len - rmem->off;
+            const size_t more = more_want < left ? more_want : left;
+            if (more) { rmem->off += more; avail += more; continue; }
+        } else if (rc == HUF_ERROR_READ_WRITE) {   /* maybe the reader has more than `length` */
             size_t more_want = avail < 65536 ? 65536 : avail;
             if (g_stage.h_a_cap < avail + more_want) {
                 void *bigger = NULL; size_t bigger_cap = 0;
@@ -881,7 +934,11 @@ static huf_error_t decode_locked(huf_decoder_t *dec)
         }
         /* bytes of the blocks that decoded completely are delivered even when a later block
          * fails, as the reference's unbuffered writer would have done */
-        if (raw) {
+        if (raw && wmem) {
+            TRY(mem_reserve(wmem, raw));
+            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, raw));
+            wmem->len += raw;
+        } else if (raw) {
             TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, raw));
             TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, raw));
             TRY(huf_bufio_write(dec->bufio_writer, g_stage.h_b, raw));

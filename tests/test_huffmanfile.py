@@ -106,6 +106,26 @@ def test_incremental_equals_one_shot_across_blocks():
 
 
 @gpu
+def test_memstream_direct_copy_equals_callback_path(monkeypatch):
+    """huf_memopen streams are copied to/from the device directly; HUF_GPU_ZERO_COPY=0 forces the
+    read()/write() callbacks that every foreign stream uses.  Same bytes either way, several
+    GPU rounds per call (HUF_GPU_BATCH_MB=1), and the same error for a truncated stream."""
+    data = datagen.zipf255(3 * (1 << 20) + 12345).tobytes()
+    monkeypatch.setenv("HUF_GPU_BATCH_MB", "1")
+    outs, backs, errs = [], [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HUF_GPU_ZERO_COPY", mode)
+        comp = huffmanfile.compress(data, 65536)
+        outs.append(comp)
+        backs.append(huffmanfile.decompress(comp))
+        with pytest.raises(huffmanfile.HuffmanError) as ei:
+            huffmanfile.decompress(comp[:-100])
+        errs.append(str(ei.value))
+    assert outs[0] == outs[1] and backs[0] == backs[1] == data
+    assert errs[0] == errs[1]
+
+
+@gpu
 def test_write_file_text_mode(tmp_path):                     # huffmanfile_test.py:37-54
     text = "Donec rhoncus quis sapien sit amet molestie.\nhéllo\n" * 40
     name = tmp_path / "archive.hm"

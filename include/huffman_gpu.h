@@ -131,6 +131,16 @@ int hufgpu_set_profiling(hufgpu_ctx_t *ctx, int enabled);
 int hufgpu_get_profile(hufgpu_ctx_t *ctx, int kind, float *ms_sum, int max_stages,
                        int *n_stages, int *n_calls);
 
+/* ---- extensions of the host API of include/huffman.h (not in the reference) ----
+ * huf_gpu_set_relaxed_tree: 1 = huf_decode() accepts the 1025-entry trees of blocks that use all
+ * 256 byte values (the reference's encoder writes them, its decoder returns error 5).
+ * huf_gpu_memwrap: a read-only huf_read_writer_t over `length` bytes the caller already holds
+ * (no copy into a huf_memopen() buffer); huf_encode()/huf_decode() send such a stream to the
+ * device directly.  Close it with huf_memclose(); the bytes are never written or freed. */
+struct __huf_read_writer;
+void huf_gpu_set_relaxed_tree(int enabled);
+int huf_gpu_memwrap(struct __huf_read_writer **self, const void *data, size_t length);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,7 +66,7 @@ GPU_SYMBOLS = """hufgpu_device_count hufgpu_ctx_create hufgpu_ctx_destroy hufgpu
 hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_decode
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_synchronize hufgpu_set_profiling
-hufgpu_get_profile""".split()
+hufgpu_get_profile huf_gpu_set_relaxed_tree huf_gpu_memwrap""".split()
 
 
 def so_path() -> str:
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
     L.huf_decode.argtypes = [C.POINTER(Config)]
     L.huf_gpu_set_relaxed_tree.argtypes = [i32]
     L.huf_gpu_set_relaxed_tree.restype = None
+    L.huf_gpu_memwrap.argtypes = [C.POINTER(C.POINTER(ReadWriter)), vp, C.c_size_t]
 
     L.hufgpu_device_count.restype = i32
     L.hufgpu_ctx_create.argtypes = [C.POINTER(vp), i32]

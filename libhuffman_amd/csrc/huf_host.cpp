@@ -83,11 +83,14 @@ typedef struct {
     size_t off;     /* read cursor */
     size_t len;
     size_t cap;
+    void *wrapped;  /* huf_gpu_memwrap(): the caller's bytes (buf points here); never written or freed */
+    int readonly;
 } membuf_t;
 
 /* room for `count` more bytes behind the stream's contents */
 static huf_error_t mem_reserve(membuf_t *m, size_t count)
 {
+    if (m->readonly) return HUF_ERROR_INVALID_ARGUMENT;
     if (m->cap - m->len < count) {
         /* growth policy of src/io.c:79-84 (double, or twice the request), but never smaller
          * than what is needed - the reference under-allocates here */
@@ -147,6 +150,30 @@ huf_error_t huf_memopen(huf_read_writer_t **self, void **buf, size_t capacity)
     return HUF_ERROR_SUCCESS;
 }
 
+/* Extension (not in the reference): a read-only memory stream over bytes the caller already has,
+ * e.g. a Python bytes object - no copy into a huf_memopen() buffer.  Closed with huf_memclose(),
+ * which never touches the bytes. */
+int huf_gpu_memwrap(huf_read_writer_t **self, const void *data, size_t length)
+{
+    GUARD(self);
+    if (!data && length) return HUF_ERROR_INVALID_ARGUMENT;
+    huf_read_writer_t *rw = (huf_read_writer_t *)calloc(1, sizeof(*rw));
+    membuf_t *m = (membuf_t *)calloc(1, sizeof(*m));
+    if (!rw || !m) {
+        free(rw); free(m);
+        return HUF_ERROR_MEMORY_ALLOCATION;
+    }
+    m->wrapped = (void *)data;
+    m->buf = &m->wrapped;
+    m->len = m->cap = length;
+    m->readonly = 1;
+    rw->stream = m;
+    rw->write = memwrite;
+    rw->read = memread;
+    *self = rw;
+    return HUF_ERROR_SUCCESS;
+}
+
 static membuf_t *as_mem(const huf_read_writer_t *rw) { return rw ? (membuf_t *)rw->stream : NULL; }
 
 huf_error_t huf_memlen(const huf_read_writer_t *self, size_t *len)
@@ -166,6 +193,7 @@ huf_error_t huf_memcap(const huf_read_writer_t *self, size_t *cap)
 huf_error_t huf_memrewind(huf_read_writer_t *self)   /* truncate, src/io.c:160-170 */
 {
     GUARD(self);
+    if (as_mem(self)->readonly) { as_mem(self)->off = 0; return HUF_ERROR_SUCCESS; }   /* wrapped bytes: start over */
     as_mem(self)->len = 0;
     as_mem(self)->off = 0;
     return HUF_ERROR_SUCCESS;

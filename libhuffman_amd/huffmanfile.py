@@ -90,6 +90,38 @@ class _MemStream:
             self._buf = C.c_void_p()
 
 
+def _address_of(view: memoryview):
+    """(address, keep-alive object) of a contiguous byte view, read-only ones included."""
+    if not view.readonly:
+        raw = (C.c_char * len(view)).from_buffer(view)
+        return C.addressof(raw), raw
+    import numpy as np                   # a read-only buffer has no ctypes.from_buffer
+    arr = np.frombuffer(view, dtype=np.uint8)
+    return arr.ctypes.data, arr
+
+
+class _WrappedBytes:
+    """Read-only stream over bytes the caller holds (huf_gpu_memwrap): they go to the device as
+    they are, without a copy into a huf_memopen() buffer."""
+
+    def __init__(self, data):
+        self._lib = N.load()
+        self._view = memoryview(data).cast("B")
+        self._rw = C.POINTER(N.ReadWriter)()
+        addr, self._keep = _address_of(self._view) if len(self._view) else (None, None)
+        _check(self._lib.huf_gpu_memwrap(C.byref(self._rw), addr, len(self._view)),
+               "Failed to wrap the input bytes")
+
+    @property
+    def handle(self):
+        return self._rw
+
+    def close(self) -> None:
+        if self._rw:
+            _check(self._lib.huf_memclose(C.byref(self._rw)), "Failed to close memory stream")
+        self._keep = None
+
+
 class HuffmanCompressor:
     """Incremental compressor: whole blocks are encoded as soon as they are available, the
     remainder (< blocksize bytes) at flush()."""
@@ -106,9 +138,8 @@ class HuffmanCompressor:
         n = len(data)
         if n == 0:
             return b""
-        src, dst = _MemStream(n), _MemStream(n + n // 8 + 4096)
+        src, dst = _WrappedBytes(data), _MemStream(n + n // 8 + 4096)
         try:
-            src.write(data)
             cfg = N.Config(n, self._blocksize, 0, 0, src.handle, dst.handle)
             _check(self._lib.huf_encode(C.byref(cfg)), "Failed to encode the data")
             return dst.getvalue()
@@ -120,11 +151,18 @@ class HuffmanCompressor:
         """Feed data; returns the encoding of the blocks that became complete (maybe b"")."""
         if self._flushed:
             raise ValueError("Compressor has been flushed")
-        self._pending += memoryview(data).cast("B")
+        view = memoryview(data).cast("B")
+        if not self._pending:
+            # nothing buffered: the whole blocks are encoded straight from the caller's bytes
+            whole = len(view) - len(view) % self._blocksize
+            self._pending += view[whole:]
+            return self._encode(view[:whole]) if whole else b""
+        self._pending += view
         whole = len(self._pending) - len(self._pending) % self._blocksize
         if not whole:
             return b""
-        out = self._encode(memoryview(self._pending)[:whole])
+        with memoryview(self._pending) as pv:
+            out = self._encode(pv[:whole])
         del self._pending[:whole]
         return out
 
@@ -154,9 +192,8 @@ class HuffmanDecompressor:
         n = len(view)
         if n == 0:
             return b""
-        src, dst = _MemStream(n), _MemStream(max(self._memlimit, 4 * n))
+        src, dst = _WrappedBytes(view), _MemStream(max(self._memlimit, 4 * n))
         try:
-            src.write(view)
             cfg = N.Config(n, 0, 0, 0, src.handle, dst.handle)
             _check(self._lib.huf_decode(C.byref(cfg)), "Failed to decode the data")
             return dst.getvalue()
@@ -169,9 +206,11 @@ class HuffmanDecompressor:
 
 
 def compress(data, blocksize: int = DEFAULT_BLOCK_SIZE) -> bytes:
-    """One-shot compression (huffmanfile.py:409-417)."""
+    """One-shot compression (huffmanfile.py:409-417): blocks of `blocksize` bytes and one short
+    block for what is left - which is what a single huf_encode() call over all of `data` writes,
+    so the bytes take one trip to the device."""
     comp = HuffmanCompressor(blocksize)
-    return comp.compress(data) + comp.flush()
+    return comp._encode(memoryview(data).cast("B"))
 
 
 def decompress(data, memlimit: int = DEFAULT_MEM_LIMIT) -> bytes:

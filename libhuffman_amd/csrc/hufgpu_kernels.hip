@@ -1393,25 +1393,35 @@ struct BitReader {
     const uint32_t *pay;
     uint32_t d0, d1;     /* ({word g, word g+1} >> 1): the bit above word g is never looked at */
     uint32_t wl;         /* word g + 1 as staged */
-    uint32_t g;
+    uint32_t r;          /* g relative to the first word of the lane's subsequence (0..DEC_SUB_WORDS-1) */
+    uint32_t waddr;      /* LDS byte offset of word g + 1 inside `pay` */
     int32_t s;
 
     __device__ __forceinline__ uint32_t word(uint32_t i) const { return pay[pay_slot<COLS>(i)]; }
-    __device__ __forceinline__ void load(uint32_t pos)
+    /* sub_w0 = first word of the lane's subsequence (a multiple of DEC_SUB_WORDS) */
+    __device__ __forceinline__ void load(uint32_t pos, uint32_t sub_w0)
     {
-        g = pos >> 5;
+        const uint32_t g = pos >> 5;
+        r = g - sub_w0;
         s = (int32_t)(31u - (pos & 31u));
         const uint32_t w0 = word(g);
-        wl = word(g + 1);
+        waddr = 4u * pay_slot<COLS>(g + 1);
+        wl = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(pay) + waddr);
         d0 = w0 >> 1;
         d1 = __builtin_amdgcn_alignbit(w0, wl, 1);
     }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(d0, d1, (uint32_t)s); }
-    __device__ __forceinline__ uint32_t pos() const { return (g << 5) + (31u - (uint32_t)s); }
-    __device__ __forceinline__ void step_next()               /* s has been brought back into 0..31 */
+    __device__ __forceinline__ uint32_t pos(uint32_t sub_w0) const { return ((r + sub_w0) << 5) + (31u - (uint32_t)s); }
+    /* The position moved into word g + 1 (s is back in 0..31); only called while r + 1 <
+     * DEC_SUB_WORDS.  The staged layout puts word i at (i % W) * COLS + i / W, so the lane's own
+     * words are COLS apart and the first word of the next lane's subsequence, the only other one
+     * ever appended here, sits one slot behind the lane's first word. */
+    __device__ __forceinline__ void step_next(uint32_t wrap_addr)
     {
-        g++;
-        const uint32_t wn = word(g + 1);
+        r++;
+        waddr += 4u * COLS;
+        if (r == DEC_SUB_WORDS - 1) waddr = wrap_addr;
+        const uint32_t wn = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(pay) + waddr);
         d0 = d1;
         d1 = __builtin_amdgcn_alignbit(wl, wn, 1);
         wl = wn;
@@ -1543,7 +1553,7 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
     const int tid = (int)threadIdx.x;
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
     const uint32_t sub_w0 = sub_lo >> 5;
-    const uint32_t limit_w = sub_w0 + DEC_SUB_WORDS;
+    constexpr uint32_t DONE = 0x1000u;   /* rd.r of a lane that has left the loop (the loop's only exit test) */
     uint32_t c = 0, nbad = 0, pos = start;
     uint32_t lw = DEC_SUB_WORDS;  /* word of the latest mark; DEC_SUB_WORDS = none written */
     uint32_t old_c = 0;
@@ -1551,25 +1561,27 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
     if (pos < limit) {
         BitReader<DecShared<THREADS>::COLS> rd;
         rd.pay = sh.pay;
-        rd.load(pos);
-        lw = rd.g - sub_w0;
+        rd.load(pos, sub_w0);
+        lw = rd.r;
         for (uint32_t k = 0; k < lw; k++) sh.mark[k][tid] = DEC_NO_MARK;     /* nothing visits these */
         if (MERGE) {
             const uint32_t old = sh.mark[lw][tid];
             if (old != DEC_NO_MARK && (old & 31u) == (pos & 31u)) { merged = true; old_c = old >> 5; }
         }
         if (!merged) {
-            sh.mark[lw][tid] = dec_mark(0, pos);
+            uint16_t *mk = &sh.mark[lw][tid];                    /* mark of the current word */
+            *mk = dec_mark(0, pos);
+            /* word DEC_SUB_WORDS of the subsequence = first word of the next lane's */
+            const uint32_t wrap_addr = 4u * pay_slot<DecShared<THREADS>::COLS>(sub_w0 + DEC_SUB_WORDS);
             uint32_t it = 0;      /* table lookups done: the same in every lane that is still in the loop (an SGPR) */
             uint32_t miss = 0;    /* lookups of this lane that were not codewords */
-            uint32_t left = limit_w - rd.g;   /* words up to the limit; 0 = this lane is done (the loop's only exit test) */
             do {
                 uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
                 bool slow = e >= DEC_E_LONG;
-                if (CHECK) slow = (e >= DEC_E_BAD) || (rd.pos() + dec_e_adv(e) > pay_rel);
+                if (CHECK) slow = (e >= DEC_E_BAD) || (rd.pos(sub_w0) + dec_e_adv(e) > pay_rel);
                 if (__builtin_expect(__ballot(e >= DEC_E_BAD || slow) != 0ull, 0)) {
                     if (slow) {
-                        const uint32_t p = rd.pos();
+                        const uint32_t p = rd.pos(sub_w0);
                         uint32_t np = DEC_EXH;                        /* needs bits past the payload (decoder.c:53-56) */
                         bool codeword = false;
                         if (e >= DEC_E_LONG) {
@@ -1577,28 +1589,29 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             const uint32_t npos = (uint32_t)r;
                             const int st = (int)(r >> 40);
                             if (st == CW_OK && npos <= pay_rel) { np = npos; codeword = true; }
-                            else if (st == CW_BAD && npos <= pay_rel) { nbad |= 1u << lw; np = p + 1; }
+                            else if (st == CW_BAD && npos <= pay_rel) { nbad |= 1u << rd.r; np = p + 1; }
                         } else if (CHECK && e >= DEC_E_BAD) {
-                            if (p + (e & 0x7fu) <= pay_rel) { nbad |= 1u << lw; np = p + 1; }   /* a real payload bit left the tree */
+                            if (p + (e & 0x7fu) <= pay_rel) { nbad |= 1u << rd.r; np = p + 1; }   /* a real payload bit left the tree */
                         }
                         if (!codeword) miss++;
                         e = 0;                                        /* the common part has nothing left to do */
-                        if (np >= limit) { pos = np; c = it + 1 - miss; left = 0; }
+                        if (np >= limit) { pos = np; c = it + 1 - miss; lw = rd.r; rd.r = DONE; }
                         else {
-                            if ((np >> 5) != rd.g) {                  /* words a long walk jumps over are never visited */
-                                const uint32_t nlw = (np >> 5) - sub_w0;
-                                for (uint32_t k = lw + 1; k < nlw; k++) sh.mark[k][tid] = DEC_NO_MARK;
-                                lw = nlw;
-                                left = limit_w - (np >> 5);
-                                const uint32_t old = sh.mark[lw][tid];
+                            const uint32_t nr = (np >> 5) - sub_w0;
+                            bool stop = false;
+                            if (nr != rd.r) {                         /* words a long walk jumps over are never visited */
+                                for (uint32_t k = rd.r + 1; k < nr; k++) sh.mark[k][tid] = DEC_NO_MARK;
+                                mk = &sh.mark[nr][tid];
+                                const uint32_t old = *mk;
                                 if (MERGE && old != DEC_NO_MARK && (old & 31u) == (np & 31u)) {
-                                    merged = true; old_c = old >> 5; pos = np; c = it + 1 - miss; left = 0;
-                                } else sh.mark[lw][tid] = dec_mark(it + 1 - miss, np);
+                                    merged = true; old_c = old >> 5; pos = np; c = it + 1 - miss; lw = nr; stop = true;
+                                } else *mk = dec_mark(it + 1 - miss, np);
                             }
-                            if (left) rd.load(np);
+                            if (stop) rd.r = DONE;
+                            else rd.load(np, sub_w0);
                         }
                     } else if (e >= DEC_E_BAD) {                      /* left the tree: resume after the run */
-                        nbad |= 1u << lw;
+                        nbad |= 1u << rd.r;
                         miss += 1u - ((e >> 7) & 1u);                 /* ... unless the entry also took the codeword behind it */
                     }
                 }
@@ -1607,30 +1620,21 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                 if (rd.s < 0) {                                       /* the track enters the next word (never after the slow path: it advanced by 0) */
                     rd.s += 32;
                     const uint32_t off = 31u - (uint32_t)rd.s;
-                    left--;
-                    if (left == 0) { pos = limit + off; c = it - miss; }      /* lw stays: the word of the last mark */
-                    else {
-                        lw++;
-                        const uint32_t old = MERGE ? (uint32_t)sh.mark[lw][tid] : (uint32_t)DEC_NO_MARK;
+                    if (rd.r == DEC_SUB_WORDS - 1) {                  /* ... which is past the lane's limit */
+                        pos = limit + off; c = it - miss; lw = DEC_SUB_WORDS - 1; rd.r = DONE;
+                    } else {
+                        mk += THREADS;                                /* &sh.mark[r + 1][tid] */
+                        const uint32_t old = MERGE ? (uint32_t)*mk : (uint32_t)DEC_NO_MARK;
                         if (MERGE && old != DEC_NO_MARK && (old & 31u) == off) {
-                            merged = true; old_c = old >> 5; pos = ((rd.g + 1) << 5) + off; c = it - miss; left = 0;
+                            merged = true; old_c = old >> 5; lw = rd.r + 1;
+                            pos = ((sub_w0 + lw) << 5) + off; c = it - miss; rd.r = DONE;
                         } else {
-                            sh.mark[lw][tid] = (uint16_t)(((it - miss) << 5) | off);
-                            rd.step_next();
+                            *mk = (uint16_t)(((it - miss) << 5) | off);
+                            rd.step_next(wrap_addr);
                         }
                     }
                 }
-            } while (left);
-#ifdef DEC_PHASE_PROF
-            {   /* loop iterations executed by this wave (max over its lanes) */
-                uint32_t mx = it;
-                for (int o = 1; o < 64; o <<= 1) mx = dmax(mx, (uint32_t)__shfl_xor((int)mx, o));
-                if ((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == 0u) {
-                    atomicAdd(&g_dec_prof[MERGE ? 9 : 8], (unsigned long long)mx);
-                    atomicAdd(&g_dec_prof[MERGE ? 11 : 10], 1ull);
-                }
-            }
-#endif
+            } while (rd.r != DONE);
         }
     }
     if (MERGE && merged) {

@@ -1475,10 +1475,10 @@ enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
 /* Table entries (uint16):
  *   leaf    (len << 8) | symbol                     len = 1..DEC_LUT_BITS
- *   bad     0x4000 | (skip << 8) | flag | bits      the walk leaves the tree at bit `bits` (7 bits) of
- *                                                   the window; a speculative track resumes `skip` bits
- *                                                   on; flag 0x80: skip also covers the codeword that
- *                                                   follows the failing run
+ *   bad     0x4000 | nocw | (skip << 8) | bits      the walk leaves the tree at bit `bits` of the
+ *                                                   window; a speculative track resumes `skip` (5 bits)
+ *                                                   bits on; nocw (0x2000) is clear when skip also
+ *                                                   covers the codeword that follows the failing run
  *   long    0xC000 | node                           still inside the tree after DEC_LUT_BITS bits
  * so bits 8..13 are "advance by" for leaf and bad alike.  Every code of an encoder-made tree
  * starts with 0 (the wrap root has no right child, src/tree.c:410-413), so a lane that starts
@@ -1487,7 +1487,8 @@ enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
  * bits that would fail the same way (bits == 1: the run of equal leading bits). */
 #define DEC_E_BAD  0x4000u
 #define DEC_E_LONG 0xC000u
-__device__ __forceinline__ uint32_t dec_e_adv(uint32_t e) { return (e >> 8) & 0x3fu; }
+#define DEC_E_NOCW 0x2000u           /* in a `bad` entry: no codeword was taken (the lookup does not count as one) */
+__device__ __forceinline__ uint32_t dec_e_adv(uint32_t e) { return (e >> 8) & 0x1fu; }
 
 #ifdef DEC_RARE_NOINLINE
 #define DEC_RARE_ATTR __noinline__
@@ -1525,7 +1526,7 @@ struct LaneTrack {
     uint32_t start;    /* first codeword of this lane (segment bits) */
     uint32_t end;      /* first codeword at/after the lane's limit, or DEC_EXH */
     uint32_t cnt;      /* codewords that start inside the lane's subsequence */
-    uint32_t badmask;  /* bit k: a walk that started in word k of the subsequence left the tree */
+    int32_t lastbad;   /* last word of the subsequence in which a walk left the tree, -1 = none */
 };
 
 #define DEC_NO_MARK 0xffffu
@@ -1544,8 +1545,9 @@ __device__ __forceinline__ uint16_t dec_mark(uint32_t count, uint32_t pos) { ret
  * The common iteration is v_alignbit, 2 x index, table read, special test, s -= advance, sign
  * test.  The subsequence limit is only looked at on a word change (it is word aligned), and the
  * codeword count is the wave-uniform iteration count minus the lane's non-codeword lookups.
- * Only WHERE walks left the tree is remembered (per word); the exact first one of the final
- * track is searched afterwards, by dec_first_bad, on corrupt streams only. */
+ * Of the walks that left the tree only the word of the LAST one is remembered (enough to tell,
+ * after a merge, whether the surviving part of the old track had one); the exact first one of
+ * the final track is searched afterwards, by dec_first_bad, on corrupt streams only. */
 template <int THREADS, bool MERGE, bool CHECK>
 __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack &tr, uint32_t start,
                                               uint32_t sub_lo, uint32_t pay_rel)
@@ -1554,7 +1556,8 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
     const uint32_t limit = sub_lo + DEC_SUB_BITS;
     const uint32_t sub_w0 = sub_lo >> 5;
     constexpr uint32_t DONE = 0x1000u;   /* rd.r of a lane that has left the loop (the loop's only exit test) */
-    uint32_t c = 0, nbad = 0, pos = start;
+    uint32_t c = 0, pos = start;
+    int32_t nlast = -1;           /* like LaneTrack::lastbad, for the part decoded here */
     uint32_t lw = DEC_SUB_WORDS;  /* word of the latest mark; DEC_SUB_WORDS = none written */
     uint32_t old_c = 0;
     bool merged = false;
@@ -1589,9 +1592,9 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             const uint32_t npos = (uint32_t)r;
                             const int st = (int)(r >> 40);
                             if (st == CW_OK && npos <= pay_rel) { np = npos; codeword = true; }
-                            else if (st == CW_BAD && npos <= pay_rel) { nbad |= 1u << rd.r; np = p + 1; }
+                            else if (st == CW_BAD && npos <= pay_rel) { nlast = (int32_t)rd.r; np = p + 1; }
                         } else if (CHECK && e >= DEC_E_BAD) {
-                            if (p + (e & 0x7fu) <= pay_rel) { nbad |= 1u << rd.r; np = p + 1; }   /* a real payload bit left the tree */
+                            if (p + (e & 0x7fu) <= pay_rel) { nlast = (int32_t)rd.r; np = p + 1; }   /* a real payload bit left the tree */
                         }
                         if (!codeword) miss++;
                         e = 0;                                        /* the common part has nothing left to do */
@@ -1611,8 +1614,8 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
                             else rd.load(np, sub_w0);
                         }
                     } else if (e >= DEC_E_BAD) {                      /* left the tree: resume after the run */
-                        nbad |= 1u << rd.r;
-                        miss += 1u - ((e >> 7) & 1u);                 /* ... unless the entry also took the codeword behind it */
+                        nlast = (int32_t)rd.r;                        /* words only grow: the latest is the last */
+                        miss += (e >> 13) & 1u;                       /* DEC_E_NOCW: not a codeword */
                     }
                 }
                 asm volatile("s_add_u32 %0, %0, 1" : "+s"(it) : : "scc");
@@ -1646,14 +1649,14 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
             if (r != DEC_NO_MARK) sh.mark[k][tid] = (uint16_t)(r + (delta << 5));
         }
         sh.mark[lw][tid] = dec_mark(c, pos);
-        tr.badmask = nbad | (tr.badmask & ~((1u << lw) - 1u));
+        if (tr.lastbad < (int32_t)lw) tr.lastbad = nlast;      /* the old track's events before word lw are gone */
         tr.cnt += delta;
         /* tr.end unchanged */
     } else {
         for (uint32_t k = (lw == DEC_SUB_WORDS ? 0u : lw + 1); k < DEC_SUB_WORDS; k++) sh.mark[k][tid] = DEC_NO_MARK;
         tr.cnt = c;
         tr.end = pos;
-        tr.badmask = nbad;
+        tr.lastbad = nlast;
     }
     tr.start = start;
 }
@@ -1669,7 +1672,7 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
 
 /* Codewords a (final) track decodes from `start` before the first walk that leaves the tree
  * on a real payload bit (src/decoder.c:69-71); DEC_NO_BAD if it reaches `limit` or the end of
- * the payload first.  Only run for lanes whose badmask is set: corrupt streams. */
+ * the payload first.  Only run for lanes whose track has such an event: corrupt streams. */
 template <int THREADS>
 __device__ __noinline__ uint32_t dec_first_bad(const DecShared<THREADS> &sh, uint32_t start, uint32_t limit, uint32_t pay_rel)
 {
@@ -2032,7 +2035,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                     const uint32_t top = (uint32_t)idx << (32 - DEC_LUT_BITS);
                     skip = dmin<uint32_t>((uint32_t)__clz((int)((top >> 31) ? ~top : top)), (uint32_t)DEC_LUT_BITS);
                 }
-                e = DEC_E_BAD | (skip << 8) | bits;
+                e = DEC_E_BAD | DEC_E_NOCW | (skip << 8) | bits;
             }
             mine[k] = (uint16_t)e;
         }
@@ -2041,8 +2044,8 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         for (int k = 0; k < PERL; k++) sh.lut[tid + k * THREADS] = mine[k];
 #ifndef DEC_NO_FOLD
         /* A speculative lane that meets a run of failing bits decodes the codeword behind the run
-         * in its next iteration; when run + codeword fit the window, one entry does both (flag
-         * 0x80: "and a codeword"), which takes a third off the count pass's iterations. */
+         * in its next iteration; when run + codeword fit the window, one entry does both
+         * (DEC_E_NOCW clear), which helps data with short codes (uniform bytes 2.61 -> 2.48 ms). */
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PERL; k++) {
@@ -2052,7 +2055,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 const uint32_t idx = (uint32_t)(tid + k * THREADS);
                 const uint32_t e2 = sh.lut[(idx << run) & ((1u << DEC_LUT_BITS) - 1u)];
                 if (run < (uint32_t)DEC_LUT_BITS && e2 < DEC_E_BAD && run + (e2 >> 8) <= (uint32_t)DEC_LUT_BITS)
-                    sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 0x80u | 1u);
+                    sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 1u);
             }
         }
 #endif
@@ -2145,7 +2148,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         /* the first walk that left the tree, in stream order, is a real error if it happens
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.
          * Symbols decoded before it are still delivered, like the reference's writer does. */
-        if (tr.badmask != 0u && (uint64_t)ex < remaining) {
+        if (tr.lastbad >= 0 && (uint64_t)ex < remaining) {
             const uint32_t bad_at = dec_first_bad<THREADS>(sh, tr.start, sub_lo + DEC_SUB_BITS, pay_rel);
             if (bad_at != DEC_NO_BAD && (uint64_t)ex + bad_at < remaining) atomicMin(&sh.badsym, ex + bad_at);
         }

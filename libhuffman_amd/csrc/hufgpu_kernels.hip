@@ -1706,59 +1706,6 @@ template <int THREADS, bool STORE>
 __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint32_t start, uint32_t pay_rel,
                                               uint32_t quota, uint8_t *g)
 {
-#ifdef DEC_OLD_WRITE
-    BitReader<DecShared<THREADS>::COLS> rd;
-    rd.pay = sh.pay;
-    rd.load(start);
-    auto next = [&]() -> uint32_t {              /* table entry of the next codeword: low byte = symbol */
-        uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
-        if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
-            if (e >= DEC_E_BAD) {
-                const uint64_t r = dec_rare_packed<THREADS>(sh, e, rd.pos(), pay_rel);
-                rd.load((uint32_t)r);
-                e = (uint32_t)(r >> 32) & 0xffu;
-            }
-        }
-        rd.s -= (int32_t)dec_e_adv(e);
-        if (rd.s < 0) {
-            rd.s += 32;
-            rd.step_next();
-        }
-        return e;
-    };
-    if (!STORE) {                       /* probe mode: only the position after the quota is wanted */
-        for (uint32_t c = 0; c < quota; c++) (void)next();
-        return rd.pos();
-    }
-#ifndef DEC_UNALIGNED_WRITE
-    /* bytes up to the first 4-byte boundary of the output, whole words (four table entries folded
-     * into one register with v_alignbit, one 32-bit store), the bytes that are left */
-    const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
-    for (uint32_t c = 0; c < head; c++) g[c] = (uint8_t)next();
-    uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
-    const uint32_t words = (quota - head) >> 2;
-    for (uint32_t k = 0; k < words; k++) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_alignbit(next(), acc, 8);
-        gw[k] = acc;
-    }
-    for (uint32_t c = head + 4u * words; c < quota; c++) g[c] = (uint8_t)next();
-#else
-    /* whole words first (four table entries folded into one register with v_alignbit, one 32-bit
-     * store at whatever byte address the lane's output starts - gfx950 global stores need no
-     * alignment), then the 0-3 bytes that are left */
-    const uint32_t words = quota >> 2;
-    for (uint32_t k = 0; k < words; k++) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_alignbit(next(), acc, 8);
-        __builtin_memcpy(g + 4u * k, &acc, 4);
-    }
-    for (uint32_t c = 4u * words; c < quota; c++) g[c] = (uint8_t)next();
-#endif
-    return rd.pos();
-#else
     BufReader<DecShared<THREADS>::COLS> rd;
     rd.pay = sh.pay;
     rd.load(start);
@@ -1806,7 +1753,6 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
         if (rd.avail <= 32) rd.refill();
     }
     return rd.pos();
-#endif
 }
 
 /* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit
@@ -1962,9 +1908,6 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     const uint8_t *pay = tree + 2 * tree_len;
     const uint64_t pay_bits = pay_bytes * 8ull;
     DPROF_ADD(0, pt); pt = DPROF_T();
-#if defined(DEC_ABLATE) && DEC_ABLATE == 1
-    *end_bits = 0; return HUFE_OK;
-#endif
 
     /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
     {
@@ -2114,13 +2057,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
         __syncthreads();
         DPROF_ADD(3, pt); pt = DPROF_T();
-#if defined(DEC_ABLATE) && DEC_ABLATE == 5
-        int dbg_rounds = 0, dbg_changed_total = 0;
-#endif
         for (;;) {
-#if defined(DEC_ABLATE) && DEC_ABLATE == 3
-            break;
-#endif
             /* left neighbour's end: a shuffle inside the wave, LDS across the wave seams */
             uint32_t ns = (uint32_t)__shfl_up((int)tr.end, 1);
             if ((tid & 63) == 0) ns = (tid == 0) ? first_start : sh.wend[(tid >> 6) - 1];
@@ -2130,15 +2067,8 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 dec_scan<THREADS, true>(sh, tr, ns, sub_lo, pay_rel);
             }
             if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
-#if defined(DEC_ABLATE) && DEC_ABLATE == 5
-            dbg_rounds++;
-            dbg_changed_total += __syncthreads_count(changed);
-#endif
             if (!__syncthreads_or(changed)) break;
         }
-#if defined(DEC_ABLATE) && DEC_ABLATE == 5
-        if (tid == 0 && blockIdx.x == 7) printf("seg0=%llu rounds=%d changed_total=%d\n", (unsigned long long)seg0, dbg_rounds, dbg_changed_total);
-#endif
 
         DPROF_ADD(4, pt); pt = DPROF_T();
         /* output positions */
@@ -2165,10 +2095,6 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
             if (quota > tr.cnt) quota = tr.cnt;
         }
         DPROF_ADD(5, pt); pt = DPROF_T();
-#if defined(DEC_ABLATE) && DEC_ABLATE == 4
-        quota = 0;
-        if (tid == 0) sh.qend = sh.wend[THREADS / 64 - 1] == DEC_EXH ? pay_rel : sh.wend[THREADS / 64 - 1];
-#endif
         if (STORE) {
             if (quota) {
 #if defined(DEC_DUP) && DEC_DUP == 3
@@ -2200,7 +2126,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
 
 /* Indexed decode: one workgroup per block, block extents from the in-process index. */
 #ifndef DEC_WAVES_PER_SIMD
-#define DEC_WAVES_PER_SIMD 8      /* 4 workgroups of 512 per CU: caps the kernel at 64 VGPRs (a 48-byte spill), +15 % */
+#define DEC_WAVES_PER_SIMD 8      /* 4 workgroups of 512 per CU: caps the kernel at 64 VGPRs (no scratch), +15 % over 3 workgroups */
 #endif
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(const uint8_t *__restrict__ stream,

@@ -245,6 +245,7 @@ static int alloc_two_level(hufgpu_ctx *c, TwoLevel *t, uint64_t cap, bool with_m
     if (with_min) HIP_OK(c, hipMalloc((void **)&t->gmin, groups * sizeof(uint64_t)));
     HIP_OK(c, hipMemset(t->gcount, 0, groups * SCAN_TICKET_STRIDE * sizeof(uint32_t)));
     HIP_OK(c, hipMemset(t->done, 0, sizeof(uint32_t)));
+    HIP_OK(c, hipDeviceSynchronize());   /* the kernels may run on a non-blocking stream: the zeros must be there first */
     return HUFE_OK;
 }
 

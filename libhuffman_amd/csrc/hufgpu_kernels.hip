@@ -404,28 +404,43 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
  *     row_bcast31) ending in lane 63 and read back as a scalar: no LDS round trips in the loop.
  *   - Children are written to LDS fire-and-forget; leaf counts are derived after the loop.
  * ==================================================================================== */
-__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v, const int ctrl_sel)
-{
-    uint32_t o;
-    switch (ctrl_sel) {
-    case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); break;   /* quad_perm [1,0,3,2] */
-    case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); break;   /* quad_perm [2,3,0,1] */
-    case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); break;  /* row_half_mirror */
-    case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); break;  /* row_mirror */
-    case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); break;  /* row_bcast:15 -> rows 1,3 */
-    default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); break; /* row_bcast:31 -> rows 2,3 */
-    }
-    return dmin(v, o);
-}
-
+/* Wave minimum: six v_min_u32 with a DPP source operand (the compiler turns update_dpp + min into
+ * mov, mov_dpp, min - three instructions per step; the merge loop runs two of these reductions
+ * per round and is VALU bound once enough tree waves are resident).  s_nop 1 = the two wait
+ * states a DPP read needs after the VALU write of its source.  Rows not named by row_mask keep
+ * their value, the result is complete in lane 63. */
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    v = dpp_min_step(v, 0);
-    v = dpp_min_step(v, 1);
-    v = dpp_min_step(v, 2);
-    v = dpp_min_step(v, 3);
-    v = dpp_min_step(v, 4);
-    v = dpp_min_step(v, 5);
+#ifdef TREE_DPP_BUILTIN
+    auto step = [](uint32_t x, int sel) {
+        uint32_t o;
+        switch (sel) {
+        case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false); break;
+        case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false); break;
+        case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false); break;
+        case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false); break;
+        case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xa, 0xf, false); break;
+        default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xc, 0xf, false); break;
+        }
+        return dmin(x, o);
+    };
+    for (int k = 0; k < 6; k++) v = step(v, k);
+#else
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+#endif
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 

@@ -1399,14 +1399,16 @@ __device__ __forceinline__ uint32_t pay_slot(uint32_t i) { return (i & (DEC_SUB_
 
 /* Two-word MSB-first window over the staged segment, kept so that a symbol costs as few vector
  * instructions as possible (the decode kernel is bound by VALU issue, 4 cycles per wave64
- * instruction): the pair is held delayed by one bit, {d0,d1} = {word g, word g+1} >> 1, and the
- * position inside word g as s = 31 - (pos & 31).  Then the 32 bits at the position are ONE
- * v_alignbit_b32 (shift amounts 0..31, no 64-bit shift and no special case at a word start),
- * a codeword of len bits is s -= len, and s < 0 says "moved into word g + 1". */
+ * instruction): the pair is held delayed, {d0,d1} = {word g, word g+1} >> 20, and the position
+ * inside word g as s = 31 - (pos & 31).  Then ONE v_alignbit_b32 by s (shift amounts 0..31, no
+ * 64-bit shift, no special case at a word start) puts the 12 bits at the position at bits 1..12
+ * of its result - masked, that is the byte offset of their table entry - a codeword of len bits
+ * is s -= len, and s < 0 says "moved into word g + 1". */
 template <int COLS>
 struct BitReader {
     const uint32_t *pay;
-    uint32_t d0, d1;     /* ({word g, word g+1} >> 1): the bit above word g is never looked at */
+    static constexpr uint32_t DELAY = 32 - DEC_LUT_BITS;   /* 20 */
+    uint32_t d0, d1;     /* {word g, word g+1} >> DELAY */
     uint32_t wl;         /* word g + 1 as staged */
     uint32_t r;          /* g relative to the first word of the lane's subsequence (0..DEC_SUB_WORDS-1) */
     uint32_t waddr;      /* LDS byte offset of word g + 1 inside `pay` */
@@ -1422,10 +1424,14 @@ struct BitReader {
         const uint32_t w0 = word(g);
         waddr = 4u * pay_slot<COLS>(g + 1);
         wl = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(pay) + waddr);
-        d0 = w0 >> 1;
-        d1 = __builtin_amdgcn_alignbit(w0, wl, 1);
+        d0 = w0 >> DELAY;
+        d1 = __builtin_amdgcn_alignbit(w0, wl, DELAY);
     }
-    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(d0, d1, (uint32_t)s); }
+    /* byte offset of the table entry for the DEC_LUT_BITS bits at the position */
+    __device__ __forceinline__ uint32_t lut_offset() const
+    {
+        return __builtin_amdgcn_alignbit(d0, d1, (uint32_t)s) & (((1u << DEC_LUT_BITS) - 1u) << 1);
+    }
     __device__ __forceinline__ uint32_t pos(uint32_t sub_w0) const { return ((r + sub_w0) << 5) + (31u - (uint32_t)s); }
     /* The position moved into word g + 1 (s is back in 0..31); only called while r + 1 <
      * DEC_SUB_WORDS.  The staged layout puts word i at (i % W) * COLS + i / W, so the lane's own
@@ -1437,8 +1443,8 @@ struct BitReader {
         waddr += 4u * COLS;
         if (r == DEC_SUB_WORDS - 1) waddr = wrap_addr;
         const uint32_t wn = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(pay) + waddr);
-        d0 = d1;
-        d1 = __builtin_amdgcn_alignbit(wl, wn, 1);
+        d0 = wl >> DELAY;
+        d1 = __builtin_amdgcn_alignbit(wl, wn, DELAY);
         wl = wn;
     }
 };
@@ -1594,7 +1600,7 @@ __device__ __forceinline__ void dec_scan_impl(DecShared<THREADS> &sh, LaneTrack 
             uint32_t it = 0;      /* table lookups done: the same in every lane that is still in the loop (an SGPR) */
             uint32_t miss = 0;    /* lookups of this lane that were not codewords */
             do {
-                uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
+                uint32_t e = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(sh.lut) + rd.lut_offset());
                 bool slow = e >= DEC_E_LONG;
                 if (CHECK) slow = (e >= DEC_E_BAD) || (rd.pos(sub_w0) + dec_e_adv(e) > pay_rel);
                 if (__builtin_expect(__ballot(e >= DEC_E_BAD || slow) != 0ull, 0)) {
@@ -1705,7 +1711,7 @@ __device__ __forceinline__ void dec_scan_words(DecShared<THREADS> &sh, LaneTrack
         int32_t s_keep = 0;
         if (rd.r == r) {          /* not the lanes that a long codeword carried past this word, or out */
             while (rd.s >= 0) {
-                uint32_t e = sh.lut[rd.window() >> (32 - DEC_LUT_BITS)];
+                uint32_t e = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(sh.lut) + rd.lut_offset());
                 if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
                     if (e >= DEC_E_LONG) {
                         const uint32_t p = rd.pos(sub_w0);

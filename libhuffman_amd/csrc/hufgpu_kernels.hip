@@ -1285,10 +1285,17 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
             load_header10(stream, stream_len, o0, bl, tl);
             if (tl < 0 || tl > max_tree_len) m.status = HUFE_OVERFLOW;          /* decoder.c:237-239 */
             else if (o1 - o0 < HUF_HEADER_FIXED + 2ull * (uint64_t)tl) m.status = HUFE_RW;   /* :248-252 */
-            else if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;              /* beyond kernel limits */
             else {
-                m.block_len = bl;
-                m.tree_len = tl;
+                /* A block cannot hold more symbols than its payload has bits: a larger block_len (a
+                 * damaged header) is decoded as far as the input goes and then fails like the
+                 * reference's reader does at the end of its input (decoder.c:53-56). */
+                const uint64_t pay_bits = (o1 - o0 - HUF_HEADER_FIXED - 2ull * (uint64_t)tl) * 8ull;
+                if (bl > pay_bits) bl = pay_bits + 1;
+                if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;               /* beyond kernel limits */
+                else {
+                    m.block_len = bl;
+                    m.tree_len = tl;
+                }
             }
         }
         dmeta[b] = m;
@@ -2302,11 +2309,19 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
         const uint8_t *tree = stream + rd;
         rd += 2ull * (uint64_t)tl;
         if (block_len == 0) { nblk++; continue; }
-        if (block_len > 0xffffffffull) { err = HUFE_ARGUMENT; break; }
-        if (wr + block_len > out_cap) { err = HUFE_MEMORY; break; }
+        /* more symbols than payload bits left (a damaged header): decode what is there, then fail
+         * where the reference's reader runs out of input (decoder.c:53-56) */
+        uint64_t want = block_len;
+        if (want > (avail - rd) * 8ull) want = (avail - rd) * 8ull + 1;
+        /* ... and no more than the output has room for: an error inside that part is the
+         * stream's first error; only a block that decodes cleanly up to there needs more room */
+        const bool capped = want > out_cap - wr;
+        if (capped) want = out_cap - wr;
+        if (want > 0xffffffffull) { err = HUFE_ARGUMENT; break; }
         uint64_t end_bits = 0, produced = 0;
-        err = decode_block<THREADS>(sh, tree, tl, block_len, avail - rd, out + wr, &end_bits, &produced);
+        if (want) err = decode_block<THREADS>(sh, tree, tl, want, avail - rd, out + wr, &end_bits, &produced);
         if (err != HUFE_OK) { wr += produced; break; }   /* symbols before the failure stay delivered */
+        if (capped) { wr += want; err = HUFE_MEMORY; break; }
         rd += (end_bits + 7) >> 3;
         wr += block_len;
         nblk++;

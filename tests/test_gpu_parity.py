@@ -372,6 +372,32 @@ def test_payload_walk_leaves_tree_mid_block(torch_mod, codec, oracle, kind):
     assert 6 in seen
 
 
+def test_damaged_block_len_fields(torch_mod, codec, oracle):
+    """A block_len larger than the block really is (found by tools/soak.py): far beyond what the
+    payload can hold -> decode what is there, then error 3 like the reference's reader at the end
+    of its input; a little too large -> the walk runs into the next header and fails there (6 or
+    3) - also when the claimed length would not fit the caller's output buffer."""
+    torch = torch_mod
+    data = datagen.zipf255(40000)
+    good, offs = oracle.encode(data, 4096, with_offsets=True)
+    cases = []
+    for blk in (0, 3, 9):
+        o0 = int(offs[blk])
+        b = good.copy(); b[o0 + 5] = 0xff; cases.append(b)                      # ~2^47 symbols
+        b = good.copy(); b[o0 + 3] = 0x01; cases.append(b)                      # +16 Mi symbols
+        b = good.copy(); b[o0] = (int(b[o0]) + 70) & 0xff; cases.append(b)      # a few dozen too many / too few
+        b = good.copy(); b[o0 + 1] ^= 0x40; cases.append(b)                     # +-16 Ki symbols
+    cap = data.size + 64
+    for i, bad in enumerate(cases):
+        oerr, oout, _ = oracle.decode(bad, cap, 1024)
+        for sequential in (False, True):
+            out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            err, raw, _ = codec.decode_stream(to_dev(torch, bad), bad.size, bad.size, out, sequential=sequential)
+            assert err == oerr, (i, sequential, err, oerr)
+            if oerr != 1:                                                       # (1 = the buffer is the limit)
+                assert raw == oout.size and np.array_equal(out[:raw].cpu().numpy(), oout), (i, sequential, raw, oout.size)
+
+
 def test_self_synchronisation_worst_cases(torch_mod, codec, oracle):
     """Inputs on which speculative starts do not re-synchronise by themselves: long runs of
     one symbol whose code is longer than a bit, and fixed-length codes."""

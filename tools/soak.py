@@ -1,0 +1,67 @@
+"""Randomised soak of the GPU codec against the oracle (not part of the pytest suite: minutes long).
+usage: python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from libhuffman_amd.codec import GpuCodec
+from oracle.oracle import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+c, o = GpuCodec(0), Oracle()
+t_end = time.time() + budget
+n_cases = n_corrupt = 0
+
+def make_data():
+    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 1500000)]))
+    k = int(rng.choice([1, 2, 3, rng.integers(2, 20), rng.integers(20, 257)]))
+    syms = rng.choice(256, size=k, replace=False)
+    kind = rng.integers(0, 5)
+    if kind == 0: p = np.full(k, 1.0 / k)
+    elif kind == 1: p = rng.dirichlet(np.full(k, 0.3))
+    elif kind == 2: p = 1.0 / np.arange(1, k + 1); p /= p.sum()
+    elif kind == 3: p = 0.5 ** np.arange(1, k + 1); p[-1] += 1 - p.sum()          # very deep codes
+    else: p = rng.dirichlet(np.full(k, 5.0))
+    data = syms[rng.choice(k, size=n, p=p)].astype(np.uint8)
+    if rng.random() < 0.3:                                                          # long runs
+        i = int(rng.integers(0, n)); data[i:i + int(rng.integers(1, n // 2 + 2))] = syms[0]
+    return data
+
+while time.time() < t_end:
+    data = make_data()
+    n = data.size
+    bs = int(rng.choice([0, 64, 257, 4096, 65536, 131072, 1 << 20]))
+    if bs and n // bs > 30000: bs = 4096
+    want, woffs = o.encode(data, bs, with_offsets=True)
+    d = torch.from_numpy(data).cuda()
+    got, offs, _ = c.encode(d, bs)
+    assert np.array_equal(got.cpu().numpy(), want), ("encode", seed, n_cases, n, bs)
+    assert np.array_equal(offs.cpu().numpy().astype(np.uint64), woffs), ("offsets", seed, n_cases)
+    nb = woffs.size - 1
+    back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    raw = c.decode(got, want.size, offs, nb, back, relaxed=True)
+    assert raw == n and np.array_equal(back[:n].cpu().numpy(), data), ("decode", seed, n_cases, n, bs)
+    for sequential in (False, True):
+        back.zero_()
+        err, raw, used = c.decode_stream(got, want.size, want.size, back, relaxed=True, sequential=sequential)
+        assert (err, raw, used) == (0, n, want.size), ("stream", seed, n_cases, sequential, err, raw, used)
+        assert np.array_equal(back[:n].cpu().numpy(), data)
+    n_cases += 1
+    # corruptions: compare error code and delivered bytes with the oracle
+    for _ in range(3):
+        bad = want.copy()
+        how = rng.integers(0, 4)
+        if how == 0: bad[int(rng.integers(0, bad.size))] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1: bad[int(rng.integers(0, bad.size))] = 0xff
+        elif how == 2: bad = bad[: int(rng.integers(1, bad.size + 1))]
+        else: bad = np.concatenate([bad, rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)])
+        oerr, oout, oused = o.decode(bad, n + 70000, 1025)
+        if oerr == 1: continue
+        for sequential in (False, True):
+            err, raw, used = c.decode_stream(torch.from_numpy(bad).cuda(), bad.size, bad.size,
+                                             torch.empty(n + 70000, dtype=torch.uint8, device="cuda"),
+                                             relaxed=True, sequential=sequential)
+            assert err == oerr and raw == oout.size, ("corrupt", seed, n_cases, how, sequential, err, oerr, raw, oout.size)
+        n_corrupt += 1
+print(f"soak ok: {n_cases} cases, {n_corrupt} corruptions, seed {seed}, {budget:.0f} s")

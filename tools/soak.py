@@ -6,6 +6,10 @@ import numpy as np, torch
 from libhuffman_amd.codec import GpuCodec
 from oracle.oracle import Oracle
 
+import ctypes as C
+from libhuffman_amd import _native as N
+from libhuffman_amd import huffmanfile as HF
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
@@ -64,4 +68,32 @@ while time.time() < t_end:
                                              relaxed=True, sequential=sequential)
             assert err == oerr and raw == oout.size, ("corrupt", seed, n_cases, how, sequential, err, oerr, raw, oout.size)
         n_corrupt += 1
+    # the drop-in host API on the same case: huf_encode / huf_decode through memstreams, with the
+    # device-direct copy and with the read()/write() callbacks
+    if n_cases % 4 == 0:
+        L = N.load()
+        L.huf_gpu_set_relaxed_tree(1)
+        for zc in ("1", "0"):
+            os.environ["HUF_GPU_ZERO_COPY"] = zc
+            os.environ["HUF_GPU_BATCH_MB"] = str(int(rng.choice([1, 256])))
+            def run(fn, payload, length, bsz, cap):
+                src = HF._MemStream(max(len(payload), 1)) if zc == "0" or rng.random() < 0.5 else HF._WrappedBytes(payload)
+                if isinstance(src, HF._MemStream): src.write(payload)
+                dst = HF._MemStream(cap)
+                cfg = N.Config(length, bsz, int(rng.choice([0, 7, 4096])), int(rng.choice([0, 5, 65536])), src.handle, dst.handle)
+                err = fn(C.byref(cfg)); outb = dst.getvalue(); src.close(); dst.close()
+                return err, outb
+            err, enc = run(L.huf_encode, data.tobytes(), n, bs, 16)
+            assert err == 0 and enc == want.tobytes(), ("huf_encode", seed, n_cases, zc, err)
+            err, dec = run(L.huf_decode, enc, len(enc), 0, 16)
+            assert err == 0 and dec == data.tobytes(), ("huf_decode", seed, n_cases, zc, err)
+            bad = want.copy(); bad[int(rng.integers(0, bad.size))] ^= 1 << int(rng.integers(0, 8))
+            oerr, oout, _ = o.decode(bad, n + 70000, 1025)
+            if oerr != 1:
+                err, dec = run(L.huf_decode, bad.tobytes(), bad.size, 0, 16)
+                # an unbuffered writer has everything the reference wrote before the error; a buffered
+                # one may hold back less than its buffer (no flush on the error path, decoder.c:278-286)
+                assert err == oerr and dec == oout.tobytes()[: len(dec)] and len(oout) - len(dec) < 65536, (
+                    "huf_decode corrupt", seed, n_cases, zc, err, oerr, len(dec), len(oout))
+        L.huf_gpu_set_relaxed_tree(0)
 print(f"soak ok: {n_cases} cases, {n_corrupt} corruptions, seed {seed}, {budget:.0f} s")

@@ -137,15 +137,27 @@ def main() -> None:
     back = torch.empty(n, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
 
+    pending = []
+
     def step():
         codec.encode(data, bs, out=out, offsets=offs, sync=False)
         if use_dist:
-            # the one real exchange: every rank learns where its stream starts in the job's stream
-            dist.all_gather_into_tensor(sizes, offs[nb:nb + 1])
+            # the one real exchange: every rank learns where its stream starts in the job's stream.
+            # Nothing on this rank's decode depends on it, so it runs on RCCL's stream beside the
+            # decode (it waits for the encode by itself) and is only waited for at the end.
+            if os.environ.get("BENCH_SYNC_GATHER") == "1":          # (A/B switch: the collective in line)
+                dist.all_gather_into_tensor(sizes, offs[nb:nb + 1])
+            else:
+                pending.append(dist.all_gather_into_tensor(sizes, offs[nb:nb + 1], async_op=True))
         codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False)
+
+    def drain():
+        while pending:
+            pending.pop().wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     raw = codec.decode_result() if args.warmup else None
     torch.cuda.synchronize()
     if use_dist:
@@ -160,6 +172,7 @@ def main() -> None:
     for k in range(args.steps):
         codec.set_profiling(k % PROFILE_EVERY == 0, resume=k > 0)
         step()
+    drain()
     ev1.record()
     torch.cuda.synchronize()
     if use_dist:

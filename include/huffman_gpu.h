@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-typedef struct hufgpu_ctx hufgpu_ctx_t;   /* per-device workspace + stream; not thread-safe */
+/* Per-device workspace (side tables, ticket counters, profiling events).  Not thread-safe, and
+ * its calls share that workspace: enqueue them on ONE stream at a time (or wait for the stream
+ * before switching to another); use one context per concurrently used stream. */
+typedef struct hufgpu_ctx hufgpu_ctx_t;
 
 /* Decode flags. */
 #define HUFGPU_STRICT_TREE  0u  /* tree_len > 1024 -> HUF_ERROR_BTREE_OVERFLOW (reference parity,

@@ -742,7 +742,7 @@ __device__ __forceinline__ uint64_t chunked_excl_scan(uint64_t n, uint64_t *__re
  *
  * Ordering inside the producing kernel.  What one wave hands to another (vals, gsum, gmin) is
  * written and read with device-scope atomic stores / loads, which are performed at the coherence
- * point past the per-XCD L2s, and the writer waits for them (s_waitcnt, __threadfence_block)
+ * point past the per-XCD L2s, and the writer waits for them (s_waitcnt vmcnt(0), handover_fence)
  * before it takes its ticket.  A device-scope __threadfence() would be correct too but on gfx950
  * it writes back and invalidates the whole L2 of the XCD: one per block made the fused
  * histogram kernel 6x slower (0.17 -> 1.02 ms per GiB).
@@ -771,6 +771,16 @@ __device__ __forceinline__ uint64_t handover_load(const uint64_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* Every handover store of this wave has been performed (acknowledged at device scope) before
+ * anything that follows is issued - in particular the ticket.  A workgroup-scope fence is NOT
+ * enough: without threadgroup-split mode the compiler lowers it to s_waitcnt lgkmcnt(0) only,
+ * and the ticket (another address, another L2 channel) can then overtake the value it
+ * announces - tools/soak.py caught exactly that as one wrong block index in ~6 000 runs with
+ * thousands of 64-byte blocks. */
+__device__ __forceinline__ void handover_fence()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 /* Scan of the group totals by the wave that completed the last group.  The caller has stored
  * gsum[g] (and gmin[g]) of its group with handover_store(). */
@@ -778,7 +788,7 @@ __device__ __forceinline__ void two_level_finish(const TwoLevel &t, uint64_t ngr
 {
     const int lane = lane_id();
     uint32_t k = 0;
-    __threadfence_block();                           /* the handover stores have been performed */
+    handover_fence();
     if (lane == 0) k = atomicAdd(t.done, 1u);
     k = uni32(k);
     if ((uint64_t)k != ngroups - 1) return;
@@ -813,7 +823,7 @@ __device__ __forceinline__ void two_level_arrive(const TwoLevel &t, uint64_t b, 
     const uint32_t members = (uint32_t)dmin<uint64_t>(SCAN_GROUP, nblocks - g0);
     uint32_t k = 0;
     if (lane == 0) handover_store(t.vals + b, value);
-    __threadfence_block();
+    handover_fence();
     if (lane == 0) k = atomicAdd(&t.gcount[g * SCAN_TICKET_STRIDE], 1u);
     k = uni32(k);
     if (k != members - 1) return;

@@ -339,6 +339,25 @@ def test_block_offsets_across_groups(torch_mod, codec, oracle, nblocks, bs):
         assert np.array_equal(back, data), first_diff(back, data)
 
 
+def test_block_index_alternating_inputs(torch_mod, codec, oracle):
+    """Two inputs of the same shape but different block sizes, encoded alternately: a block size
+    left over from the previous launch (the ticket of the in-kernel prefix sum overtaking the
+    value it announces - tools/stress_encode.py found 3 such launches in 300 000 before the
+    s_waitcnt fix) would show up as a wrong index entry.  A cheap guard, not a proof."""
+    torch = torch_mod
+    rng = np.random.default_rng(99)
+    n, bs = 700 * 64 + 5, 64
+    inputs = []
+    for k in (2, 40):
+        data = rng.integers(0, k, n).astype(np.uint8)
+        want, woffs = oracle.encode(data, bs, with_offsets=True)
+        inputs.append((to_dev(torch, data), to_dev(torch, want), torch.from_numpy(woffs.astype(np.int64)).cuda()))
+    for it in range(1500):
+        d, ws, wo = inputs[it & 1]
+        got, offs, ln = codec.encode(d, bs)
+        assert ln == ws.numel() and torch.equal(offs, wo) and torch.equal(got, ws), it
+
+
 @pytest.mark.parametrize("kind", ["zipf255", "uniform255"])
 def test_payload_walk_leaves_tree_mid_block(torch_mod, codec, oracle, kind):
     """A byte of ones in the payload: some codeword then starts with 1, which leaves an

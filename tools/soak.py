@@ -40,7 +40,17 @@ while time.time() < t_end:
     want, woffs = o.encode(data, bs, with_offsets=True)
     d = torch.from_numpy(data).cuda()
     got, offs, _ = c.encode(d, bs)
-    assert np.array_equal(got.cpu().numpy(), want), ("encode", seed, n_cases, n, bs)
+    gnp = got.cpu().numpy()
+    if not np.array_equal(gnp, want):
+        m = min(gnp.size, want.size)
+        d = int(np.flatnonzero(gnp[:m] != want[:m])[0]) if np.any(gnp[:m] != want[:m]) else m
+        blk = int(np.searchsorted(woffs, d, side="right") - 1)
+        np.save("gpurun_out/soak_fail_data.npy", data)
+        print("ENCODE MISMATCH", dict(seed=seed, case=n_cases, n=n, bs=bs, sizes=(gnp.size, want.size), first_diff=d, block=blk,
+                                      block_off=int(woffs[blk]), goffs=offs.cpu().numpy()[blk:blk + 2].tolist(), woffs=woffs[blk:blk + 2].tolist(),
+                                      got=gnp[d - 4:d + 12].tolist(), want=want[d - 4:d + 12].tolist(),
+                                      block_data=data[blk * max(bs, 1):(blk + 1) * max(bs, 1)].tolist() if bs else None))
+        raise SystemExit(1)
     assert np.array_equal(offs.cpu().numpy().astype(np.uint64), woffs), ("offsets", seed, n_cases)
     nb = woffs.size - 1
     back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")

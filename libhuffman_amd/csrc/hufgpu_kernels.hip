@@ -2486,9 +2486,12 @@ __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *_
 /* result: [0] validated blocks m, [1] offset where the sequential decoder must take over
  * (meaningful when [2] == 0), [2] 1 = the chain reached `length`, [3] bytes consumed then.
  * block_offsets[0..m] receives the validated block index.
- * ONE wavefront: lane 0 follows the chain through an LDS copy of nxt[] (the chain only moves
- * forward, so the copy is refilled chunk by chunk); every loop-control value lives in registers
- * and is broadcast from lane 0 with a shuffle, so no flag is ever polled in memory. */
+ * ONE wavefront follows the chain through an LDS copy of nxt[] (the chain only moves forward, so
+ * the copy is refilled chunk by chunk).  In a stream without false candidates every link is
+ * "the next candidate", so the wave tests 64 links per step and takes the whole run of such
+ * links at once (16 384 blocks: 256 steps instead of 16 384 dependent LDS reads, 2.9 -> 0.1 ms
+ * per GiB); any other link is followed one step at a time.  Every loop-control value is the
+ * same in all lanes (ballots), so no flag is ever polled in memory. */
 #define WALK_CHUNK 8192
 __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ cand,
                                                   const uint64_t *__restrict__ cand_end,
@@ -2497,43 +2500,37 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
                                                   uint64_t *__restrict__ result)
 {
     __shared__ uint32_t s_nxt[WALK_CHUNK];
-    __shared__ uint32_t s_list[WALK_CHUNK];
     const int lane = (int)threadIdx.x;
     uint64_t cur = 0, m = 0, resume = 0, consumed = 0;
     int complete = 0;
     bool stop = (ncand == 0) || (cand[0] != 0);       /* the stream must start with a header */
     while (!stop) {
         const uint64_t base = cur - (cur % WALK_CHUNK);
-        for (uint64_t i = (uint64_t)lane; i < WALK_CHUNK && base + i < ncand; i += 64) s_nxt[i] = nxt[base + i];
+        const uint64_t top = dmin<uint64_t>(base + WALK_CHUNK, ncand);      /* candidates [base, top) are in LDS */
+        for (uint64_t i = (uint64_t)lane; base + i < top; i += 64) s_nxt[i] = nxt[base + i];
         __syncthreads();
-        uint32_t cnt = 0, code = 0;                    /* code: 0 next chunk, 1 bad block, 2 terminal, 3 no header */
-        uint32_t ncur_lo = (uint32_t)cur, ncur_hi = (uint32_t)(cur >> 32);
-        if (lane == 0) {
-            uint64_t c = cur;
-            while (c < base + WALK_CHUNK) {
-                const uint32_t nx = s_nxt[c - base];
-                if (nx == LINK_BAD) { code = 1; break; }
-                s_list[cnt++] = (uint32_t)c;
-                if (nx == LINK_TERMINAL) { code = 2; break; }
-                if (nx == LINK_NOTFOUND) { code = 3; break; }
-                c = nx;                                /* nx > c: the chain only moves forward */
-            }
-            ncur_lo = (uint32_t)c;
-            ncur_hi = (uint32_t)(c >> 32);
+        uint64_t c = cur;
+        while (c < top) {
+            /* the run of plain links that starts at c */
+            const uint64_t idx = c + (uint64_t)lane;
+            const bool plain = idx < top && s_nxt[idx - base] == (uint32_t)(idx + 1);
+            const unsigned long long mask = __ballot(plain);
+            const uint32_t run = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);
+            if ((uint32_t)lane < run) block_offsets[m + (uint64_t)lane] = cand[idx];
+            m += run;
+            c += run;
+            if (run == 64u || c >= top) continue;
+            /* one link of another kind */
+            const uint32_t nx = s_nxt[c - base];
+            if (nx == LINK_BAD) { resume = cand[c]; stop = true; break; }
+            if (lane == 0) block_offsets[m] = cand[c];
+            m++;
+            if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
+            if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
+            c = nx;                                    /* nx > c: the chain only moves forward */
         }
-        cnt = (uint32_t)__shfl((int)cnt, 0);
-        code = (uint32_t)__shfl((int)code, 0);
-        ncur_lo = (uint32_t)__shfl((int)ncur_lo, 0);
-        ncur_hi = (uint32_t)__shfl((int)ncur_hi, 0);
-        const uint64_t ncur = ((uint64_t)ncur_hi << 32) | ncur_lo;
-        __syncthreads();                               /* s_list is complete */
-        for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) block_offsets[m + j] = cand[s_list[j]];
-        m += cnt;
-        if (code == 1) { resume = cand[ncur]; stop = true; }
-        else if (code == 2) { complete = 1; consumed = cand_end[ncur]; stop = true; }
-        else if (code == 3) { resume = cand_end[ncur]; stop = true; }
-        cur = ncur;
-        __syncthreads();                               /* before s_nxt / s_list are reused */
+        cur = c;
+        __syncthreads();                               /* before s_nxt is reused */
     }
     if (lane == 0) {
         result[0] = m;

@@ -55,6 +55,7 @@ struct hufgpu_ctx {
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
     uint32_t *d_wg_counts;
+    uint64_t *d_disc_masks;       /* 64 header-test verdicts per discovery thread */
     uint64_t *d_wg_base;
     uint64_t *d_cand, *d_cand_end, *d_chain;
     int32_t *d_cand_status;
@@ -193,7 +194,7 @@ static void free_encode_ws(hufgpu_ctx *c)
 
 static void free_disc_ws(hufgpu_ctx *c, int which)
 {
-    if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); c->d_wg_counts = NULL; c->d_wg_base = NULL; c->disc_wgs = 0; }
+    if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); (void)hipFree(c->d_disc_masks); c->d_wg_counts = NULL; c->d_wg_base = NULL; c->d_disc_masks = NULL; c->disc_wgs = 0; }
     if (which & 2) {
         (void)hipFree(c->d_cand); (void)hipFree(c->d_cand_end); (void)hipFree(c->d_chain); (void)hipFree(c->d_cand_status); (void)hipFree(c->d_nxt);
         c->d_cand = c->d_cand_end = c->d_chain = NULL; c->d_cand_status = NULL; c->d_nxt = NULL; c->disc_cands = 0;
@@ -556,9 +557,10 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
             const uint64_t cap = nwg + nwg / 8 + 16;
             HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
             HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1) * sizeof(uint64_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_masks, cap * DISC_THREADS * sizeof(uint64_t)));
             ctx->disc_wgs = cap;
         }
-        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL);
+        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
         DISC_TRACE("discover count done");
         scan_counts_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base);
         DISC_TRACE("scan done");
@@ -580,7 +582,7 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
                 HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
                 ctx->disc_cands = cap;
             }
-            discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand);
+            discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks);
             DISC_TRACE("discover write done");
             probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status);
             DISC_TRACE("probe done");

@@ -2365,7 +2365,8 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
  * ==================================================================================== */
 #define DISC_THREADS 256
 #define DISC_PER 16
-#define DISC_CHUNK (DISC_THREADS * DISC_PER)
+#define DISC_ITERS 4
+#define DISC_CHUNK (DISC_THREADS * DISC_PER * DISC_ITERS)
 #define LINK_BAD      0xfffffffdu
 #define LINK_TERMINAL 0xfffffffeu
 #define LINK_NOTFOUND 0xffffffffu
@@ -2388,45 +2389,76 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                                                                 uint64_t scan_len, int max_tree_len,
                                                                 uint32_t *__restrict__ wg_counts,
                                                                 const uint64_t *__restrict__ wg_base,
-                                                                uint64_t *__restrict__ cand)
+                                                                uint64_t *__restrict__ cand,
+                                                                uint64_t *__restrict__ masks)
 {
+    /* A thread owns DISC_ITERS consecutive 16-byte pieces (thread order = stream order, one scan
+     * per workgroup of 16 KiB: with 4 KiB workgroups the kernel was bound by their dispatch). */
     __shared__ uint32_t s_part[DISC_THREADS / 64];
-    const uint64_t p0 = (uint64_t)blockIdx.x * DISC_CHUNK + (uint64_t)threadIdx.x * DISC_PER;
-    uint32_t mask = 0;
-    if (p0 < scan_len) {
-        uint32_t w[8];
-        const uint4 a = *reinterpret_cast<const uint4 *>(stream + p0);          /* 16-byte unit that holds a valid byte */
-        uint4 b = make_uint4(0u, 0u, 0u, 0u);
-        if (p0 + 16 < avail) b = *reinterpret_cast<const uint4 *>(stream + p0 + 16);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    const uint64_t t0 = (uint64_t)blockIdx.x * DISC_CHUNK + (uint64_t)threadIdx.x * (DISC_PER * DISC_ITERS);
+    const uint64_t slot = (uint64_t)blockIdx.x * DISC_THREADS + threadIdx.x;
+    uint64_t mask = 0;
+    /* the counting pass leaves its 64 verdicts per thread for the writing pass, which then reads
+     * 1/8 of the stream's size instead of testing the whole stream again */
+    if (WRITE) mask = masks[slot];
+    else if (t0 < scan_len) {
+        uint4 b = *reinterpret_cast<const uint4 *>(stream + t0);               /* 16-byte unit that holds a valid byte */
 #pragma unroll
-        for (int k = 0; k < DISC_PER; k++) {
-            const uint64_t p = p0 + k;
-            /* little-endian fields at byte k of the window */
-            const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
-            if (hi != 0 || p >= scan_len || avail - p < HUF_HEADER_FIXED) continue;   /* block_len < 2^32 */
-            const uint32_t lo = __funnelshift_r(w[k >> 2], w[(k >> 2) + 1], 8 * (k & 3));
-            if (lo == 0) continue;
-            const uint32_t t16 = __funnelshift_r(w[(k + 8) >> 2], w[((k + 8) >> 2) + 1], 8 * ((k + 8) & 3)) & 0xffffu;
-            const int tl = (int)(int16_t)t16;
-            if (tl < 1 || tl > max_tree_len) continue;
-            const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
-            if (hdr_end > avail) continue;
-            if ((uint64_t)lo > (avail - hdr_end) * 8ull) continue;               /* every symbol costs a bit */
-            if (!tree_grammar_complete(stream + p + HUF_HEADER_FIXED, tl)) continue;
-            mask |= 1u << k;
+        for (int it = 0; it < DISC_ITERS; it++) {
+            const uint64_t p0 = t0 + (uint64_t)(it * DISC_PER);
+            if (p0 >= scan_len) break;
+            const uint4 a = b;
+            b = make_uint4(0u, 0u, 0u, 0u);
+            if (p0 + 16 < avail) b = *reinterpret_cast<const uint4 *>(stream + p0 + 16);
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            /* almost no offset survives "the upper half of block_len is zero": that test is done
+             * for all 16 offsets without a branch, everything else only for the survivors */
+            uint32_t maybe = 0;
+#pragma unroll
+            for (int k = 0; k < DISC_PER; k++) {
+                const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
+                maybe |= (hi == 0u ? 1u : 0u) << k;                              /* block_len < 2^32 */
+            }
+            if (maybe) {                                    /* runs of zero bytes pass the first test everywhere: */
+                uint32_t nz = 0;                            /* block_len != 0, again for all offsets at once */
+#pragma unroll
+                for (int k = 0; k < DISC_PER; k++) {
+                    const uint32_t lo = __funnelshift_r(w[k >> 2], w[(k >> 2) + 1], 8 * (k & 3));
+                    nz |= (lo != 0u ? 1u : 0u) << k;
+                }
+                maybe &= nz;
+            }
+            while (maybe) {
+                const int k = __builtin_ctz(maybe);
+                maybe &= maybe - 1;
+                const uint64_t p = p0 + (uint64_t)k;
+                if (p >= scan_len || avail - p < HUF_HEADER_FIXED) continue;
+                /* (survivors are rare: their fields are read from memory, not picked out of the
+                 * register window with a run-time index) */
+                const uint8_t *h = stream + p;
+                const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
+                if (lo == 0) continue;
+                const int tl = (int)(int16_t)((uint16_t)h[8] | ((uint16_t)h[9] << 8));
+                if (tl < 1 || tl > max_tree_len) continue;
+                const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+                if (hdr_end > avail) continue;
+                if ((uint64_t)lo > (avail - hdr_end) * 8ull) continue;           /* every symbol costs a bit */
+                if (!tree_grammar_complete(stream + p + HUF_HEADER_FIXED, tl)) continue;
+                mask |= 1ull << (it * DISC_PER + k);
+            }
         }
     }
     uint32_t total;
-    const uint32_t ex = block_excl_scan<DISC_THREADS, uint32_t>((uint32_t)__popc(mask), s_part, total);
+    const uint32_t ex = block_excl_scan<DISC_THREADS, uint32_t>((uint32_t)__popcll(mask), s_part, total);
     if (!WRITE) {
+        masks[slot] = mask;
         if (threadIdx.x == 0) wg_counts[blockIdx.x] = total;
     } else {
         uint64_t at = wg_base[blockIdx.x] + ex;
         while (mask) {
-            const int k = __builtin_ctz(mask);
+            const int k = __builtin_ctzll(mask);
             mask &= mask - 1;
-            cand[at++] = p0 + (uint64_t)k;
+            cand[at++] = t0 + (uint64_t)k;
         }
     }
 }

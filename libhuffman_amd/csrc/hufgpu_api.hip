@@ -60,7 +60,8 @@ struct hufgpu_ctx {
     uint64_t *d_cand, *d_cand_end, *d_chain;
     int32_t *d_cand_status;
     uint32_t *d_nxt;
-    uint64_t *d_walk;             /* 4 result words of walk_kernel */
+    uint64_t *d_walk;             /* 5 result words of walk_kernel */
+    uint64_t *d_spec_off;         /* speculative output offsets of the candidates (disc_cands + 1) */
 
     uint64_t *d_result;           /* 4 words: err, raw_len, failing block, spare */
     uint64_t *h_result;           /* pinned mirror */
@@ -163,8 +164,8 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     HIP_OK(NULL, hipSetDevice(device));
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
-    HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 4 * sizeof(uint64_t)));
-    HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 4 * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 8 * sizeof(uint64_t)));
+    HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t), hipHostMallocDefault));
 
     /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
     uint64_t cum[255], acc = 0;
@@ -196,8 +197,8 @@ static void free_disc_ws(hufgpu_ctx *c, int which)
 {
     if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); (void)hipFree(c->d_disc_masks); c->d_wg_counts = NULL; c->d_wg_base = NULL; c->d_disc_masks = NULL; c->disc_wgs = 0; }
     if (which & 2) {
-        (void)hipFree(c->d_cand); (void)hipFree(c->d_cand_end); (void)hipFree(c->d_chain); (void)hipFree(c->d_cand_status); (void)hipFree(c->d_nxt);
-        c->d_cand = c->d_cand_end = c->d_chain = NULL; c->d_cand_status = NULL; c->d_nxt = NULL; c->disc_cands = 0;
+        (void)hipFree(c->d_cand); (void)hipFree(c->d_cand_end); (void)hipFree(c->d_chain); (void)hipFree(c->d_cand_status); (void)hipFree(c->d_nxt); (void)hipFree(c->d_spec_off);
+        c->d_cand = c->d_cand_end = c->d_chain = NULL; c->d_cand_status = NULL; c->d_nxt = NULL; c->d_spec_off = NULL; c->disc_cands = 0;
     }
 }
 
@@ -580,23 +581,28 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
                 HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
                 HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
                 HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
                 ctx->disc_cands = cap;
             }
             discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks);
             DISC_TRACE("discover write done");
-            probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status);
+            cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(st, ctx->d_cand, ncand, ctx->d_spec_off);
+            probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap);
             DISC_TRACE("probe done");
             link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
             DISC_TRACE("link done");
-            walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk);
+            walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
             DISC_TRACE("walk done");
             HIP_OK(ctx, hipGetLastError());
-            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIP_OK(ctx, hipStreamSynchronize(s));
             const uint64_t m = ctx->h_result[0];
+            const uint64_t in_place = ctx->h_result[4];   /* bytes the probe already decoded into `out` for these m blocks */
             complete = ctx->h_result[2] != 0;
             resume = complete ? ctx->h_result[3] : ctx->h_result[1];
-            if (m > 0) {
+            if (m > 0 && in_place != ~0ull) {
+                prefix_raw = in_place;                 /* every candidate was a block: nothing to decode again */
+            } else if (m > 0) {
                 err = hufgpu_decode(ctx, st, resume, ctx->d_chain, m, out, out_cap, flags, &prefix_raw, stream);
                 if (err != HUFE_OK) {                  /* cannot happen for probed blocks except for lack of room */
                     if (err == HUFE_MEMORY) { if (raw_len) *raw_len = prefix_raw; return err; }

@@ -2471,12 +2471,30 @@ __global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__
     if (threadIdx.x == 0) base[n] = total;
 }
 
-/* Count-only decode of one candidate: where does its payload end, and does it decode at all? */
+/* Where the output of candidate i would start if every candidate were a block of the stream, in
+ * order: the exclusive prefix sum of the block_len fields (ONE workgroup; spec_off[ncand] = sum). */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint8_t *__restrict__ stream,
+                                                            const uint64_t *__restrict__ cand, uint64_t ncand,
+                                                            uint64_t *__restrict__ spec_off)
+{
+    const uint64_t total = chunked_excl_scan<THREADS>(ncand, spec_off, [=](uint64_t i) {
+        return load_u64_unaligned(stream + cand[i]);
+    });
+    if (threadIdx.x == 0) spec_off[ncand] = total;
+}
+
+/* Decode of one candidate: where does its payload end, and does it decode at all?  Count-only,
+ * unless all candidates together fit the output (spec_off[ncand] <= out_cap): then the symbols
+ * are written where they belong if every candidate is a real block - the usual case, in which the
+ * chain walk afterwards confirms exactly that and nothing has to be decoded twice. */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void probe_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
                                                         const uint64_t *__restrict__ cand,
                                                         uint64_t *__restrict__ cand_end,
-                                                        int32_t *__restrict__ cand_status)
+                                                        int32_t *__restrict__ cand_status,
+                                                        const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
+                                                        uint64_t out_cap)
 {
     __shared__ DecShared<THREADS> sh;
     const uint64_t c = cand[blockIdx.x];
@@ -2484,8 +2502,13 @@ __global__ __launch_bounds__(THREADS) void probe_kernel(const uint8_t *__restric
     const int tl = (int)(int16_t)((uint16_t)stream[c + 8] | ((uint16_t)stream[c + 9] << 8));
     const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
     uint64_t end_bits = 0, produced = 0;
-    const int err = decode_block<THREADS, false>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
-                                                 nullptr, &end_bits, &produced);
+    int err;
+    if (spec_off[gridDim.x] <= out_cap)
+        err = decode_block<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                          out + spec_off[blockIdx.x], &end_bits, &produced);
+    else
+        err = decode_block<THREADS, false>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                           nullptr, &end_bits, &produced);
     if (threadIdx.x == 0) {
         cand_status[blockIdx.x] = err;
         cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
@@ -2516,7 +2539,8 @@ __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *_
 }
 
 /* result: [0] validated blocks m, [1] offset where the sequential decoder must take over
- * (meaningful when [2] == 0), [2] 1 = the chain reached `length`, [3] bytes consumed then.
+ * (meaningful when [2] == 0), [2] 1 = the chain reached `length`, [3] bytes consumed then,
+ * [4] see below.
  * block_offsets[0..m] receives the validated block index.
  * ONE wavefront follows the chain through an LDS copy of nxt[] (the chain only moves forward, so
  * the copy is refilled chunk by chunk).  In a stream without false candidates every link is
@@ -2529,12 +2553,14 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
                                                   const uint64_t *__restrict__ cand_end,
                                                   const uint32_t *__restrict__ nxt, uint64_t ncand,
                                                   uint64_t *__restrict__ block_offsets,
-                                                  uint64_t *__restrict__ result)
+                                                  uint64_t *__restrict__ result,
+                                                  const uint64_t *__restrict__ spec_off, uint64_t out_cap)
 {
     __shared__ uint32_t s_nxt[WALK_CHUNK];
     const int lane = (int)threadIdx.x;
     uint64_t cur = 0, m = 0, resume = 0, consumed = 0;
     int complete = 0;
+    bool contiguous = true;       /* validated block j is candidate j, for every j so far */
     bool stop = (ncand == 0) || (cand[0] != 0);       /* the stream must start with a header */
     while (!stop) {
         const uint64_t base = cur - (cur % WALK_CHUNK);
@@ -2549,6 +2575,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
             const unsigned long long mask = __ballot(plain);
             const uint32_t run = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);
             if ((uint32_t)lane < run) block_offsets[m + (uint64_t)lane] = cand[idx];
+            if (run && c != m) contiguous = false;
             m += run;
             c += run;
             if (run == 64u || c >= top) continue;
@@ -2556,6 +2583,7 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
             const uint32_t nx = s_nxt[c - base];
             if (nx == LINK_BAD) { resume = cand[c]; stop = true; break; }
             if (lane == 0) block_offsets[m] = cand[c];
+            if (c != m) contiguous = false;
             m++;
             if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
             if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
@@ -2569,6 +2597,8 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
         result[1] = resume;
         result[2] = (uint64_t)complete;
         result[3] = consumed;
+        /* [4]: bytes the probe already put in place for the validated blocks (~0 = it did not) */
+        result[4] = (contiguous && spec_off[ncand] <= out_cap) ? spec_off[m] : ~0ull;
         block_offsets[m] = complete ? consumed : resume;   /* end of the validated prefix */
     }
 }

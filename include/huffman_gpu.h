@@ -100,10 +100,11 @@ int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
  * Decode a raw stream (no index): `avail` bytes are readable at d_stream, `length` compressed
  * bytes drive the block loop exactly like config->length in src/decoder.c:218.  Block
  * boundaries are discovered on the device: every byte offset is tested for a valid header,
- * every candidate is decoded in count-only mode to find its end, the chain from offset 0 is
- * followed, the validated blocks are decoded in parallel and anything else (errors, odd
- * headers, tails) goes to an exact in-order decoder - results, errors and byte counts are those
- * of the reference in every case.  Synchronous.
+ * every candidate is decoded to find its end (straight into d_out when all candidates together
+ * fit it), the chain from offset 0 is followed, blocks that are not in place yet are decoded in
+ * parallel and anything else (errors, odd headers, tails) goes to an exact in-order decoder -
+ * results, errors and byte counts are those of the reference in every case.  Synchronous.
+ * *raw_len bytes of d_out are the result; what lies behind them in d_out is unspecified.
  */
 int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                          void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,

@@ -2402,14 +2402,19 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
      * 1/8 of the stream's size instead of testing the whole stream again */
     if (WRITE) mask = masks[slot];
     else if (t0 < scan_len) {
-        uint4 b = *reinterpret_cast<const uint4 *>(stream + t0);               /* 16-byte unit that holds a valid byte */
+        /* all five loads of the thread are issued before the first use (one memory round trip) */
+        uint4 v[DISC_ITERS + 1];
+        v[0] = *reinterpret_cast<const uint4 *>(stream + t0);                  /* 16-byte unit that holds a valid byte */
+#pragma unroll
+        for (int it = 1; it <= DISC_ITERS; it++) {
+            v[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (t0 + (uint64_t)(it * DISC_PER) < avail) v[it] = *reinterpret_cast<const uint4 *>(stream + t0 + it * DISC_PER);
+        }
 #pragma unroll
         for (int it = 0; it < DISC_ITERS; it++) {
             const uint64_t p0 = t0 + (uint64_t)(it * DISC_PER);
             if (p0 >= scan_len) break;
-            const uint4 a = b;
-            b = make_uint4(0u, 0u, 0u, 0u);
-            if (p0 + 16 < avail) b = *reinterpret_cast<const uint4 *>(stream + p0 + 16);
+            const uint4 a = v[it], b = v[it + 1];
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             /* almost no offset survives "the upper half of block_len is zero": that test is done
              * for all 16 offsets without a branch, everything else only for the survivors */

@@ -2384,6 +2384,30 @@ __device__ __forceinline__ bool tree_grammar_complete(const uint8_t *t, int tl)
 
 /* stream must be 16-byte aligned.  WRITE = false: per-workgroup candidate counts;
  * WRITE = true: candidates written in ascending order at wg_base[workgroup]. */
+/* The same test by a whole wavefront (all 64 lanes call it with the same arguments): 64 entries
+ * per step, open-slot counts by a wave prefix sum.  A lane walking the up to 1 025 entries alone
+ * is ~1 000 pairs of dependent byte loads (~0.5 ms), and every real header costs one such walk. */
+__device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl)
+{
+    const int lane = lane_id();
+    int open = 1;                                                /* child slots still to be filled */
+    bool bad = false;
+    for (int base = 0; base < tl; base += 64) {                  /* uniform */
+        const int i = base + lane;
+        int d = 0;
+        if (i < tl) d = (((uint32_t)t[2 * i] | ((uint32_t)t[2 * i + 1] << 8)) != 0xffffu) ? 1 : -1;
+        int inc = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (i < tl && open + inc - d <= 0) bad = true;           /* an entry behind a complete tree */
+        open += __shfl(inc, 63);
+    }
+    return __ballot(bad) == 0ull && open == 0;
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
                                                                 uint64_t scan_len, int max_tree_len,
@@ -2413,8 +2437,7 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
 #pragma unroll
         for (int it = 0; it < DISC_ITERS; it++) {
             const uint64_t p0 = t0 + (uint64_t)(it * DISC_PER);
-            if (p0 >= scan_len) break;
-            const uint4 a = v[it], b = v[it + 1];
+            const uint4 a = v[it], b = v[it + 1];              /* zeros behind the data: no survivors there */
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             /* almost no offset survives "the upper half of block_len is zero": that test is done
              * for all 16 offsets without a branch, everything else only for the survivors */
@@ -2433,23 +2456,36 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                 }
                 maybe &= nz;
             }
-            while (maybe) {
-                const int k = __builtin_ctz(maybe);
-                maybe &= maybe - 1;
-                const uint64_t p = p0 + (uint64_t)k;
-                if (p >= scan_len || avail - p < HUF_HEADER_FIXED) continue;
-                /* (survivors are rare: their fields are read from memory, not picked out of the
-                 * register window with a run-time index) */
-                const uint8_t *h = stream + p;
-                const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
-                if (lo == 0) continue;
-                const int tl = (int)(int16_t)((uint16_t)h[8] | ((uint16_t)h[9] << 8));
-                if (tl < 1 || tl > max_tree_len) continue;
-                const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
-                if (hdr_end > avail) continue;
-                if ((uint64_t)lo > (avail - hdr_end) * 8ull) continue;           /* every symbol costs a bit */
-                if (!tree_grammar_complete(stream + p + HUF_HEADER_FIXED, tl)) continue;
-                mask |= 1ull << (it * DISC_PER + k);
+            if (p0 >= scan_len) maybe = 0;
+            /* survivors (rare): the lane checks the header fields of its next one, then the wave
+             * checks the tree grammar of every lane's survivor together, one after the other */
+            while (__ballot(maybe != 0u) != 0ull) {
+                int k = 0, tl = 0;
+                uint64_t p = 0;
+                bool pre = false;
+                if (maybe) {
+                    k = __builtin_ctz(maybe);
+                    maybe &= maybe - 1;
+                    p = p0 + (uint64_t)k;
+                    if (p < scan_len && avail - p >= HUF_HEADER_FIXED) {
+                        const uint8_t *h = stream + p;
+                        const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
+                        tl = (int)(int16_t)((uint16_t)h[8] | ((uint16_t)h[9] << 8));
+                        if (lo != 0 && tl >= 1 && tl <= max_tree_len) {
+                            const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+                            pre = hdr_end <= avail && (uint64_t)lo <= (avail - hdr_end) * 8ull;   /* every symbol costs a bit */
+                        }
+                    }
+                }
+                unsigned long long pend = __ballot(pre);
+                while (pend) {
+                    const int src = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    const uint64_t sp = uni64((uint64_t)__shfl((unsigned long long)p, src));
+                    const int stl = (int)uni32((uint32_t)__shfl(tl, src));
+                    const bool ok = tree_grammar_complete_wave(stream + sp + HUF_HEADER_FIXED, stl);
+                    if (ok && lane_id() == src) mask |= 1ull << (it * DISC_PER + k);
+                }
             }
         }
     }

@@ -2,8 +2,9 @@
 
 ``GpuCodec`` works on torch uint8 tensors that already live in HBM: torch is used for device
 memory and streams only, every byte of codec work happens in the HIP kernels of
-``csrc/hufgpu_kernels.hip`` through the C ABI.  There is no eager/CPU path: constructing a
-codec without a usable MI355X raises ``HuffmanGpuError``.
+``csrc/kernels/*.hpp`` (one translation unit, ``csrc/hufgpu_kernels.hip``) through the C ABI.
+There is no eager/CPU path: constructing a codec without a usable MI355X raises
+``HuffmanGpuError``.
 """
 from __future__ import annotations
 

@@ -1,0 +1,311 @@
+/* discover.hpp - raw-stream block discovery: discover / probe / link / walk kernels.
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "decode.hpp"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * Raw-stream block discovery (SURVEY §7.3-A option 2, §8f-2).
+ *
+ * The wire format stores no payload length, so the header of block i+1 is only found by
+ * decoding block i.  To break that chain without changing any result:
+ *   1. discover_kernel tests EVERY byte offset for a syntactically valid header
+ *      (block_len in range, tree_len in [1, max], a preorder tree that consumes exactly tree_len
+ *      entries, enough bytes left) - every real header passes, almost nothing else does;
+ *   2. probe_kernel decodes every candidate in count-only mode (decode_block<.., false>), which
+ *      yields the offset right behind its payload;
+ *   3. link_kernel / walk_kernel follow the chain offset 0 -> end(0) -> ... through the sorted
+ *      candidates; a false candidate can never be entered, because a real block's end is the
+ *      next real header;
+ *   4. the validated prefix is decoded by the indexed kernels; whatever the walk could not
+ *      validate (an erroring block, a header the strict test rejects, trailing garbage) is left
+ *      to decode_chain_kernel, the exact sequential restatement - so errors, partial output and
+ *      consumed-byte counts are those of src/decoder.c in every case.
+ * ==================================================================================== */
+#define DISC_THREADS 256
+#define DISC_PER 16
+#define DISC_ITERS 4
+#define DISC_CHUNK (DISC_THREADS * DISC_PER * DISC_ITERS)
+#define LINK_BAD      0xfffffffdu
+#define LINK_TERMINAL 0xfffffffeu
+#define LINK_NOTFOUND 0xffffffffu
+
+__device__ __forceinline__ bool tree_grammar_complete(const uint8_t *t, int tl)
+{
+    int open = 1;                               /* child slots still to be filled */
+    for (int i = 0; i < tl; i++) {
+        if (open == 0) return false;            /* entries behind a complete tree */
+        const int16_t v = (int16_t)((uint16_t)t[2 * i] | ((uint16_t)t[2 * i + 1] << 8));
+        open += (v != -1) ? 1 : -1;
+    }
+    return open == 0;
+}
+
+/* stream must be 16-byte aligned.  WRITE = false: per-workgroup candidate counts;
+ * WRITE = true: candidates written in ascending order at wg_base[workgroup]. */
+/* The same test by a whole wavefront (all 64 lanes call it with the same arguments): 64 entries
+ * per step, open-slot counts by a wave prefix sum.  A lane walking the up to 1 025 entries alone
+ * is ~1 000 pairs of dependent byte loads (~0.5 ms), and every real header costs one such walk. */
+__device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl)
+{
+    const int lane = lane_id();
+    int open = 1;                                                /* child slots still to be filled */
+    bool bad = false;
+    for (int base = 0; base < tl; base += 64) {                  /* uniform */
+        const int i = base + lane;
+        int d = 0;
+        if (i < tl) d = (((uint32_t)t[2 * i] | ((uint32_t)t[2 * i + 1] << 8)) != 0xffffu) ? 1 : -1;
+        int inc = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (i < tl && open + inc - d <= 0) bad = true;           /* an entry behind a complete tree */
+        open += __shfl(inc, 63);
+    }
+    return __ballot(bad) == 0ull && open == 0;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
+                                                                uint64_t scan_len, int max_tree_len,
+                                                                uint32_t *__restrict__ wg_counts,
+                                                                const uint64_t *__restrict__ wg_base,
+                                                                uint64_t *__restrict__ cand,
+                                                                uint64_t *__restrict__ masks)
+{
+    /* A thread owns DISC_ITERS consecutive 16-byte pieces (thread order = stream order, one scan
+     * per workgroup of 16 KiB: with 4 KiB workgroups the kernel was bound by their dispatch). */
+    __shared__ uint32_t s_part[DISC_THREADS / 64];
+    const uint64_t t0 = (uint64_t)blockIdx.x * DISC_CHUNK + (uint64_t)threadIdx.x * (DISC_PER * DISC_ITERS);
+    const uint64_t slot = (uint64_t)blockIdx.x * DISC_THREADS + threadIdx.x;
+    uint64_t mask = 0;
+    /* the counting pass leaves its 64 verdicts per thread for the writing pass, which then reads
+     * 1/8 of the stream's size instead of testing the whole stream again */
+    if (WRITE) mask = masks[slot];
+    else if (t0 < scan_len) {
+        /* all five loads of the thread are issued before the first use (one memory round trip) */
+        uint4 v[DISC_ITERS + 1];
+        v[0] = *reinterpret_cast<const uint4 *>(stream + t0);                  /* 16-byte unit that holds a valid byte */
+#pragma unroll
+        for (int it = 1; it <= DISC_ITERS; it++) {
+            v[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (t0 + (uint64_t)(it * DISC_PER) < avail) v[it] = *reinterpret_cast<const uint4 *>(stream + t0 + it * DISC_PER);
+        }
+#pragma unroll
+        for (int it = 0; it < DISC_ITERS; it++) {
+            const uint64_t p0 = t0 + (uint64_t)(it * DISC_PER);
+            const uint4 a = v[it], b = v[it + 1];              /* zeros behind the data: no survivors there */
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            /* almost no offset survives "the upper half of block_len is zero": that test is done
+             * for all 16 offsets without a branch, everything else only for the survivors */
+            uint32_t maybe = 0;
+#pragma unroll
+            for (int k = 0; k < DISC_PER; k++) {
+                const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
+                maybe |= (hi == 0u ? 1u : 0u) << k;                              /* block_len < 2^32 */
+            }
+            if (maybe) {                                    /* runs of zero bytes pass the first test everywhere: */
+                uint32_t nz = 0;                            /* block_len != 0, again for all offsets at once */
+#pragma unroll
+                for (int k = 0; k < DISC_PER; k++) {
+                    const uint32_t lo = __funnelshift_r(w[k >> 2], w[(k >> 2) + 1], 8 * (k & 3));
+                    nz |= (lo != 0u ? 1u : 0u) << k;
+                }
+                maybe &= nz;
+            }
+            if (p0 >= scan_len) maybe = 0;
+            /* survivors (rare): the lane checks the header fields of its next one, then the wave
+             * checks the tree grammar of every lane's survivor together, one after the other */
+            while (__ballot(maybe != 0u) != 0ull) {
+                int k = 0, tl = 0;
+                uint64_t p = 0;
+                bool pre = false;
+                if (maybe) {
+                    k = __builtin_ctz(maybe);
+                    maybe &= maybe - 1;
+                    p = p0 + (uint64_t)k;
+                    if (p < scan_len && avail - p >= HUF_HEADER_FIXED) {
+                        const uint8_t *h = stream + p;
+                        const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
+                        tl = (int)(int16_t)((uint16_t)h[8] | ((uint16_t)h[9] << 8));
+                        if (lo != 0 && tl >= 1 && tl <= max_tree_len) {
+                            const uint64_t hdr_end = p + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+                            pre = hdr_end <= avail && (uint64_t)lo <= (avail - hdr_end) * 8ull;   /* every symbol costs a bit */
+                        }
+                    }
+                }
+                unsigned long long pend = __ballot(pre);
+                while (pend) {
+                    const int src = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    const uint64_t sp = uni64((uint64_t)__shfl((unsigned long long)p, src));
+                    const int stl = (int)uni32((uint32_t)__shfl(tl, src));
+                    const bool ok = tree_grammar_complete_wave(stream + sp + HUF_HEADER_FIXED, stl);
+                    if (ok && lane_id() == src) mask |= 1ull << (it * DISC_PER + k);
+                }
+            }
+        }
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<DISC_THREADS, uint32_t>((uint32_t)__popcll(mask), s_part, total);
+    if (!WRITE) {
+        masks[slot] = mask;
+        if (threadIdx.x == 0) wg_counts[blockIdx.x] = total;
+    } else {
+        uint64_t at = wg_base[blockIdx.x] + ex;
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            cand[at++] = t0 + (uint64_t)k;
+        }
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                              uint64_t *__restrict__ base)
+{
+    const uint64_t total = chunked_excl_scan<THREADS>(n, base, [counts](uint64_t i) { return (uint64_t)counts[i]; });
+    if (threadIdx.x == 0) base[n] = total;
+}
+
+/* Where the output of candidate i would start if every candidate were a block of the stream, in
+ * order: the exclusive prefix sum of the block_len fields (ONE workgroup; spec_off[ncand] = sum). */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint8_t *__restrict__ stream,
+                                                            const uint64_t *__restrict__ cand, uint64_t ncand,
+                                                            uint64_t *__restrict__ spec_off)
+{
+    const uint64_t total = chunked_excl_scan<THREADS>(ncand, spec_off, [=](uint64_t i) {
+        return load_u64_unaligned(stream + cand[i]);
+    });
+    if (threadIdx.x == 0) spec_off[ncand] = total;
+}
+
+/* Decode of one candidate: where does its payload end, and does it decode at all?  Count-only,
+ * unless all candidates together fit the output (spec_off[ncand] <= out_cap): then the symbols
+ * are written where they belong if every candidate is a real block - the usual case, in which the
+ * chain walk afterwards confirms exactly that and nothing has to be decoded twice. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void probe_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
+                                                        const uint64_t *__restrict__ cand,
+                                                        uint64_t *__restrict__ cand_end,
+                                                        int32_t *__restrict__ cand_status,
+                                                        const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
+                                                        uint64_t out_cap)
+{
+    __shared__ DecShared<THREADS> sh;
+    const uint64_t c = cand[blockIdx.x];
+    const uint64_t block_len = load_u64_unaligned(stream + c);
+    const int tl = (int)(int16_t)((uint16_t)stream[c + 8] | ((uint16_t)stream[c + 9] << 8));
+    const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+    uint64_t end_bits = 0, produced = 0;
+    int err;
+    if (spec_off[gridDim.x] <= out_cap)
+        err = decode_block<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                          out + spec_off[blockIdx.x], &end_bits, &produced);
+    else
+        err = decode_block<THREADS, false>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                           nullptr, &end_bits, &produced);
+    if (threadIdx.x == 0) {
+        cand_status[blockIdx.x] = err;
+        cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
+    }
+}
+
+__global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *__restrict__ cand_end,
+                            const int32_t *__restrict__ cand_status, uint64_t ncand, uint64_t length,
+                            uint32_t *__restrict__ nxt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand) return;
+    uint32_t r;
+    if (cand_status[i] != HUFE_OK) r = LINK_BAD;
+    else {
+        const uint64_t e = cand_end[i];
+        if (e >= length) r = LINK_TERMINAL;                      /* src/decoder.c:218 loop condition */
+        else {
+            uint64_t lo = i + 1, hi = ncand;                     /* first candidate with offset >= e */
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (cand[mid] < e) lo = mid + 1; else hi = mid;
+            }
+            r = (lo < ncand && cand[lo] == e) ? (uint32_t)lo : LINK_NOTFOUND;
+        }
+    }
+    nxt[i] = r;
+}
+
+/* result: [0] validated blocks m, [1] offset where the sequential decoder must take over
+ * (meaningful when [2] == 0), [2] 1 = the chain reached `length`, [3] bytes consumed then,
+ * [4] see below.
+ * block_offsets[0..m] receives the validated block index.
+ * ONE wavefront follows the chain through an LDS copy of nxt[] (the chain only moves forward, so
+ * the copy is refilled chunk by chunk).  In a stream without false candidates every link is
+ * "the next candidate", so the wave tests 64 links per step and takes the whole run of such
+ * links at once (16 384 blocks: 256 steps instead of 16 384 dependent LDS reads, 2.9 -> 0.1 ms
+ * per GiB); any other link is followed one step at a time.  Every loop-control value is the
+ * same in all lanes (ballots), so no flag is ever polled in memory. */
+#define WALK_CHUNK 8192
+__global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ cand,
+                                                  const uint64_t *__restrict__ cand_end,
+                                                  const uint32_t *__restrict__ nxt, uint64_t ncand,
+                                                  uint64_t *__restrict__ block_offsets,
+                                                  uint64_t *__restrict__ result,
+                                                  const uint64_t *__restrict__ spec_off, uint64_t out_cap)
+{
+    __shared__ uint32_t s_nxt[WALK_CHUNK];
+    const int lane = (int)threadIdx.x;
+    uint64_t cur = 0, m = 0, resume = 0, consumed = 0;
+    int complete = 0;
+    bool contiguous = true;       /* validated block j is candidate j, for every j so far */
+    bool stop = (ncand == 0) || (cand[0] != 0);       /* the stream must start with a header */
+    while (!stop) {
+        const uint64_t base = cur - (cur % WALK_CHUNK);
+        const uint64_t top = dmin<uint64_t>(base + WALK_CHUNK, ncand);      /* candidates [base, top) are in LDS */
+        for (uint64_t i = (uint64_t)lane; base + i < top; i += 64) s_nxt[i] = nxt[base + i];
+        __syncthreads();
+        uint64_t c = cur;
+        while (c < top) {
+            /* the run of plain links that starts at c */
+            const uint64_t idx = c + (uint64_t)lane;
+            const bool plain = idx < top && s_nxt[idx - base] == (uint32_t)(idx + 1);
+            const unsigned long long mask = __ballot(plain);
+            const uint32_t run = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);
+            if ((uint32_t)lane < run) block_offsets[m + (uint64_t)lane] = cand[idx];
+            if (run && c != m) contiguous = false;
+            m += run;
+            c += run;
+            if (run == 64u || c >= top) continue;
+            /* one link of another kind */
+            const uint32_t nx = s_nxt[c - base];
+            if (nx == LINK_BAD) { resume = cand[c]; stop = true; break; }
+            if (lane == 0) block_offsets[m] = cand[c];
+            if (c != m) contiguous = false;
+            m++;
+            if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
+            if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
+            c = nx;                                    /* nx > c: the chain only moves forward */
+        }
+        cur = c;
+        __syncthreads();                               /* before s_nxt is reused */
+    }
+    if (lane == 0) {
+        result[0] = m;
+        result[1] = resume;
+        result[2] = (uint64_t)complete;
+        result[3] = consumed;
+        /* [4]: bytes the probe already put in place for the validated blocks (~0 = it did not) */
+        result[4] = (contiguous && spec_off[ncand] <= out_cap) ? spec_off[m] : ~0ull;
+        block_offsets[m] = complete ? consumed : resume;   /* end of the validated prefix */
+    }
+}
+
+}  // namespace hufgpu

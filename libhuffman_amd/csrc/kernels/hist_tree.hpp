@@ -1,0 +1,106 @@
+/* hist_tree.hpp - hist_tree_kernel: histogram + tree + size sums of a block in one launch.
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "histogram.hpp"
+#include "tree.hpp"
+#include "offsets.hpp"
+
+namespace hufgpu {
+
+
+#ifndef HT_COPIES
+#define HT_COPIES 2
+#endif
+
+/* hist256 + tree in one launch: the block's byte counts never leave the CU.  All waves count;
+ * then waves 1.. retire and wave 0 builds the tree in the LDS the histogram copies occupied.
+ * The tree rounds are latency bound and the counting is memory bound, so on a CU the tree of
+ * one block runs under the counting of the next ones.  The wave that finishes a group of blocks
+ * last also prefix-sums the group's encoded sizes (no scan launch between this kernel and pack). */
+#ifndef HTP_ARRAYS
+#define HTP_ARRAYS 2        /* packed mode: 256-word arrays per wave, each holding two 16-bit copies (1: 0.79, 2: 0.71, 4: 0.86 ms on Zipf) */
+#endif
+#define HT_PACKED_MAX_BLOCK 131072u     /* a wave counts a quarter of the block: < 65 536 per 16-bit counter */
+
+/* PACKED: the block is at most HT_PACKED_MAX_BLOCK bytes, so the private histograms use 16-bit
+ * counters, two per word (lane parity picks the half): four copies per wave in the LDS of two
+ * (hot symbols of skewed data collide half as often).  The totals are accumulated in place in the
+ * last array, which lies behind the 7 KiB TreeLds: 8 KiB per workgroup = 20 resident groups per
+ * CU instead of 13, and the latency-bound tree waves are what the kernel waits for on
+ * multi-symbol data (uniform bytes 0.68 -> 0.60 ms, Zipf 0.77 -> 0.71 ms per GiB). */
+template <int THREADS, bool PACKED>
+__global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                            uint64_t blocksize, hufcode_t *__restrict__ codetab,
+                                                            int16_t *__restrict__ treebuf,
+                                                            HufBlockMeta *__restrict__ meta, TwoLevel sizes)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr int COPIES = WAVES * (PACKED ? HTP_ARRAYS : HT_COPIES);   /* 256-word arrays */
+    constexpr size_t HBYTES = (size_t)COPIES * HUF_NSYM * sizeof(uint32_t);
+    constexpr size_t TBYTES = HUF_NSYM * sizeof(uint32_t);
+    /* totals: the last histogram array when that lies behind the tree's area (summed in place:
+     * a thread reads and writes only its own bin there), else right behind the tree's area */
+    constexpr size_t TOT_OFF = (HBYTES >= sizeof(TreeLds) + TBYTES) ? HBYTES - TBYTES : sizeof(TreeLds);
+    constexpr size_t UBYTES = (HBYTES > TOT_OFF + TBYTES) ? HBYTES : TOT_OFF + TBYTES;
+    static_assert(TOT_OFF >= sizeof(TreeLds) && TOT_OFF % 16 == 0, "totals must survive the tree's initialisation");
+    __shared__ __attribute__((aligned(16))) uint8_t s_union[UBYTES];
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_union);
+    uint32_t *s_tot = reinterpret_cast<uint32_t *>(s_union + TOT_OFF);
+
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    const int tid = (int)threadIdx.x;
+
+    for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
+    __syncthreads();
+    uint32_t *mine;
+    uint32_t one = 1u;
+    if (PACKED) {
+        mine = s_hist + ((tid >> 6) * HTP_ARRAYS + ((tid >> 1) & (HTP_ARRAYS - 1))) * HUF_NSYM;
+        one = (tid & 1) ? 0x10000u : 1u;
+    } else {
+        mine = s_hist + ((tid >> 6) * HT_COPIES + (tid & (HT_COPIES - 1))) * HUF_NSYM;
+    }
+    const uint8_t *p = in + base;
+    const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
+    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], one);
+    const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
+    const uint64_t nvec = (len - head) >> 4;
+    uint64_t i = (uint64_t)tid;
+    for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
+        const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
+                    v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
+        hist_add_chunk(mine, v0, one);
+        hist_add_chunk(mine, v1, one);
+        hist_add_chunk(mine, v2, one);
+        hist_add_chunk(mine, v3, one);
+    }
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i), one);
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], one);   /* < 16 bytes */
+    __syncthreads();
+    for (int b = tid; b < HUF_NSYM; b += THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < COPIES; w++) {
+            const uint32_t x = s_hist[w * HUF_NSYM + b];
+            sum += PACKED ? ((x & 0xffffu) + (x >> 16)) : x;
+        }
+        s_tot[b] = sum;
+    }
+    __syncthreads();                     /* copies are dead from here on; s_tot is complete */
+    if (tid >= 64) return;               /* ended waves do not take part in anything below */
+    uint32_t rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rate[j] = s_tot[tid + 64 * j];
+    const uint64_t bytes = tree_fast_wave(rate, *reinterpret_cast<TreeLds *>(s_union), blk, codetab, treebuf, meta);
+    /* stream offsets (the reference's running file position): summed here, see two_level_arrive */
+    two_level_arrive(sizes, blk, gridDim.x, bytes);
+}
+
+}  // namespace hufgpu

@@ -1,0 +1,295 @@
+/* pack.hpp - pack_kernel: block header and MSB-first bit-pack (src/encoder.c:85-131, 322-339).
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "offsets.hpp"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * pack_kernel - replaces the header emission (src/encoder.c:322-339) and __huf_encode_block
+ * + huf_bit_write (src/encoder.c:85-131, src/bufio.c:18-23).
+ *
+ * One workgroup per block.  The block record [u64 len][i16 tree_len][tree][payload] is a bit
+ * string that starts at byte offsets[blk] of the output; it is produced as big-endian 32-bit
+ * words aligned with the 4-byte words of the destination (stream bit b, MSB first inside each
+ * byte, is bit 31-(b&31) of word b>>5; a finished word is byte-swapped and stored).
+ *
+ * Payload tiles of THREADS*32 symbols.  Every lane loads 32 contiguous input bytes, looks the
+ * codes up in the LDS table and keeps them in registers; the workgroup prefix-sums the per-lane
+ * bit counts; then each lane shifts its codes through a 64-bit accumulator and stores every
+ * word that ENDS inside its bit range straight to HBM.  32 symbols are at least 32 bits, so
+ * every lane owns at least one word end: the only thing a lane needs from its left neighbour
+ * is the neighbour's unfinished tail (< 32 bits), one __shfl_up (LDS for the wave seams, the
+ * header tail / previous tile for lane 0).  No LDS image, no atomics.  The record's first and
+ * last word are byte-masked because neighbouring blocks own the rest of those words.
+ * ==================================================================================== */
+#define PACK_SPT 32
+#define PACK_STAGE_WORDS 3328          /* 13 KiB: a 256x32-symbol tile at up to ~12.9 bits per symbol */
+
+template <typename CodeT>
+struct PackAcc {
+    uint64_t acc;       /* right-aligned bits not yet emitted */
+    uint32_t nacc;      /* number of them (< 32 between pushes) */
+    uint32_t first;     /* first finished word (its leading bits belong to the left neighbour) */
+    bool have_first;
+    uint32_t *gw;       /* where the next finished word goes (LDS stage or HBM, fixed per tile) */
+
+    __device__ __forceinline__ void emit(uint32_t word)
+    {
+        if (!have_first) { first = word; have_first = true; }
+        else *gw = __builtin_bswap32(word);
+        gw++;
+    }
+    __device__ __forceinline__ void push32(uint32_t code, uint32_t len)     /* len <= 32 */
+    {
+        acc = (acc << len) | code;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            emit((uint32_t)(acc >> nacc));
+        }
+    }
+    __device__ __forceinline__ void push(CodeT e)
+    {
+        uint32_t len = (uint32_t)(e & 0xffu);
+        if constexpr (sizeof(CodeT) == 8) {
+            const uint64_t c = e >> 8;
+            if (len > 32) {                      /* long code: high part first */
+                push32((uint32_t)(c >> 32), len - 32);
+                len = 32;
+            }
+            push32((uint32_t)c, len);
+        } else {
+            push32((uint32_t)(e >> 8), len);
+        }
+    }
+};
+
+/* byte j of the block header (encoder.c:325-339, little-endian fields) */
+__device__ __forceinline__ uint32_t header_byte(uint32_t j, uint64_t block_len, uint32_t tree_len,
+                                                const int16_t *__restrict__ tb)
+{
+    if (j < 8) return (uint32_t)(block_len >> (8 * j)) & 0xffu;
+    if (j < 10) return (tree_len >> (8 * (j - 8))) & 0xffu;
+    const uint16_t e = (uint16_t)tb[(j - 10) >> 1];
+    return (e >> (8 * (j & 1))) & 0xffu;
+}
+
+template <int THREADS, typename CodeT>
+__device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint64_t len,
+                                           const hufcode_t *__restrict__ codes64,
+                                           const int16_t *__restrict__ tb, uint32_t tree_len,
+                                           uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
+                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage)
+{
+    constexpr int TILE = THREADS * PACK_SPT;
+    constexpr int WAVES = THREADS / 64;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    uint8_t *g_a0 = out + (dst0 & ~3ull);
+    const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
+    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
+    uint32_t *g_w0 = reinterpret_cast<uint32_t *>(g_a0);
+
+    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = (CodeT)codes64[i];
+
+    /* ---- header: whole aligned words are stored here, the unfinished last word becomes the
+     *      incoming tail of the payload's first lane ---- */
+    const uint32_t hdr_bytes = HUF_HEADER_FIXED + 2u * tree_len;
+    const uint32_t hdr_end = rec_lo + hdr_bytes;                 /* relative to A0 */
+    for (uint32_t w = tid; w < (hdr_end >> 2); w += THREADS) {
+        uint32_t v = 0;                                          /* little-endian memory word */
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t bp = 4 * w + k;
+            if (bp >= rec_lo) v |= header_byte(bp - rec_lo, len, tree_len, tb) << (8 * k);
+        }
+        if (4 * w >= rec_lo) g_w0[w] = v;
+        else {
+            for (uint32_t k = rec_lo - 4 * w; k < 4; k++) g_a0[4 * w + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+    if (tree_len == 5) {
+        /* One distinct byte in the block: its code is the single bit 0 (tree.c:410-413 with one
+         * leaf), so the payload is ceil(len/8) zero bytes - nothing of the input needs reading
+         * again (the histogram already saw it). */
+        for (uint32_t bp = (hdr_end & ~3u) + tid; bp < hdr_end; bp += THREADS)       /* header bytes of the seam word */
+            g_a0[bp] = (uint8_t)header_byte(bp - rec_lo, len, tree_len, tb);
+        const uint64_t z0 = hdr_end, z1 = rec_hi;                /* zero bytes [z0, z1) relative to A0 */
+        const uint64_t a0 = dmin<uint64_t>((z0 + 15) & ~15ull, z1);
+        const uint64_t a1 = dmax<uint64_t>(a0, z1 & ~15ull);
+        /* g_a0 is 4-byte aligned; 16-byte stores need the absolute address aligned */
+        const uint64_t skew = (uint64_t)((uintptr_t)g_a0 & 15u);
+        const uint64_t b0 = dmin<uint64_t>(((z0 + skew + 15) & ~15ull) - skew, z1);
+        const uint64_t b1 = dmax<uint64_t>(b0, ((z1 + skew) & ~15ull) - skew);
+        (void)a0; (void)a1;
+        for (uint64_t bp = z0 + tid; bp < b0; bp += THREADS) g_a0[bp] = 0;
+        uint4 *q = reinterpret_cast<uint4 *>(g_a0 + b0);
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t i = (uint64_t)tid; i < ((b1 - b0) >> 4); i += THREADS) store_pack16(q + i, zero4);
+        for (uint64_t bp = b1 + tid; bp < z1; bp += THREADS) g_a0[bp] = 0;
+        return;
+    }
+    if (tid == 0) {
+        uint32_t t = 0;                                          /* big-endian partial word */
+        for (uint32_t bp = hdr_end & ~3u; bp < hdr_end; bp++)
+            t = (t << 8) | header_byte(bp - rec_lo, len, tree_len, tb);
+        s_tail[WAVES] = t;                                       /* carry: value of the (hdr_end&3)*8 leading bits */
+    }
+    __syncthreads();
+
+    uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
+
+
+    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
+        /* ---- load + look up ---- */
+        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SPT;
+        uint32_t nsym = 0;
+        CodeT code[PACK_SPT];
+        uint32_t mybits = 0;
+        if (my0 < len) {
+            nsym = (uint32_t)dmin<uint64_t>(PACK_SPT, len - my0);
+            const uint8_t *p = src + my0;
+            if (nsym == PACK_SPT && (((uintptr_t)p) & 15u) == 0) {
+                const uint4 v0 = load_stream16(reinterpret_cast<const uint4 *>(p));
+                const uint4 v1 = load_stream16(reinterpret_cast<const uint4 *>(p) + 1);
+                const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k++) code[k] = s_code[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+            } else {
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k++) code[k] = (k < (int)nsym) ? s_code[p[k]] : (CodeT)0;
+            }
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) mybits += (uint32_t)(code[k] & 0xffu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) code[k] = 0;
+        }
+        uint32_t tile_bits;
+        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
+
+        /* ---- shift the codes out ----
+         * Finished words go to an LDS stage laid out like the destination (stage word i <-> HBM
+         * address stage_addr + 4 i, both 16-byte aligned), then the workgroup flushes the stage
+         * with 16-byte stores: lanes' words are adjacent in memory but not in time, so storing
+         * them one by one costs a partially filled store instruction per word.  A tile whose
+         * codes are too long for the stage (possible only far above the 9-bit average) stores
+         * straight to HBM instead. */
+        const uint64_t s = bitpos + ex;                          /* my first bit */
+        const uint64_t w_lo = bitpos >> 5, w_hi = (bitpos + tile_bits) >> 5;   /* tile's finished words [w_lo, w_hi) */
+        const uintptr_t stage_addr = (uintptr_t)(g_w0 + w_lo) & ~(uintptr_t)15;
+        const uint32_t i_lo = (uint32_t)(((uintptr_t)(g_w0 + w_lo) - stage_addr) >> 2);
+        const uint32_t i_hi = i_lo + (uint32_t)(w_hi - w_lo);
+        const bool staged = i_hi + 2 <= PACK_STAGE_WORDS;        /* wave-uniform */
+        PackAcc<CodeT> a;
+        a.acc = 0;
+        a.nacc = (uint32_t)(s & 31u);                            /* leading bits come from the left */
+        a.have_first = false;
+        a.first = 0;
+        uint32_t *const g_first = g_w0 + (s >> 5);
+        uint32_t *const s_first = s_stage + (i_lo + (uint32_t)((s >> 5) - w_lo));
+        if (staged) {
+            a.gw = s_first;
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);  /* absent symbols have len 0 */
+        } else {
+            a.gw = g_first;
+#pragma unroll
+            for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);
+        }
+        const uint32_t nwords = (uint32_t)(a.gw - (staged ? s_first : g_first));   /* finished words of this lane */
+        const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
+
+        /* ---- tails hop one lane to the right ---- */
+        uint32_t in_tail = (uint32_t)__shfl_up((int)tail_val, 1);
+        if (lane == 63) s_tail[wave] = tail_val;
+        __syncthreads();
+        if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];
+        const uint32_t n_in = (uint32_t)(s & 31u);
+        const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
+        if (a.have_first) {
+            const uint32_t word = __builtin_bswap32(a.first | (n_in ? (in_tail << (32 - n_in)) : 0u));
+            if (staged) *s_first = word;
+            else *g_first = word;
+        }
+        uint32_t out_tail = tail_val;
+        if (!a.have_first && nsym > 0) {
+            /* only the block's last lane can be shorter than a word: its tail continues the
+             * neighbour's */
+            out_tail = (n_in ? (in_tail << (a.nacc - n_in)) : 0u) | tail_val;
+        }
+        if (is_last && a.nacc) {
+            /* zero-padded final byte(s) (encoder.c:123-128); bytes past the record belong to
+             * the next block */
+            const uint32_t word = out_tail << (32 - a.nacc);
+            const uint32_t nbytes = (a.nacc + 7) >> 3;
+            uint8_t *b = reinterpret_cast<uint8_t *>(g_first + nwords);
+            for (uint32_t k = 0; k < nbytes; k++) b[k] = (uint8_t)(word >> (24 - 8 * k));
+        }
+        __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
+        if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
+        if (staged) {
+            uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
+            for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
+                const uint32_t i0 = 4 * u;
+                if (i0 >= i_lo && i0 + 4 <= i_hi) {
+                    store_pack16(reinterpret_cast<uint4 *>(g16 + 4 * i0), *reinterpret_cast<const uint4 *>(s_stage + i0));
+                } else {
+                    for (uint32_t i = (i0 > i_lo ? i0 : i_lo); i < i0 + 4 && i < i_hi; i++)
+                        *reinterpret_cast<uint32_t *>(g16 + 4 * i) = s_stage[i];
+                }
+            }
+        }
+        bitpos += tile_bits;
+        (void)rec_hi;
+    }
+}
+
+/* SHORT = true: the host guarantees that no code of this launch is longer than 24 bits (any
+ * Huffman merge order on n <= 121392 symbols gives depth <= 23, plus the wrap-root bit; the
+ * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
+ * registers, more waves. */
+template <int THREADS, bool SHORT>
+__global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                       uint64_t blocksize,
+                                                       const hufcode_t *__restrict__ codetab,
+                                                       const int16_t *__restrict__ treebuf,
+                                                       const HufBlockMeta *__restrict__ meta,
+                                                       uint64_t *__restrict__ offsets, TwoLevel sizes,
+                                                       uint8_t *__restrict__ out)
+{
+    __shared__ hufcode_t s_code[SHORT ? HUF_NSYM / 2 : HUF_NSYM];   /* u32[256] on the short-code path */
+    __shared__ uint32_t s_part[THREADS / 64];
+    __shared__ uint32_t s_tail[THREADS / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
+
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    const HufBlockMeta m = meta[blk];
+    const hufcode_t *codes = codetab + blk * HUF_NSYM;
+    const int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    uint64_t o0, o1;
+    if (sizes.local) {                   /* sizes were summed by hist_tree_kernel: publish the index entry */
+        o0 = sizes.gprefix[blk / SCAN_GROUP] + sizes.local[blk];
+        o1 = o0 + encoded_block_bytes(m);
+        if (threadIdx.x == 0) offsets[blk] = o0;
+    } else {
+        o0 = offsets[blk];
+        o1 = offsets[blk + 1];
+    }
+    if (SHORT || m.max_len <= 24)
+        pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage);
+    else if constexpr (!SHORT)
+        pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                       s_code, s_part, s_tail, s_stage);
+}
+
+}  // namespace hufgpu

@@ -1,0 +1,431 @@
+/* tree.hpp - tree_kernel / tree_fast_wave: tree build, codes, serialized tree (src/tree.c:292-427, 12-47, 233-289).
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "util.hpp"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * tree_kernel - replaces huf_tree_from_histogram (src/tree.c:292-427), the code walk
+ * (src/tree.c:12-47 + src/encoder.c:40-81) and huf_tree_serialize (src/tree.c:233-289).
+ *
+ * One wavefront per block.  The 512 rate slots live in registers, 8 per lane (slot = lane +
+ * 64*j).  A slot's sort key is (rate << 9) | (511 - slot): the plain minimum of the keys is
+ * the reference's selection order "rate ascending, index descending" (tree.c:329-352), and
+ * keys are unique.  Each round reduces the two smallest keys across the wave, makes the
+ * smaller one the left child and the other the right child of the new node (tree.c:390-408),
+ * and stops on the round that finds a single survivor, which becomes the left-only wrap root
+ * (tree.c:410-413).  K = uint32_t serves blocks shorter than 2^22 bytes, uint64_t the rest.
+ *
+ * Then, level by level from the root: code bits, depth and the preorder position of every
+ * node (position of a right child = parent + 1 + entries of the left subtree, a subtree with
+ * L leaves holding 4L-1 entries), which gives codes and the serialized tree without recursion.
+ * ==================================================================================== */
+template <typename K>
+__global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ hist, uint64_t n,
+                                                  uint64_t blocksize, hufcode_t *__restrict__ codetab,
+                                                  int16_t *__restrict__ treebuf,
+                                                  HufBlockMeta *__restrict__ meta)
+{
+    __shared__ int16_t s_left[HUF_NSLOT];
+    __shared__ int16_t s_right[HUF_NSLOT];
+    __shared__ uint16_t s_leaves[HUF_NSLOT];  /* leaves below each slot */
+    __shared__ uint16_t s_depth[HUF_NSLOT];   /* 0xffff = not reached */
+    __shared__ uint16_t s_pos[HUF_NSLOT];     /* preorder position */
+    __shared__ uint64_t s_code[HUF_NSLOT];
+    __shared__ int16_t s_tree[HUF_TREE_STRIDE];
+
+    const K KMAX = ~(K)0;
+    const int lane = lane_id();
+    const uint64_t blk = blockIdx.x;
+    const uint32_t *h = hist + blk * HUF_NSYM;
+
+    K key[8];
+    uint32_t rate[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        rate[j] = h[slot];
+        key[j] = rate[j] ? (((K)rate[j] << 9) | (K)(511 - slot)) : KMAX;
+    }
+#pragma unroll
+    for (int j = 4; j < 8; j++) key[j] = KMAX;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int slot = lane + 64 * j;
+        s_left[slot] = -1;
+        s_right[slot] = -1;
+        s_leaves[slot] = (j < 4 && rate[j & 3]) ? 1 : 0;
+        s_depth[slot] = 0xffffu;
+    }
+    __syncthreads();
+
+    int node = HUF_NSYM;
+    int root = -1;
+    for (;;) {
+        K a = KMAX, b = KMAX;              /* two smallest keys of this lane */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const K k = key[j];
+            const K t = dmax(a, k);
+            a = dmin(a, k);
+            b = dmin(b, t);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {  /* butterfly: disjoint lane groups, unique keys */
+            const K oa = shfl_xor_key(a, o);
+            const K ob = shfl_xor_key(b, o);
+            const K t = dmax(a, oa);
+            a = dmin(a, oa);
+            b = dmin(dmin(b, ob), t);
+        }
+        if (a == KMAX) {                   /* tree.c:355-358 (only for an empty histogram) */
+            root = node - 1;
+            break;
+        }
+        const int i1 = 511 - (int)(a & (K)511);
+        if (b == KMAX) {                   /* tree.c:410-413: single survivor -> left-only root */
+            if (lane == 0) {
+                s_left[node] = (int16_t)i1;
+                s_right[node] = -1;
+                s_leaves[node] = s_leaves[i1];
+            }
+            root = node;
+            node++;
+            break;
+        }
+        const int i2 = 511 - (int)(b & (K)511);
+        const K sum = (a >> 9) + (b >> 9);  /* tree.c:407 */
+        const K nk = (sum << 9) | (K)(511 - node);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int slot = lane + 64 * j;
+            if (slot == i1 || slot == i2) key[j] = KMAX;   /* tree.c:396,403 */
+            if (slot == node) key[j] = nk;
+        }
+        if (lane == 0) {
+            s_left[node] = (int16_t)i1;
+            s_right[node] = (int16_t)i2;
+            s_leaves[node] = (uint16_t)(s_leaves[i1] + s_leaves[i2]);
+        }
+        node++;
+    }
+    __syncthreads();
+
+    const int nodes = node;
+    const int nleaves = (root >= 0) ? (int)s_leaves[root] : 0;
+    const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
+
+    for (int i = lane; i < HUF_TREE_STRIDE; i += 64) s_tree[i] = -1;
+    if (lane == 0 && root >= 0) {
+        s_depth[root] = 0;
+        s_code[root] = 0;
+        s_pos[root] = 0;
+    }
+    __syncthreads();
+
+    for (int d = 0; d < HUF_NSLOT; d++) {
+        bool any = false;
+#pragma unroll
+        for (int j = 4; j < 8; j++) {
+            const int slot = lane + 64 * j;
+            if (slot < nodes && s_depth[slot] == (uint16_t)d) {
+                any = true;
+                const int l = s_left[slot], r = s_right[slot];
+                const uint64_t c = s_code[slot];
+                const int p = s_pos[slot];
+                s_tree[p] = (int16_t)slot;
+                s_depth[l] = (uint16_t)(d + 1);
+                s_code[l] = c << 1;
+                s_pos[l] = (uint16_t)(p + 1);
+                if (l < HUF_NSYM) s_tree[p + 1] = (int16_t)l;
+                if (r >= 0) {
+                    const int pr = p + 1 + 4 * (int)s_leaves[l] - 1;
+                    s_depth[r] = (uint16_t)(d + 1);
+                    s_code[r] = (c << 1) | 1u;
+                    s_pos[r] = (uint16_t)pr;
+                    if (r < HUF_NSYM) s_tree[pr] = (int16_t)r;
+                }
+            }
+        }
+        __syncthreads();
+        if (!__any(any)) break;
+    }
+
+    uint64_t bits = 0;
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        hufcode_t e = 0;
+        if (rate[j]) {
+            const uint32_t len = s_depth[slot];
+            e = (s_code[slot] << 8) | (hufcode_t)len;
+            bits += (uint64_t)rate[j] * len;
+            maxlen = dmax(maxlen, len);
+        }
+        codetab[blk * HUF_NSYM + slot] = e;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        bits += shfl_xor_u64(bits, o);
+        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    }
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
+    if (lane == 0) {
+        HufBlockMeta m;
+        m.tree_len = (uint32_t)tree_len;
+        m.max_len = maxlen;
+        m.payload_bits = bits;
+        meta[blk] = m;
+    }
+    (void)n;
+    (void)blocksize;
+}
+
+/* ======================================================================================
+ * tree_fast_wave - same algorithm and outputs as tree_kernel<uint32_t>, tuned for the wave (it runs
+ * as the tail of hist_tree_kernel).
+ *   - At most 256 items are alive at any time (k leaves, one fewer after every merge), so the
+ *     live keys fit a pool of 4 registers per lane; the node created by a merge takes over the
+ *     pool position of the smaller of the two items it replaces.  A key still carries the
+ *     item's logical index (rate<<9 | 511-index), so the selection order is unchanged.
+ *   - The wave minimum is a DPP reduction (quad_perm, row_half_mirror, row_mirror, row_bcast15,
+ *     row_bcast31) ending in lane 63 and read back as a scalar: no LDS round trips in the loop.
+ *   - Children are written to LDS fire-and-forget; leaf counts are derived after the loop.
+ * ==================================================================================== */
+/* Wave minimum: six v_min_u32 with a DPP source operand (the compiler turns update_dpp + min into
+ * mov, mov_dpp, min - three instructions per step; the merge loop runs two of these reductions
+ * per round and is VALU bound once enough tree waves are resident).  s_nop 1 = the two wait
+ * states a DPP read needs after the VALU write of its source.  Rows not named by row_mask keep
+ * their value, the result is complete in lane 63. */
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#ifdef TREE_DPP_BUILTIN
+    auto step = [](uint32_t x, int sel) {
+        uint32_t o;
+        switch (sel) {
+        case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false); break;
+        case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false); break;
+        case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false); break;
+        case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false); break;
+        case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xa, 0xf, false); break;
+        default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xc, 0xf, false); break;
+        }
+        return dmin(x, o);
+    };
+    for (int k = 0; k < 6; k++) v = step(v, k);
+#else
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+#endif
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct TreeLds {                  /* 7 KiB: what bounds the tree waves a CU holds (they are latency bound) */
+    uint32_t code[HUF_NSLOT];     /* blocks shorter than 2^22 bytes: depth <= 32 */
+    int16_t left[HUF_NSLOT];
+    int16_t right[HUF_NSLOT];
+    uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot, 0xffff = not known yet */
+    uint16_t depth[HUF_NSLOT];    /* 0xffff = not reached */
+    uint16_t pos[HUF_NSLOT];      /* preorder position */
+};
+
+/* Single-wave synchronisation: LDS operations of one wave are in order, so only the compiler and
+ * the LDS counter have to be fenced.  (The fused kernel calls this after its other waves have
+ * retired, so a workgroup barrier must not be used here.) */
+#define TREE_WAVE_SYNC()                                        \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+/* Executed by ONE wavefront; rate[j] = count of byte (lane + 64 j) in the block.  Returns the
+ * encoded size of the block in bytes (every lane). */
+__device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], TreeLds &L, uint64_t blk,
+                                               hufcode_t *__restrict__ codetab, int16_t *__restrict__ treebuf,
+                                               HufBlockMeta *__restrict__ meta)
+{
+    int16_t *s_left = L.left, *s_right = L.right;
+    uint16_t *s_lcnt = L.lcnt, *s_depth = L.depth, *s_pos = L.pos;
+    uint32_t *s_code = L.code;
+    const uint32_t KMAX = 0xffffffffu;
+    const int lane = lane_id();
+
+    /* one distinct byte: the tree is [256, s, -1, -1, -1] and the code of s is the single bit 0
+     * (tree.c:410-413 on the first round) - no need for the general machinery */
+    {
+        const unsigned long long nz0 = __ballot(rate[0] != 0), nz1 = __ballot(rate[1] != 0);
+        const unsigned long long nz2 = __ballot(rate[2] != 0), nz3 = __ballot(rate[3] != 0);
+        if (__popcll(nz0) + __popcll(nz1) + __popcll(nz2) + __popcll(nz3) == 1) {
+            const int j1 = nz0 ? 0 : (nz1 ? 1 : (nz2 ? 2 : 3));
+            const unsigned long long m1 = nz0 | nz1 | nz2 | nz3;
+            const int sym = __builtin_ctzll(m1) + 64 * j1;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += rate[j];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+            /* pack_kernel never looks codes up for a 5-entry tree (all-zero payload), so the 2 KiB
+             * code table of this block is not written */
+            int16_t *tb1 = treebuf + blk * HUF_TREE_STRIDE;
+            if (lane < 5) tb1[lane] = (lane == 0) ? (int16_t)256 : (lane == 1 ? (int16_t)sym : (int16_t)-1);
+            HufBlockMeta mm;
+            mm.tree_len = 5;
+            mm.max_len = 1;
+            mm.payload_bits = cnt;
+            if (lane == 0) meta[blk] = mm;
+            return encoded_block_bytes(mm);
+        }
+    }
+
+    uint32_t k[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        k[j] = rate[j] ? ((rate[j] << 9) | (uint32_t)(511 - slot)) : KMAX;
+        s_lcnt[slot] = rate[j] ? 1 : 0;
+        s_lcnt[256 + slot] = 0xffffu;
+        s_depth[slot] = 0xffffu;
+        s_depth[256 + slot] = 0xffffu;
+        s_left[256 + slot] = -1;
+        s_right[256 + slot] = -1;
+    }
+
+    int node = HUF_NSYM;
+    int root = -1;
+    for (;;) {
+        const uint32_t a = wave_min_u32(dmin(dmin(k[0], k[1]), dmin(k[2], k[3])));
+        if (a == KMAX) { root = node - 1; break; }                 /* tree.c:355-358 */
+        uint32_t t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[j] = (k[j] == a) ? KMAX : k[j];
+        const uint32_t b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
+        const int i1 = 511 - (int)(a & 511u);
+        if (b == KMAX) {                                           /* tree.c:410-413: left-only wrap root */
+            if (lane == 0) s_left[node] = (int16_t)i1;
+            root = node;
+            node++;
+            break;
+        }
+        const int i2 = 511 - (int)(b & 511u);
+        const uint32_t nk = (((a >> 9) + (b >> 9)) << 9) | (uint32_t)(511 - node);   /* tree.c:407 */
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = (k[j] == a) ? nk : ((t[j] == b) ? KMAX : t[j]);
+        if (lane == 0) {
+            s_left[node] = (int16_t)i1;                            /* tree.c:390-404 */
+            s_right[node] = (int16_t)i2;
+        }
+        node++;
+    }
+    TREE_WAVE_SYNC();
+    const int nodes = node;
+
+    /* leaves below every internal node: children always have smaller indices, so a few rounds of
+     * "both children known -> sum" settle it (one tree level per round) */
+    for (int round = 0; round < HUF_NSLOT; round++) {
+        bool pending = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int slot = 256 + lane + 64 * j;
+            if (slot < nodes && s_lcnt[slot] == 0xffffu) {
+                const int l = s_left[slot], r = s_right[slot];
+                const uint32_t cl = s_lcnt[l];
+                const uint32_t cr = (r >= 0) ? (uint32_t)s_lcnt[r] : 0u;
+                if (cl != 0xffffu && cr != 0xffffu) s_lcnt[slot] = (uint16_t)(cl + cr);
+                else pending = true;
+            }
+        }
+        TREE_WAVE_SYNC();
+        if (!__any(pending)) break;
+    }
+    const int nleaves = (root >= 0) ? (int)s_lcnt[root] : 0;
+    const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
+
+    if (lane == 0 && root >= 0) {
+        s_depth[root] = 0;
+        s_code[root] = 0;
+        s_pos[root] = 0;
+    }
+    TREE_WAVE_SYNC();
+
+    /* level sweep: codes, depths, preorder positions (see tree_kernel).  The serialized tree goes
+     * straight to HBM: a node at position p writes its index there, a leaf also the two -1 of its
+     * absent children behind it, and a node without a right child (the wrap root) the -1 where
+     * that child would start - together exactly the 4k+1 entries, each written once. */
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+    for (int d = 0; d < HUF_NSLOT; d++) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int slot = 256 + lane + 64 * j;
+            if (slot < nodes && s_depth[slot] == (uint16_t)d) {
+                any = true;
+                const int l = s_left[slot], r = s_right[slot];
+                const uint32_t c = s_code[slot];
+                const int p = s_pos[slot];
+                tb[p] = (int16_t)slot;
+                s_depth[l] = (uint16_t)(d + 1);
+                s_code[l] = c << 1;
+                s_pos[l] = (uint16_t)(p + 1);
+                if (l < HUF_NSYM) { tb[p + 1] = (int16_t)l; tb[p + 2] = -1; tb[p + 3] = -1; }
+                const int pr = p + 4 * (int)s_lcnt[l];
+                if (r >= 0) {
+                    s_depth[r] = (uint16_t)(d + 1);
+                    s_code[r] = (c << 1) | 1u;
+                    s_pos[r] = (uint16_t)pr;
+                    if (r < HUF_NSYM) { tb[pr] = (int16_t)r; tb[pr + 1] = -1; tb[pr + 2] = -1; }
+                } else {
+                    tb[pr] = -1;
+                }
+            }
+        }
+        TREE_WAVE_SYNC();
+        if (!__any(any)) break;
+    }
+
+    uint64_t bits = 0;
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = lane + 64 * j;
+        hufcode_t e = 0;
+        if (rate[j]) {
+            const uint32_t len = s_depth[slot];
+            e = ((hufcode_t)s_code[slot] << 8) | (hufcode_t)len;
+            bits += (uint64_t)rate[j] * len;
+            maxlen = dmax(maxlen, len);
+        }
+        codetab[blk * HUF_NSYM + slot] = e;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        bits += shfl_xor_u64(bits, o);
+        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    }
+    HufBlockMeta mm;
+    mm.tree_len = (uint32_t)tree_len;
+    mm.max_len = maxlen;
+    mm.payload_bits = bits;
+    if (lane == 0) meta[blk] = mm;
+    return encoded_block_bytes(mm);
+}
+
+}  // namespace hufgpu

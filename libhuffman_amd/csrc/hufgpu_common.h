@@ -34,7 +34,8 @@ struct HufBlockMeta {
 /* Written by decode_prepare, read by decode. 16 bytes. */
 struct HufDecodeMeta {
     uint64_t block_len;      /* symbols to restore (0 when status != 0)                 */
-    int32_t  tree_len;
+    int16_t  tree_len;
+    int16_t  leaf;           /* the byte of a [root, leaf, -1, -1, -1] tree, else -1    */
     int32_t  status;         /* HUFE_* found while parsing the header                   */
 };
 

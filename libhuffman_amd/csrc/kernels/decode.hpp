@@ -40,6 +40,17 @@ __device__ __forceinline__ void load_header10(const uint8_t *stream, uint64_t st
     tree_len = (int16_t)(d[2] & 0xffffu);
 }
 
+/* The tree every one-symbol block carries, [root, leaf, -1, -1, -1]: the
+ * leaf's byte, or -1 for any other five entries (those go through the general tree build). */
+__device__ __forceinline__ int single_leaf_symbol(const uint8_t *tree)
+{
+    int16_t e5[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) e5[i] = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
+    const bool one = e5[0] != -1 && e5[1] != -1 && e5[2] == -1 && e5[3] == -1 && e5[4] == -1;
+    return one ? (int)(uint8_t)e5[1] : -1;
+}
+
 /* decode_prepare_kernel - header parse of src/decoder.c:218-252 for every indexed block, one block
  * per thread, and the sums of the block lengths (= where each block's output starts) as a
  * two-level prefix: a workgroup is one SCAN_GROUP.  result words: [0] unused, [1] total raw
@@ -60,6 +71,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
     HufDecodeMeta m;
     m.block_len = 0;
     m.tree_len = 0;
+    m.leaf = -1;
     m.status = HUFE_OK;
     if (b < nblocks) {
         const uint64_t o0 = offsets[b];
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
                 else {
                     m.block_len = bl;
                     m.tree_len = tl;
+                    if (tl == 5) m.leaf = (int16_t)single_leaf_symbol(stream + o0 + HUF_HEADER_FIXED);
                 }
             }
         }
@@ -658,9 +671,48 @@ __device__ __forceinline__ uint32_t dec_write(const DecShared<THREADS> &sh, uint
     return rd.pos();
 }
 
+/* Set bits among the payload bits [0, have) that the aligned 16 bytes at address p hold (v = those
+ * 16 bytes; the payload starts at address a0 and `end` is one past the last byte with a needed bit). */
+__device__ __forceinline__ uint32_t single_leaf_stray_bits(uint4 v, uintptr_t p, uintptr_t a0, uintptr_t end, uint64_t have)
+{
+    if (p >= a0 && p + 16 < end) return v.x | v.y | v.z | v.w;      /* interior: every bit counts */
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uintptr_t addr = p + (uintptr_t)k;
+        uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        if (addr < a0 || addr >= end) byte = 0;
+        else if (addr == end - 1 && (have & 7u)) byte &= 0xff00u >> (uint32_t)(have & 7u);   /* first bits = high bits */
+        any |= byte;
+    }
+    return any;
+}
+
+/* dst[0, n) = symv by the whole workgroup: bytes up to the first 16-byte boundary, 16-byte
+ * streaming stores, bytes behind the last boundary */
+template <int THREADS>
+__device__ __forceinline__ void fill_bytes(uint8_t *dst, uint64_t n, uint32_t symv)
+{
+    const int tid = (int)threadIdx.x;
+    const uint32_t rep = symv * 0x01010101u;
+    const uint64_t head = dmin<uint64_t>(n, (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u);
+    if ((uint64_t)tid < head) dst[tid] = (uint8_t)symv;
+    uint4 *q = reinterpret_cast<uint4 *>(dst + head);
+    const uint64_t nvec = (n - head) >> 4;
+    const uint4 v4 = make_uint4(rep, rep, rep, rep);
+    for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) store_stream16(q + i, v4);
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)tid < n) dst[tail0 + tid] = (uint8_t)symv;
+}
+
 /* Trees whose root has one leaf child on the left: every symbol is a single 0 bit and a 1 bit
- * leaves the tree (src/decoder.c:69-71).  Scan the needed payload bits for a set bit, then the
- * output is a fill.  sh.firstone must be DEC_NO_BAD on entry. */
+ * leaves the tree (src/decoder.c:69-71).  The output is a fill and the payload only has to be
+ * free of set bits: its loads are issued, then the fill (as far as the input could reach at
+ * all), then the loaded words are looked at - memory operations complete in order, so neither
+ * waits for the other.  Only a payload with a set bit is read again for the bit's position; what
+ * the fill wrote behind it is unspecified, as everywhere behind the end of a failed decode.
+ * Aligned 16-byte loads: the chunks that hold a payload byte are readable (never across a page). */
 template <int THREADS, bool STORE>
 __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const uint8_t *pay, uint64_t block_len,
                                   uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits, uint64_t *produced_out)
@@ -668,31 +720,31 @@ __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const u
     const int tid = (int)threadIdx.x;
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint64_t have = dmin<uint64_t>(block_len, pay_bits);       /* bits we may look at */
-    const uint64_t nwords = (have + 31) >> 5;
-    uint32_t first = DEC_NO_BAD;
-    for (uint64_t w = (uint64_t)tid; w < nwords; w += THREADS) {
-        uint32_t v = load_be32(pay, w * 4, pay_bytes);
-        const uint64_t left_bits = have - (w << 5);
-        if (left_bits < 32) v &= ~(0xffffffffu >> (uint32_t)left_bits);
-        if (v) { first = (uint32_t)dmin<uint64_t>(first, (w << 5) + (uint32_t)__clz(v)); break; }
-    }
-    if (first != DEC_NO_BAD) atomicMin(&sh.firstone, first);
-    __syncthreads();
-    const uint32_t fo = sh.firstone;
-    const uint64_t good = (fo != DEC_NO_BAD) ? (uint64_t)fo : have;
-    if (STORE) {                        /* fill gout[0, good) */
-        const uint32_t rep = symv * 0x01010101u;
-        const uint64_t head = dmin<uint64_t>(good, (16u - (uint32_t)((uintptr_t)gout & 15u)) & 15u);
-        if ((uint64_t)tid < head) gout[tid] = (uint8_t)symv;
-        uint4 *q = reinterpret_cast<uint4 *>(gout + head);
-        const uint64_t nvec = (good - head) >> 4;
-        const uint4 v4 = make_uint4(rep, rep, rep, rep);
-        for (uint64_t i = (uint64_t)tid; i < nvec; i += THREADS) store_stream16(q + i, v4);
-        const uint64_t tail0 = head + (nvec << 4);
-        if (tail0 + (uint64_t)tid < good) gout[tail0 + tid] = (uint8_t)symv;
+    const uintptr_t a0 = (uintptr_t)pay, end = a0 + (uintptr_t)((have + 7) >> 3);
+    uintptr_t p = (a0 & ~(uintptr_t)15) + 16u * (uintptr_t)tid;
+    uint4 v0 = make_uint4(0, 0, 0, 0);
+    if (p < end) v0 = load_stream16(reinterpret_cast<const uint4 *>(p));
+    if (STORE) fill_bytes<THREADS>(gout, have, symv);
+    uint32_t any = (p < end) ? single_leaf_stray_bits(v0, p, a0, end, have) : 0u;
+    for (p += 16u * THREADS; p < end; p += 16u * THREADS)
+        any |= single_leaf_stray_bits(load_stream16(reinterpret_cast<const uint4 *>(p)), p, a0, end, have);
+    uint64_t good = have;
+    if (__syncthreads_or(any != 0u)) {                               /* a 1 bit: which one is the first? */
+        if (tid == 0) sh.firstone = DEC_NO_BAD;
+        __syncthreads();
+        const uint64_t nwords = (have + 31) >> 5;
+        for (uint64_t w = (uint64_t)tid; w < nwords; w += THREADS) {
+            uint32_t v = load_be32(pay, w * 4, pay_bytes);
+            const uint64_t left_bits = have - (w << 5);
+            if (left_bits < 32) v &= ~(0xffffffffu >> (uint32_t)left_bits);
+            if (v) { atomicMin(&sh.firstone, (uint32_t)((w << 5) + (uint32_t)__clz(v))); break; }
+        }
+        __syncthreads();
+        good = sh.firstone;
+        *produced_out = good;
+        return HUFE_CORRUPTED;                                       /* decoder.c:69-71 */
     }
     *produced_out = good;
-    if (fo != DEC_NO_BAD) return HUFE_CORRUPTED;                     /* decoder.c:69-71 */
     if (have < block_len) return HUFE_RW;                            /* decoder.c:53-56 */
     *end_bits = block_len;
     return HUFE_OK;
@@ -717,16 +769,10 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
      *         caught after the general tree build below ---- */
     unsigned long long pt = DPROF_T();
     if (tree_len == 5) {
-        int16_t e5[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) e5[i] = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
-        if (e5[0] != -1 && e5[1] != -1 && e5[2] == -1 && e5[3] == -1 && e5[4] == -1) {
-            __syncthreads();
-            if (tid == 0) sh.firstone = DEC_NO_BAD;
-            __syncthreads();
-            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)(uint8_t)e5[1], tree + 10, block_len, pay_bytes, gout,
-                                               end_bits, produced_out);
-        }
+        const int leaf = single_leaf_symbol(tree);
+        if (leaf >= 0)
+            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)leaf, tree + 10, block_len, pay_bytes, gout,
+                                                      end_bits, produced_out);
     }
 
     /* ---- 1. tree ---- */
@@ -1056,8 +1102,13 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(con
         } else {
             const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
             uint64_t end_bits = 0, produced = 0;
-            err = decode_block<THREADS>(sh, stream + o0 + HUF_HEADER_FIXED, m.tree_len, m.block_len,
-                                        pay_bytes, out + obase, &end_bits, &produced);
+            const uint8_t *tree = stream + o0 + HUF_HEADER_FIXED;
+            if (m.leaf >= 0)                   /* decode_prepare has read the tree: straight to the fill */
+                err = decode_single_leaf<THREADS, true>(sh, (uint32_t)m.leaf, tree + 10, m.block_len, pay_bytes,
+                                                        out + obase, &end_bits, &produced);
+            else
+                err = decode_block<THREADS>(sh, tree, m.tree_len, m.block_len, pay_bytes, out + obase, &end_bits,
+                                            &produced);
         }
     }
     if (tid == 0 && err != m.status) {       /* header errors were recorded by decode_prepare */

@@ -192,6 +192,48 @@ def test_one_symbol_blocks_any_alignment(torch_mod, codec, oracle):
             assert err == oerr == 6 and raw == oout.size == 0
 
 
+def test_one_symbol_payload_stray_bits(torch_mod, codec, oracle):
+    """The payload of a one-symbol block is checked 16 bytes at a time for a set bit: first and last
+    needed bit, the pad bits behind them (ignored, decoder.c:89-91), any payload alignment, block
+    sizes around the byte and 16-byte edges - same error, byte count and bytes as the reference, by
+    the indexed kernel and by both raw-stream decoders."""
+    import ctypes as C
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    for bs in (1, 5, 8, 9, 127, 128, 129, 1000, 4099, 65536):
+        for lead in (0, 1, 2, 3, 7, 13):                 # an ordinary block in front shifts the alignment
+            parts = [rng.integers(0, 5, size=bs, dtype=np.uint8)] if lead else []
+            if lead:
+                parts[0][:lead] = 200                     # k and the payload length vary with `lead`
+            parts += [np.full(bs, 0x30 + i, np.uint8) for i in range(3)]
+            data = np.concatenate(parts)
+            good, offs = oracle.encode(data, bs, with_offsets=True)
+            b = len(parts) - 2                            # the one-symbol block in the middle
+            p0, p1 = int(offs[b]) + 20, int(offs[b + 1])
+            nbits = (p1 - p0) * 8
+            spots = {0, bs - 1, bs, bs + 1, nbits - 1, bs // 2, max(0, bs - 9), min(nbits - 1, 127), min(nbits - 1, 128)}
+            spots |= {int(x) for x in rng.integers(0, nbits, size=3)}
+            for bit in sorted(x for x in spots if 0 <= x < nbits):
+                bad = good.copy()
+                bad[p0 + bit // 8] |= 0x80 >> (bit % 8)
+                cap = data.size + 32
+                oerr, oout, _ = oracle.decode(bad, cap, 1024)
+                assert oerr == (6 if bit < bs else 0), (bs, lead, bit, oerr)
+                out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+                raw = C.c_uint64(0)
+                d_bad, d_offs = to_dev(torch, bad), torch.from_numpy(offs.astype(np.int64)).cuda()
+                err = codec.lib.hufgpu_decode(codec._ctx, d_bad.data_ptr(), bad.size, d_offs.data_ptr(), offs.size - 1,
+                                              out.data_ptr(), cap, 0, C.byref(raw), None)
+                want_raw = oout.size if oerr == 0 else b * bs        # indexed: the bytes in front of the failing block
+                assert (err, raw.value) == (oerr, want_raw), (bs, lead, bit, err, oerr, raw.value, want_raw)
+                assert np.array_equal(out[:oout.size].cpu().numpy(), oout), (bs, lead, bit)
+                for sequential in (False, True):
+                    out.zero_()
+                    err, n, _ = codec.decode_stream(to_dev(torch, bad), bad.size, bad.size, out, sequential=sequential)
+                    assert (err, n) == (oerr, oout.size), (bs, lead, bit, sequential, err, oerr, n, oout.size)
+                    assert np.array_equal(out[:n].cpu().numpy(), oout), (bs, lead, bit, sequential)
+
+
 def test_encode_deep_codes(torch_mod, codec, oracle):
     """Fibonacci-weighted inputs give the longest codes a block can have (22 bits at 64 KiB,
     >32 bits needs > 5.7 MB: exercised with one 8 MiB block)."""

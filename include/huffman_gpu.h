@@ -121,6 +121,7 @@ int hufgpu_malloc(hufgpu_ctx_t *ctx, void **d_ptr, uint64_t bytes);
 int hufgpu_free(hufgpu_ctx_t *ctx, void *d_ptr);
 int hufgpu_memcpy_h2d(hufgpu_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int hufgpu_memcpy_d2d(hufgpu_ctx_t *ctx, void *d_dst, const void *d_src, uint64_t bytes);
 int hufgpu_synchronize(hufgpu_ctx_t *ctx);
 
 /* Per-kernel timing. While enabled, every hufgpu_encode/hufgpu_decode call records HIP

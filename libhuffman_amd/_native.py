@@ -65,7 +65,7 @@ huf_tree_free huf_tree_from_histogram huf_tree_init huf_tree_reset huf_tree_seri
 GPU_SYMBOLS = """hufgpu_device_count hufgpu_ctx_create hufgpu_ctx_destroy hufgpu_last_error
 hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_decode
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
-hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_synchronize hufgpu_set_profiling
+hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_set_profiling
 hufgpu_get_profile huf_gpu_set_relaxed_tree huf_gpu_memwrap""".split()
 
 
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.hufgpu_free.argtypes = [vp, vp]
     L.hufgpu_memcpy_h2d.argtypes = [vp, vp, vp, u64]
     L.hufgpu_memcpy_d2h.argtypes = [vp, vp, vp, u64]
+    L.hufgpu_memcpy_d2d.argtypes = [vp, vp, vp, u64]
     L.hufgpu_synchronize.argtypes = [vp]
     L.hufgpu_set_profiling.argtypes = [vp, i32]
     L.hufgpu_get_profile.argtypes = [vp, i32, C.POINTER(C.c_float), i32, C.POINTER(i32), C.POINTER(i32)]

@@ -682,8 +682,8 @@ static int g_relaxed = -1;
 typedef struct {
     void *h_a, *h_b;           /* pinned staging */
     size_t h_a_cap, h_b_cap;
-    void *d_a, *d_b;           /* device staging */
-    size_t d_a_cap, d_b_cap;
+    void *d_a, *d_b, *d_c;     /* device staging (d_c: one round of a descriptor-fed decode) */
+    size_t d_a_cap, d_b_cap, d_c_cap;
 } staging_t;
 static staging_t g_stage;
 
@@ -821,33 +821,162 @@ static int zero_copy_enabled(void)
     return !(e && atoi(e) == 0);
 }
 
+/* ------------------------------------------------------------------ fd streams: I/O next to the GPU work
+ * A stream made by huf_fdopen() is this library's own object too: its read(2)/write(2) calls can
+ * run on a helper thread while the calling thread drives the GPU, in order and one at a time per
+ * descriptor.  Two pinned buffers per direction: the reader fills one while the other is encoded,
+ * the writer drains one while the next result arrives.  Streams with foreign
+ * callbacks are never touched from a helper thread (§8b: callbacks run serially on the caller's
+ * thread). */
+typedef struct {
+    pthread_t thread;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int started;
+    int fd;
+    int writer;              /* 0: fills the slots from fd, 1: drains them to fd */
+    char *buf[2];
+    size_t len[2];           /* bytes in the slot (reader: what the read returned) */
+    int full[2];             /* reader: filled, waiting for the consumer; writer: handed over, waiting for write(2) */
+    uint64_t remaining;      /* reader: bytes still to be requested */
+    size_t batch;            /* reader: bytes per request; writer: bytes a slot holds */
+    int eof_ok;              /* reader: the end of the input is the consumer's business (decode), not a failure */
+    int next;                /* writer: slot of the next fd_writer_push() piece */
+    int quit;                /* consumer/producer side is done (or gave up) */
+    huf_error_t err;
+} fd_worker_t;
+
+static void *fd_worker_main(void *arg)
+{
+    fd_worker_t *w = (fd_worker_t *)arg;
+    for (int k = 0;; k ^= 1) {
+        pthread_mutex_lock(&w->mu);
+        if (w->writer) {
+            while (!w->full[k] && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+            if (!w->full[k]) { pthread_mutex_unlock(&w->mu); break; }     /* quit and nothing handed over */
+        } else {
+            while (w->full[k] && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+            if (w->quit || !w->remaining) { pthread_mutex_unlock(&w->mu); break; }
+        }
+        pthread_mutex_unlock(&w->mu);
+        huf_error_t err = HUF_ERROR_SUCCESS;
+        size_t got = 0;
+        if (w->writer) {
+            if (w->err == HUF_ERROR_SUCCESS) err = fdwrite(&w->fd, w->buf[k], w->len[k]);   /* after a failure: drop */
+        } else {
+            got = w->remaining < w->batch ? (size_t)w->remaining : w->batch;
+            const size_t want = got;
+            err = fdread(&w->fd, w->buf[k], &got);
+            if (err == HUF_ERROR_SUCCESS && got < want && !w->eof_ok) err = HUF_ERROR_READ_WRITE;   /* bufio.c:251-253 */
+            w->remaining = (got < want) ? 0 : w->remaining - want;
+        }
+        pthread_mutex_lock(&w->mu);
+        if (err != HUF_ERROR_SUCCESS && w->err == HUF_ERROR_SUCCESS) w->err = err;
+        if (w->writer) w->full[k] = 0;
+        else { w->len[k] = got; w->full[k] = 1; }
+        pthread_cond_broadcast(&w->cv);
+        const int stop = !w->writer && (err != HUF_ERROR_SUCCESS || !w->remaining);
+        pthread_mutex_unlock(&w->mu);
+        if (stop) break;
+    }
+    return NULL;
+}
+
+static huf_error_t fd_worker_start(fd_worker_t *w)
+{
+    pthread_mutex_init(&w->mu, NULL);
+    pthread_cond_init(&w->cv, NULL);
+    if (pthread_create(&w->thread, NULL, fd_worker_main, w) != 0) return HUF_ERROR_MEMORY_ALLOCATION;
+    w->started = 1;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* the caller is done with the worker: a writer first drains what was handed over */
+static huf_error_t fd_worker_finish(fd_worker_t *w)
+{
+    if (!w->started) return HUF_ERROR_SUCCESS;
+    pthread_mutex_lock(&w->mu);
+    w->quit = 1;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+    pthread_join(w->thread, NULL);
+    pthread_mutex_destroy(&w->mu);
+    pthread_cond_destroy(&w->cv);
+    w->started = 0;
+    return w->err;
+}
+
+/* reader slot k: wait for its bytes (a short or failed read is reported with the slot it hit) */
+static huf_error_t fd_reader_wait(fd_worker_t *w, int k, size_t want)
+{
+    pthread_mutex_lock(&w->mu);
+    while (!w->full[k]) pthread_cond_wait(&w->cv, &w->mu);
+    const huf_error_t err = (w->len[k] < want) ? (w->err != HUF_ERROR_SUCCESS ? w->err : HUF_ERROR_READ_WRITE)
+                                                : HUF_ERROR_SUCCESS;
+    pthread_mutex_unlock(&w->mu);
+    return err;
+}
+
+static void fd_reader_release(fd_worker_t *w, int k)
+{
+    pthread_mutex_lock(&w->mu);
+    w->full[k] = 0;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+}
+
+/* writer slot k: wait until its previous content is on the descriptor */
+static huf_error_t fd_writer_wait(fd_worker_t *w, int k)
+{
+    pthread_mutex_lock(&w->mu);
+    while (w->full[k]) pthread_cond_wait(&w->cv, &w->mu);
+    const huf_error_t err = w->err;
+    pthread_mutex_unlock(&w->mu);
+    return err;
+}
+
+static void fd_writer_submit(fd_worker_t *w, int k, size_t len)
+{
+    pthread_mutex_lock(&w->mu);
+    w->len[k] = len;
+    w->full[k] = 1;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+}
+
+/* len bytes at d_src -> the descriptor, through the slots (a piece per slot) */
+static huf_error_t fd_writer_push(fd_worker_t *w, const void *d_src, uint64_t len)
+{
+    const char *p = (const char *)d_src;
+    while (len) {
+        const size_t n = len < w->batch ? (size_t)len : w->batch;
+        const int k = w->next;
+        TRY(fd_writer_wait(w, k));
+        TRY(hufgpu_memcpy_d2h(g_ctx, w->buf[k], p, n));
+        fd_writer_submit(w, k, n);
+        w->next ^= 1;
+        p += n;
+        len -= n;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+static int own_fd_of(const huf_read_writer_t *rw, int writer)
+{
+    if (!rw || !rw->stream) return -1;
+    if (writer ? rw->write != fdwrite : rw->read != fdread) return -1;
+    return *(const int *)rw->stream;
+}
+
 /* ------------------------------------------------------------------ huf_encode (src/encoder.c:261-388) */
-static huf_error_t encode_locked(huf_encoder_t *enc)
+static huf_error_t encode_rounds(huf_encoder_t *enc, uint64_t batch, membuf_t *rmem, membuf_t *wmem,
+                                 fd_worker_t *rd, fd_worker_t *wr)
 {
     const uint64_t length = enc->config->length;
     const uint64_t blocksize = enc->config->blocksize;
-    if (blocksize > HUFGPU_MAX_BLOCK) {
-        fprintf(stderr, "libhuffman: blocksize %llu exceeds the GPU kernel limit (%llu)\n",
-                (unsigned long long)blocksize, (unsigned long long)HUFGPU_MAX_BLOCK);
-        return HUF_ERROR_INVALID_ARGUMENT;
-    }
-    TRY(session_acquire());
-
-    const char *env = getenv("HUF_GPU_BATCH_MB");
-    uint64_t batch = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : 256) << 20;
-    if (batch < blocksize) batch = blocksize;
-    batch -= batch % blocksize;                   /* whole blocks per round */
-    if (batch > length) batch = length;
-
     const uint64_t bound = hufgpu_encode_bound(batch, blocksize);
-    membuf_t *rmem = zero_copy_enabled() ? own_memstream_reader(enc->config->reader) : NULL;
-    membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(enc->config->writer) : NULL;
-    if (!rmem) TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, batch));
-    if (!wmem) TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, bound));
-    TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, batch));
-    TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound));
-
-    for (uint64_t done = 0; done < length;) {
+    int round = 0;
+    for (uint64_t done = 0; done < length; round ^= 1) {
         const uint64_t take = (length - done < batch) ? length - done : batch;
         /* one large read per round; a short read is an error exactly like the reference's
          * block read (src/encoder.c:296, src/bufio.c:251-253) */
@@ -858,6 +987,10 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
             }
             TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, (const char *)*rmem->buf + rmem->off, take));
             rmem->off += take;
+        } else if (rd->started) {
+            TRY(fd_reader_wait(rd, round, take));
+            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rd->buf[round], take));
+            fd_reader_release(rd, round);                       /* the next read starts under the encode */
         } else {
             TRY(huf_bufio_read(enc->bufio_reader, g_stage.h_a, take));
             TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take));
@@ -869,13 +1002,74 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
             TRY(mem_reserve(wmem, out_len));
             TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, out_len));
             wmem->len += out_len;
+        } else if (wr->started) {
+            TRY(fd_writer_push(wr, g_stage.d_b, out_len));      /* waits for the write of two rounds ago */
         } else {
             TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, out_len));
             TRY(huf_bufio_write(enc->bufio_writer, g_stage.h_b, out_len));
         }
         done += take;
     }
-    return huf_bufio_read_writer_flush(enc->bufio_writer);   /* encoder.c:377 */
+    (void)bound;
+    return HUF_ERROR_SUCCESS;
+}
+
+static huf_error_t encode_locked(huf_encoder_t *enc)
+{
+    const uint64_t length = enc->config->length;
+    const uint64_t blocksize = enc->config->blocksize;
+    if (blocksize > HUFGPU_MAX_BLOCK) {
+        fprintf(stderr, "libhuffman: blocksize %llu exceeds the GPU kernel limit (%llu)\n",
+                (unsigned long long)blocksize, (unsigned long long)HUFGPU_MAX_BLOCK);
+        return HUF_ERROR_INVALID_ARGUMENT;
+    }
+    TRY(session_acquire());
+
+    membuf_t *rmem = zero_copy_enabled() ? own_memstream_reader(enc->config->reader) : NULL;
+    membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(enc->config->writer) : NULL;
+    const int rfd = (rmem || !zero_copy_enabled()) ? -1 : own_fd_of(enc->config->reader, 0);
+    const int wfd = (wmem || !zero_copy_enabled()) ? -1 : own_fd_of(enc->config->writer, 1);
+
+    /* bytes per round: whole blocks; smaller rounds when descriptor I/O runs next to the GPU
+     * (the first read and the last write are not hidden) */
+    const char *env = getenv("HUF_GPU_BATCH_MB");
+    uint64_t batch = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : ((rfd >= 0 || wfd >= 0) ? 32 : 256)) << 20;
+    if (batch < blocksize) batch = blocksize;
+    batch -= batch % blocksize;
+    if (batch > length) batch = length;
+
+    const uint64_t bound = hufgpu_encode_bound(batch, blocksize);
+    if (!rmem) TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, rfd >= 0 ? 2 * batch : batch));
+    if (!wmem) TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, wfd >= 0 ? 2 * bound : bound));
+    TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, batch));
+    TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound));
+
+    fd_worker_t rd, wr;
+    memset(&rd, 0, sizeof(rd));
+    memset(&wr, 0, sizeof(wr));
+    huf_error_t err = HUF_ERROR_SUCCESS;
+    if (rfd >= 0) {
+        rd.fd = rfd;
+        rd.buf[0] = (char *)g_stage.h_a;
+        rd.buf[1] = (char *)g_stage.h_a + batch;
+        rd.remaining = length;
+        rd.batch = (size_t)batch;
+        err = fd_worker_start(&rd);
+    }
+    if (wfd >= 0 && err == HUF_ERROR_SUCCESS) {
+        wr.fd = wfd;
+        wr.writer = 1;
+        wr.buf[0] = (char *)g_stage.h_b;
+        wr.buf[1] = (char *)g_stage.h_b + bound;
+        wr.batch = (size_t)bound;
+        err = fd_worker_start(&wr);
+    }
+    if (err == HUF_ERROR_SUCCESS) err = encode_rounds(enc, batch, rmem, wmem, &rd, &wr);
+    (void)fd_worker_finish(&rd);                                  /* its failures surfaced with their round */
+    const huf_error_t werr = fd_worker_finish(&wr);               /* results of complete rounds still go out */
+    if (err == HUF_ERROR_SUCCESS) err = werr;
+    if (err != HUF_ERROR_SUCCESS) return err;
+    return huf_bufio_read_writer_flush(enc->bufio_writer);        /* encoder.c:377 */
 }
 
 huf_error_t huf_encode(const huf_config_t *config)
@@ -907,11 +1101,164 @@ static huf_error_t read_upto(huf_read_writer_t *rw, uint8_t *dst, size_t want, s
     return HUF_ERROR_SUCCESS;
 }
 
+/* like grow_dev(), but the first `keep` bytes survive */
+static huf_error_t grow_dev_keep(void **p, size_t *cap, size_t want, size_t keep)
+{
+    if (*cap >= want) return HUF_ERROR_SUCCESS;
+    void *bigger = NULL;
+    TRY(hufgpu_malloc(g_ctx, &bigger, want));
+    if (keep) {
+        const int rc = hufgpu_memcpy_d2d(g_ctx, bigger, *p, keep);
+        if (rc != HUF_ERROR_SUCCESS) { hufgpu_free(g_ctx, bigger); return (huf_error_t)rc; }
+    }
+    if (*p) hufgpu_free(g_ctx, *p);
+    *p = bigger;
+    *cap = want;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* the helper thread's next piece (it asked for `want` bytes) -> behind the `*loaded` stream bytes on the device */
+static huf_error_t fd_reader_to_device(fd_worker_t *rd, int *rslot, uint64_t want, uint64_t *loaded, int *eof)
+{
+    const int k = *rslot;
+    pthread_mutex_lock(&rd->mu);
+    while (!rd->full[k]) pthread_cond_wait(&rd->cv, &rd->mu);
+    const size_t got = rd->len[k];
+    const huf_error_t rerr = rd->err;
+    pthread_mutex_unlock(&rd->mu);
+    if (rerr != HUF_ERROR_SUCCESS) return rerr;
+    TRY(hufgpu_memcpy_h2d(g_ctx, (char *)g_stage.d_a + *loaded, rd->buf[k], got));
+    fd_reader_release(rd, k);
+    *rslot = k ^ 1;
+    *loaded += got;
+    if (got < want) *eof = 1;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* Decode with the input on a huf_fdopen() descriptor: the file is read by a helper thread in
+ * pieces that go to the device as they arrive, and the stream is decoded in rounds of `piece`
+ * compressed bytes - the block loop of src/decoder.c:218 cut at block boundaries: a round starts
+ * where the previous one stopped and runs while fewer than its share of bytes is consumed, which
+ * is the reference's loop condition with more check points.  Each round's output leaves through
+ * the writer (a helper thread as well when that is a descriptor) while the next pieces are read
+ * and decoded.  A round whose last block needs bytes that are not there yet is repeated once
+ * they are; past `length` the descriptor is asked for more like the reference's on-demand reads. */
+static huf_error_t decode_rounds_fd(huf_decoder_t *dec, fd_worker_t *rd, membuf_t *wmem, fd_worker_t *wr,
+                                    uint64_t piece, uint32_t flags)
+{
+    const uint64_t length = dec->config->length;
+    const uint64_t margin = 4u << 20;            /* what a round may look ahead before it is worth starting */
+    uint64_t loaded = 0;                         /* bytes of the stream on the device (g_stage.d_a) */
+    uint64_t requested = 0;                      /* of `length`, by the helper thread */
+    int rslot = 0, eof = 0;
+    uint64_t pos = 0;
+    uint64_t out_cap = (piece + margin) * 8 + (1u << 20);
+    TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, (size_t)length + 16));
+
+    while (pos < length) {
+        const uint64_t round_len = (length - pos < piece) ? length - pos : piece;
+        /* input up to the round's end plus the margin, or all there is */
+        while (!eof && requested < length && loaded < pos + round_len + margin) {
+            TRY(fd_reader_to_device(rd, &rslot, (length - requested < piece) ? length - requested : piece, &loaded, &eof));
+            requested = (length - requested < piece) ? length : requested + piece;
+        }
+        const uint64_t avail = loaded - pos;
+        /* the round's bytes at an aligned address (the parallel block discovery wants that) */
+        TRY(grow_dev(&g_stage.d_c, &g_stage.d_c_cap, (size_t)avail + 16));
+        TRY(hufgpu_memcpy_d2d(g_ctx, g_stage.d_c, (const char *)g_stage.d_a + pos, avail));
+        TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, out_cap));
+        uint64_t raw = 0, used = 0;
+        int rc = hufgpu_decode_stream(g_ctx, g_stage.d_c, avail, round_len, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
+        if (rc == HUF_ERROR_MEMORY_ALLOCATION && out_cap < ((uint64_t)1 << 40)) {   /* output did not fit: enlarge */
+            out_cap *= 4;
+            continue;
+        }
+        if (rc == HUF_ERROR_READ_WRITE) {
+            if (!eof && requested < length) {            /* more of the stream is on its way: take a piece, again */
+                TRY(fd_reader_to_device(rd, &rslot, (length - requested < piece) ? length - requested : piece, &loaded, &eof));
+                requested = (length - requested < piece) ? length : requested + piece;
+                continue;
+            }
+            if (!eof) {                                   /* maybe the descriptor holds more than `length` */
+                const size_t more_want = loaded < 65536 ? 65536 : (size_t)loaded;
+                TRY(grow_dev_keep(&g_stage.d_a, &g_stage.d_a_cap, (size_t)loaded + more_want + 16, (size_t)loaded));
+                size_t more = 0;
+                while (more < more_want) {                /* the helper thread has finished: read here */
+                    size_t n = more_want - more < rd->batch ? more_want - more : rd->batch;
+                    const size_t asked = n;
+                    TRY(fdread(&rd->fd, rd->buf[0], &n));
+                    TRY(hufgpu_memcpy_h2d(g_ctx, (char *)g_stage.d_a + loaded + more, rd->buf[0], n));
+                    more += n;
+                    if (n < asked) { eof = 1; break; }
+                }
+                loaded += more;
+                if (more) continue;
+            }
+        }
+        /* bytes of the blocks that decoded completely are delivered even when a later block
+         * fails, as the reference's unbuffered writer would have done */
+        if (raw && wmem) {
+            TRY(mem_reserve(wmem, raw));
+            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, raw));
+            wmem->len += raw;
+        } else if (raw && wr->started) {
+            TRY(fd_writer_push(wr, g_stage.d_b, raw));
+        } else if (raw) {
+            TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, raw));
+            TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, raw));
+            TRY(huf_bufio_write(dec->bufio_writer, g_stage.h_b, raw));
+        }
+        if (rc != HUF_ERROR_SUCCESS) return (huf_error_t)rc;
+        pos += used;
+    }
+    return HUF_ERROR_SUCCESS;
+}
+
+static huf_error_t decode_from_fd(huf_decoder_t *dec, int rfd, membuf_t *wmem, int wfd, uint32_t flags)
+{
+    const uint64_t length = dec->config->length;
+    const char *env = getenv("HUF_GPU_BATCH_MB");
+    uint64_t piece = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : 32) << 20;
+    if (piece > length) piece = length;
+    if (piece < 65536) piece = 65536;                             /* also the size of the reads past `length` */
+    TRY(grow_host(&g_stage.h_a, &g_stage.h_a_cap, 2 * piece));
+    if (wfd >= 0) TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, 2 * piece));
+
+    fd_worker_t rd, wr;
+    memset(&rd, 0, sizeof(rd));
+    memset(&wr, 0, sizeof(wr));
+    rd.fd = rfd;
+    rd.buf[0] = (char *)g_stage.h_a;
+    rd.buf[1] = (char *)g_stage.h_a + piece;
+    rd.remaining = length;
+    rd.batch = (size_t)piece;
+    rd.eof_ok = 1;
+    huf_error_t err = fd_worker_start(&rd);
+    if (wfd >= 0 && err == HUF_ERROR_SUCCESS) {
+        wr.fd = wfd;
+        wr.writer = 1;
+        wr.buf[0] = (char *)g_stage.h_b;
+        wr.buf[1] = (char *)g_stage.h_b + piece;
+        wr.batch = (size_t)piece;
+        err = fd_worker_start(&wr);
+    }
+    if (err == HUF_ERROR_SUCCESS) err = decode_rounds_fd(dec, &rd, wmem, &wr, piece, flags);
+    (void)fd_worker_finish(&rd);
+    const huf_error_t werr = fd_worker_finish(&wr);               /* what was delivered before a failure still goes out */
+    if (err == HUF_ERROR_SUCCESS) err = werr;
+    if (err != HUF_ERROR_SUCCESS) return err;                     /* no flush on the error path (decoder.c:278-286) */
+    return huf_bufio_read_writer_flush(dec->bufio_writer);
+}
+
 static huf_error_t decode_locked(huf_decoder_t *dec)
 {
     const uint64_t length = dec->config->length;
     TRY(session_acquire());
     const uint32_t flags = relaxed_tree() ? HUFGPU_RELAXED_TREE : HUFGPU_STRICT_TREE;
+    if (zero_copy_enabled() && own_fd_of(dec->config->reader, 0) >= 0) {
+        membuf_t *wm = own_memstream_writer(dec->config->writer);
+        return decode_from_fd(dec, own_fd_of(dec->config->reader, 0), wm, wm ? -1 : own_fd_of(dec->config->writer, 1), flags);
+    }
 
     /* The reference pulls bytes on demand and may run past `length` to finish the last block
      * (src/decoder.c:218); here: take `length` bytes, and if the device reports that a block

@@ -691,6 +691,16 @@ extern "C" int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_s
     return HUFE_OK;
 }
 
+extern "C" int hufgpu_memcpy_d2d(hufgpu_ctx_t *ctx, void *d_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (!bytes) return HUFE_OK;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return HUFE_OK;
+}
+
 extern "C" int hufgpu_synchronize(hufgpu_ctx_t *ctx)
 {
     if (!ctx) return HUFE_ARGUMENT;

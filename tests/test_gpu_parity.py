@@ -5,6 +5,7 @@ with (a) the golden vectors captured from the unmodified reference, (b) the CPU 
 same seeded input.  Bit-exact everywhere - the codec is pure integer/byte work.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -473,6 +474,127 @@ def test_self_synchronisation_worst_cases(torch_mod, codec, oracle):
         stream, offs = oracle.encode(data, 65536, with_offsets=True)
         back = gpu_decode_indexed(torch_mod, codec, stream, offs, data.size)
         assert np.array_equal(back, data), first_diff(back, data)
+
+
+def test_c_api_fd_streams(torch_mod, oracle, tmp_path, monkeypatch):
+    """huf_fdopen streams (src/io.c:9-63): their read(2)/write(2) run on helper threads next to the
+    GPU work, two rounds in flight.  Same bytes as the reference for file -> file, file -> memory,
+    memory -> file and a pipe; a short input fails with error 3 after the complete rounds went
+    out; a descriptor that cannot be written fails with error 3; decode file -> file restores."""
+    import ctypes as C
+    import threading
+    from libhuffman_amd import _native as N
+    L = N.load()
+    monkeypatch.setenv("HUF_GPU_BATCH_MB", "1")           # many rounds on a small input
+    bs = 65536
+    data = datagen.zipf255(5 * (1 << 20) + 12345)
+    want = oracle.encode(data, bs)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data.tobytes())
+
+    def fdopen(fd):
+        rw = C.POINTER(N.ReadWriter)()
+        assert L.huf_fdopen(C.byref(rw), fd) == 0
+        return rw
+
+    def memopen(cap=16):
+        rw, buf = C.POINTER(N.ReadWriter)(), C.c_void_p()
+        assert L.huf_memopen(C.byref(rw), C.byref(buf), cap) == 0
+        return rw, buf
+
+    def memcontent(rw, buf):
+        n = C.c_size_t()
+        L.huf_memlen(rw, C.byref(n))
+        return C.string_at(buf.value, n.value)
+
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    # file -> file
+    fin, fout = os.open(src, os.O_RDONLY), os.open(tmp_path / "out.hm", os.O_CREAT | os.O_RDWR | os.O_TRUNC)
+    rin, rout = fdopen(fin), fdopen(fout)
+    assert L.huf_encode(C.byref(N.Config(data.size, bs, 0, 0, rin, rout))) == 0
+    assert (tmp_path / "out.hm").read_bytes() == want.tobytes()
+    assert os.lseek(fin, 0, os.SEEK_CUR) == data.size
+    # decode file -> file
+    os.lseek(fout, 0, os.SEEK_SET)
+    fback = os.open(tmp_path / "back.bin", os.O_CREAT | os.O_RDWR | os.O_TRUNC)
+    rback = fdopen(fback)
+    assert L.huf_decode(C.byref(N.Config(want.size, 0, 0, 0, rout, rback))) == 0
+    assert (tmp_path / "back.bin").read_bytes() == data.tobytes()
+    for rw, fd in ((rin, fin), (rout, fout), (rback, fback)):
+        L.huf_fdclose(C.byref(rw)); os.close(fd)
+
+    # decode in rounds (1 MiB of stream each) against the reference on damaged and cut streams:
+    # error, delivered bytes; a `length` inside a block finishes that block (decoder.c:218)
+    cases = [("cut mid-block", want[: want.size - 777], want.size - 777),
+             ("length mid-block", want, int(want.size * 0.6)),
+             ("length = 1", want, 1),
+             ("trailing garbage", np.concatenate([want, np.frombuffer(b"\x01" * 40, np.uint8)]), want.size + 40)]
+    for spot in (100, want.size // 3, want.size - 5000):
+        bad = want.copy()
+        bad[spot] = 0xff
+        cases.append((f"damaged byte {spot}", bad, want.size))
+    for name, stream, length in cases:
+        (tmp_path / "case.hm").write_bytes(stream.tobytes())
+        oerr, oout, _ = oracle.decode(stream, data.size + 64, 1024, length=length)
+        fin, fout = os.open(tmp_path / "case.hm", os.O_RDONLY), os.open(tmp_path / "case.out", os.O_CREAT | os.O_RDWR | os.O_TRUNC)
+        rin, rout = fdopen(fin), fdopen(fout)
+        err = L.huf_decode(C.byref(N.Config(length, 0, 0, 0, rin, rout)))
+        got = (tmp_path / "case.out").read_bytes()
+        assert err == oerr and got == oout.tobytes(), (name, err, oerr, len(got), oout.size)
+        for rw, fd in ((rin, fin), (rout, fout)):
+            L.huf_fdclose(C.byref(rw)); os.close(fd)
+
+    # file -> memory, memory -> file
+    fin = os.open(src, os.O_RDONLY)
+    rin = fdopen(fin)
+    rmem, bmem = memopen()
+    assert L.huf_encode(C.byref(N.Config(data.size, bs, 0, 0, rin, rmem))) == 0
+    assert memcontent(rmem, bmem) == want.tobytes()
+    L.huf_fdclose(C.byref(rin)); os.close(fin)
+    fin = os.open(tmp_path / "out.hm", os.O_RDONLY)          # decode file -> memory
+    rin = fdopen(fin)
+    rdec, bdec = memopen()
+    assert L.huf_decode(C.byref(N.Config(want.size, 0, 0, 0, rin, rdec))) == 0
+    assert memcontent(rdec, bdec) == data.tobytes()
+    L.huf_fdclose(C.byref(rin)); os.close(fin)
+    L.huf_memclose(C.byref(rdec)); libc.free(bdec)
+    rsrc, bsrc = memopen()
+    assert rsrc.contents.write(rsrc.contents.stream, data.ctypes.data_as(C.c_void_p), data.size) == 0
+    fout = os.open(tmp_path / "out2.hm", os.O_CREAT | os.O_RDWR | os.O_TRUNC)
+    rout = fdopen(fout)
+    assert L.huf_encode(C.byref(N.Config(data.size, bs, 0, 0, rsrc, rout))) == 0
+    assert (tmp_path / "out2.hm").read_bytes() == want.tobytes()
+    L.huf_fdclose(C.byref(rout)); os.close(fout)
+    for rw, b in ((rmem, bmem), (rsrc, bsrc)):
+        L.huf_memclose(C.byref(rw)); libc.free(b)
+
+    # pipe -> memory: reads come back in pieces
+    pr, pw = os.pipe()
+    feeder = threading.Thread(target=lambda: (os.write(pw, data.tobytes()), os.close(pw)))
+    feeder.start()
+    rin = fdopen(pr)
+    rmem, bmem = memopen()
+    assert L.huf_encode(C.byref(N.Config(data.size, bs, 0, 0, rin, rmem))) == 0
+    feeder.join()
+    assert memcontent(rmem, bmem) == want.tobytes()
+    L.huf_fdclose(C.byref(rin)); os.close(pr)
+    L.huf_memclose(C.byref(rmem)); libc.free(bmem)
+
+    # the input ends early: error 3, the complete rounds (1 MiB each) are on the descriptor
+    fin, fout = os.open(src, os.O_RDONLY), os.open(tmp_path / "short.hm", os.O_CREAT | os.O_RDWR | os.O_TRUNC)
+    rin, rout = fdopen(fin), fdopen(fout)
+    assert L.huf_encode(C.byref(N.Config(data.size + 1000, bs, 0, 0, rin, rout))) == 3
+    assert (tmp_path / "short.hm").read_bytes() == oracle.encode(data[: 5 << 20], bs).tobytes()
+    L.huf_fdclose(C.byref(rout)); os.close(fout)
+    # a descriptor that takes no writes: error 3
+    os.lseek(fin, 0, os.SEEK_SET)
+    fro = os.open(tmp_path / "short.hm", os.O_RDONLY)
+    rout = fdopen(fro)
+    assert L.huf_encode(C.byref(N.Config(data.size, bs, 0, 0, rin, rout))) == 3
+    for rw, fd in ((rin, fin), (rout, fro)):
+        L.huf_fdclose(C.byref(rw)); os.close(fd)
 
 
 def test_c_api_roundtrip_readme_example(torch_mod, golden):

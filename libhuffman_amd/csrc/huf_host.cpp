@@ -12,9 +12,12 @@
  *
  * Environment (huf_config_t's 48-byte layout is ABI, so switches live outside it):
  *   HUF_GPU_DEVICE        device ordinal (default 0)
- *   HUF_GPU_BATCH_MB      input bytes staged per GPU round in huf_encode (default 256)
+ *   HUF_GPU_BATCH_MB      MiB per GPU round: input of huf_encode (default 256; 32 when a
+ *                         huf_fdopen() descriptor is read or written under the GPU work), stream
+ *                         bytes of a huf_decode that reads a huf_fdopen() descriptor (default 32)
  *   HUF_GPU_ZERO_COPY     0 = always go through the streams' read/write callbacks (default 1:
- *                         huf_memopen() streams are copied to/from the device directly)
+ *                         huf_memopen() streams are copied to/from the device directly and
+ *                         huf_fdopen() descriptors are read/written by helper threads)
  *   HUF_GPU_RELAXED_TREE  1 = accept 1025-entry trees on decode
  */
 #include <errno.h>

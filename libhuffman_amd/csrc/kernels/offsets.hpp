@@ -150,7 +150,7 @@ __device__ __forceinline__ uint64_t handover_load(const uint64_t *p)
  * anything that follows is issued - in particular the ticket.  A workgroup-scope fence is NOT
  * enough: without threadgroup-split mode the compiler lowers it to s_waitcnt lgkmcnt(0) only,
  * and the ticket (another address, another L2 channel) can then overtake the value it
- * announces - tools/soak.py caught exactly that as one wrong block index in ~6 000 runs with
+ * announces - tests/stress/soak.py caught exactly that as one wrong block index in ~6 000 runs with
  * thousands of 64-byte blocks. */
 __device__ __forceinline__ void handover_fence()
 {

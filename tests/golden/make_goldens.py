@@ -4,7 +4,7 @@ built from /root/reference/src by `make -C oracle ref`) into tests/golden/vector
 
 Runs only in the authoring container (the reference does not exist on the GPU box); the JSON
 it writes is data: inputs (literal bytes or generator parameters) and expected outputs (hex
-for small streams, sha256 + length for large ones).  Re-run:  python tools/make_goldens.py
+for small streams, sha256 + length for large ones).  Re-run:  python tests/golden/make_goldens.py
 """
 import hashlib
 import json
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from libhuffman_amd import datagen  # noqa: E402
 from oracle.oracle import Reference, build  # noqa: E402
@@ -26,7 +26,7 @@ def sha(b) -> str:
 def main() -> None:
     build(ref=True)
     ref = Reference()
-    vectors = {"_about": "captured from the unmodified reference by tools/make_goldens.py",
+    vectors = {"_about": "captured from the unmodified reference by tests/golden/make_goldens.py",
                "encode_small": [], "encode_large": [], "decode_errors": [], "decode_ok": []}
 
     # ---- small streams, stored whole (hex) ------------------------------------------

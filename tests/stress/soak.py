@@ -1,7 +1,7 @@
 """Randomised soak of the GPU codec against the oracle (not part of the pytest suite: minutes long).
-usage: python tools/soak.py [seconds] [seed]"""
+usage: python tests/stress/soak.py [seconds] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libhuffman_amd.codec import GpuCodec
 from oracle.oracle import Oracle

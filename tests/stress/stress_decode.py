@@ -1,7 +1,7 @@
 """Repeats indexed and raw-stream decodes of alternating inputs and checks every output (races in the
 decode kernels would show up as rare mismatches).  usage: stress_decode.py [seconds]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libhuffman_amd import datagen
 from libhuffman_amd.codec import GpuCodec

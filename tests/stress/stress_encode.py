@@ -1,7 +1,7 @@
 """Many encodes of randomly shaped inputs, each compared with the oracle (bytes and block index);
 every case is encoded several times in a row to expose races.  usage: stress_encode.py [seconds] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libhuffman_amd.codec import GpuCodec
 from oracle.oracle import Oracle

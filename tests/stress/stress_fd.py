@@ -1,8 +1,8 @@
 """Stress of the huf_fdopen paths (helper-thread I/O): random sizes, block sizes, round sizes, files
 and pipes on either side (pipes deliver in odd pieces and block), encode checked against the
-oracle, decode against the input.  Usage: python tools/stress_fd.py [seconds] [seed]"""
+oracle, decode against the input.  Usage: python tests/stress/stress_fd.py [seconds] [seed]"""
 import ctypes as C, os, sys, tempfile, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libhuffman_amd import _native as N, datagen
 from oracle.oracle import Oracle

@@ -1,7 +1,7 @@
 """Hammers the in-kernel prefix sums (two-level tickets): many tiny blocks, many launches, every
-block index compared with the oracle's.  usage: python tools/stress_offsets.py [launches]"""
+block index compared with the oracle's.  usage: python tests/stress/stress_offsets.py [launches]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libhuffman_amd.codec import GpuCodec
 from oracle.oracle import Oracle

@@ -385,7 +385,7 @@ def test_block_offsets_across_groups(torch_mod, codec, oracle, nblocks, bs):
 def test_block_index_alternating_inputs(torch_mod, codec, oracle):
     """Two inputs of the same shape but different block sizes, encoded alternately: a block size
     left over from the previous launch (the ticket of the in-kernel prefix sum overtaking the
-    value it announces - tools/stress_encode.py found 3 such launches in 300 000 before the
+    value it announces - tests/stress/stress_encode.py found 3 such launches in 300 000 before the
     s_waitcnt fix) would show up as a wrong index entry.  A cheap guard, not a proof."""
     torch = torch_mod
     rng = np.random.default_rng(99)
@@ -435,7 +435,7 @@ def test_payload_walk_leaves_tree_mid_block(torch_mod, codec, oracle, kind):
 
 
 def test_damaged_block_len_fields(torch_mod, codec, oracle):
-    """A block_len larger than the block really is (found by tools/soak.py): far beyond what the
+    """A block_len larger than the block really is (found by tests/stress/soak.py): far beyond what the
     payload can hold -> decode what is there, then error 3 like the reference's reader at the end
     of its input; a little too large -> the walk runs into the next header and fails there (6 or
     3) - also when the claimed length would not fit the caller's output buffer."""

@@ -257,6 +257,29 @@ def test_encode_deep_codes(torch_mod, codec, oracle):
         assert np.array_equal(back, data), (limit, first_diff(back, data))
 
 
+def test_blocks_of_4_mib_and_more(torch_mod, codec, oracle):
+    """Blocks >= 4 MiB take the unfused kernels (hist256 -> tree with 64-bit keys -> scan_sizes ->
+    pack): several such blocks, a one-symbol block among them, a ragged tail; and the block sizes
+    just below the switch and around the 16-bit counter limit of the fused kernel (128 KiB)."""
+    torch = torch_mod
+    for bs in ((5 << 20) + 3, 4 << 20, (4 << 20) - 1, 131072, 131073):
+        nblk = 3 if bs >= (4 << 20) - 1 else 5
+        parts = [datagen.zipf255(bs), np.full(bs, 0x5a, np.uint8)]
+        parts += [datagen.uniform256(bs) for _ in range(nblk - 2)]
+        parts.append(datagen.zipf255(bs // 3 + 7))
+        data = np.concatenate(parts)
+        want, woffs = oracle.encode(data, bs, with_offsets=True)
+        out, offs = gpu_encode(torch, codec, data, bs)
+        assert np.array_equal(out, want), (bs, first_diff(out, want))
+        assert np.array_equal(offs, woffs), bs
+        back = gpu_decode_indexed(torch, codec, out, offs, data.size, relaxed=True)
+        assert np.array_equal(back, data), (bs, first_diff(back, data))
+        o = torch.empty(data.size + 8, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(to_dev(torch, out), out.size, out.size, o, relaxed=True)
+        assert (err, raw, used) == (0, data.size, out.size), bs
+        assert torch.equal(o[:raw], to_dev(torch, data)), bs
+
+
 @pytest.mark.parametrize("kind,n,bs", [("const41", 262144, 65536), ("uniform256", 262144, 65536),
                                        ("uniform255", 262144, 65536), ("zipf255", 262144, 65536),
                                        ("zipf255", 2 << 20, 1 << 20), ("logtext", 2 << 20, 1 << 20),

@@ -256,6 +256,9 @@ def main() -> None:
             traffic = None
         pipeline_bytes = 2 * (n + comp_len)
         gpu_ms = ev0.elapsed_time(ev1) / K
+        # encode-only / decode-only: this rank's bytes over the kernels of each half
+        enc_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in enc_prof)
+        dec_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in dec_prof)
         result = {
             "metric": "encode+decode GiB/s (uncompressed) on %s blocks" % ("64KiB" if bs == 65536 else "%dKiB" % (bs >> 10)),
             "value": round(value, 3),
@@ -278,16 +281,26 @@ def main() -> None:
                          "alg_bytes_per_launch": alg[dom],
                          "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
+            "encode_only_GiBps_per_gpu": round(n / GIB / (enc_ms / 1e3), 1) if enc_ms > 0 else None,
+            "decode_only_GiBps_per_gpu": round(n / GIB / (dec_ms / 1e3), 1) if dec_ms > 0 else None,
             "gpu_ms_per_step_rank0": round(gpu_ms, 4),
             "profiled_steps": max(enc_calls, dec_calls),
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, bs)
-        print(json.dumps(result), flush=True)
 
+    # RCCL writes its version banner through C stdio, which a pipe only sees when a process exits:
+    # every rank pushes its buffer out before the last barrier, so that rank 0's JSON line is the
+    # last line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -814,40 +814,59 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     }
     __syncthreads();
     const int eff = (int)uni32((uint32_t)sh.efflen);
-    /* Child links from subtree sizes: size(marker) = 1, size(node) = 1 + size(left) + size(right),
-     * left child of node j is entry j+1, right child is entry j+1+size(j+1); entries at or past
-     * `eff` do not exist (size 0, NULL).  Sizes become known bottom-up, one tree level per round
-     * (s_open is reused as the size array, 0 = not known yet). */
-    __syncthreads();
-    uint16_t *s_size = s_open;
-    for (int i = tid; i < ENT; i += THREADS) s_size[i] = (i < eff && sh.ent[i] == -1) ? 1 : 0;
-    __syncthreads();
-    for (int round = 0; round < ENT; round++) {
-        int progress = 0;
-        for (int j = tid; j < eff; j += THREADS) {
-            if (s_size[j] != 0) continue;                 /* marker or already done */
-            const int l = j + 1;
-            uint32_t sl = 0, sr = 0;
-            bool ready = true;
-            if (l < eff) {
-                sl = s_size[l];
-                if (sl == 0) ready = false;
-                else {
-                    const int r = l + (int)sl;
-                    if (r < eff) {
-                        sr = s_size[r];
-                        if (sr == 0) ready = false;
-                        else if (sh.ent[r] != -1) sh.right[j] = (uint16_t)r;
-                    }
-                }
-                if (ready && sh.ent[l] != -1) sh.left[j] = (uint16_t)l;
-            }
-            if (ready) {
-                s_size[j] = (uint16_t)(1 + sl + sr);
-                progress = 1;
-            }
+    /* Child links: the left child of node j is entry j+1; its right child is the entry behind the
+     * left subtree, and that is the first r > j with S(r) <= S(j) (inside the left subtree more
+     * slots are open than before j; it is complete when the count is back at S(j)).  Entries at or
+     * past `eff` do not exist (NULL).  "First later entry with a value <= mine" for all entries at
+     * once: a min-tree over S in heap order (node h covers leaves [h << k, (h + 1) << k) - (N >> k)),
+     * leaves past `eff` hold 0 so that every search ends; a search climbs while the node to the
+     * right has no such entry and then descends to the first one that has (<= 2 x 11 reads).
+     * (The first version settled subtree sizes bottom-up, one tree level per round and barrier.) */
+    {
+        constexpr int N = 2048, TOP = 11;                 /* leaves (>= ENT + 1), levels above them */
+        static_assert(N > ENT && (N >> TOP) == 1 && THREADS * 4 == N, "one thread per four leaves");
+        uint16_t *s_min = reinterpret_cast<uint16_t *>(&sh.pay[(ENT + 1) / 2]);      /* behind S(i) */
+        static_assert(sizeof(sh.pay) >= ((ENT + 1) / 2) * sizeof(uint32_t) + 2 * N * sizeof(uint16_t), "min-tree must fit");
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 4 * tid + q;
+            v[q] = (i < eff) ? (uint32_t)s_open[i] : 0u;
+            s_min[N + i] = (uint16_t)v[q];
         }
-        if (!__syncthreads_or(progress)) break;
+        const uint32_t a0 = dmin<uint32_t>(v[0], v[1]), a1 = dmin<uint32_t>(v[2], v[3]);
+        s_min[(N >> 1) + 2 * tid] = (uint16_t)a0;
+        s_min[(N >> 1) + 2 * tid + 1] = (uint16_t)a1;
+        uint32_t m = dmin<uint32_t>(a0, a1);
+        s_min[(N >> 2) + tid] = (uint16_t)m;                          /* level 2: one node per thread */
+#pragma unroll
+        for (int k = 3; k <= 8; k++) {                                /* levels 3..8 inside the wave */
+            m = dmin<uint32_t>(m, (uint32_t)__shfl_xor((int)m, 1 << (k - 3)));
+            if ((tid & ((1 << (k - 2)) - 1)) == 0) s_min[(N >> k) + (tid >> (k - 2))] = (uint16_t)m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll 1
+            for (int h = (N >> 8) - 1; h >= 1; h--) s_min[h] = (uint16_t)dmin<uint32_t>(s_min[2 * h], s_min[2 * h + 1]);
+        }
+        __syncthreads();
+        for (int j = tid; j < eff; j += THREADS) {
+            if (sh.ent[j] == -1) continue;
+            const int l = j + 1;
+            if (l < eff && sh.ent[l] != -1) sh.left[j] = (uint16_t)l;
+            const uint32_t s = s_open[j];
+            uint32_t k = 0, p = (uint32_t)l;                          /* node (k, p): leaves [p << k, (p + 1) << k) */
+            while (s_min[(N >> k) + p] > s) {                         /* nothing in this node: the next one, as high up as it starts */
+                p++;
+                while ((p & 1u) == 0u && k < (uint32_t)TOP) { p >>= 1; k++; }
+            }
+            while (k > 0) {                                           /* the first leaf inside that qualifies */
+                k--;
+                p <<= 1;
+                if (s_min[(N >> k) + p] > s) p++;
+            }
+            if ((int)p < eff && sh.ent[p] != -1) sh.right[j] = (uint16_t)p;
+        }
     }
     __syncthreads();
     /* tree_len == 0 or a tree that starts with -1 is a NULL root: the reference crashes,

@@ -318,17 +318,12 @@ enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 #define DEC_E_NOCW 0x2000u           /* in a `bad` entry: no codeword was taken (the lookup does not count as one) */
 __device__ __forceinline__ uint32_t dec_e_adv(uint32_t e) { return (e >> 8) & 0x1fu; }
 
-#ifdef DEC_RARE_NOINLINE
-#define DEC_RARE_ATTR __noinline__
-#else
-#define DEC_RARE_ATTR __forceinline__
-#endif
 /* Bit-serial walk for `long` entries (and the verdict of a `bad` one), on the staged words.
  * CW_OK: sym, npos = position after the codeword.  CW_BAD: the walk left the tree, npos =
  * position after the failing bit.  CW_EXH: the walk needs bits past the readable payload.
  * Result packed in registers (no stack): bits 0-31 npos, 32-39 sym, 40-41 status. */
 template <int THREADS>
-__device__ DEC_RARE_ATTR uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
+__device__ __forceinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh, uint32_t e, uint32_t pos, uint32_t pay_rel)
 {
     if (e < DEC_E_LONG)                          /* the table walk already left the tree */
         return ((uint64_t)CW_BAD << 40) | (uint64_t)(pos + (e & 0x7fu));
@@ -578,10 +573,8 @@ __device__ __forceinline__ void dec_scan(DecShared<THREADS> &sh, LaneTrack &tr, 
                                          uint32_t sub_lo, uint32_t pay_rel)
 {
     if (sub_lo + DEC_SUB_BITS + DEC_LUT_BITS <= pay_rel) {
-#ifndef DEC_NO_WORDS
         if (!MERGE && start - sub_lo < 32u) dec_scan_words<THREADS>(sh, tr, start, sub_lo, pay_rel);
         else
-#endif
             dec_scan_impl<THREADS, MERGE, false>(sh, tr, start, sub_lo, pay_rel);
     } else dec_scan_impl<THREADS, MERGE, true>(sh, tr, start, sub_lo, pay_rel);
 }
@@ -953,7 +946,6 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         __syncthreads();                                  /* all reads of s_hop are done */
 #pragma unroll
         for (int k = 0; k < PERL; k++) sh.lut[tid + k * THREADS] = mine[k];
-#ifndef DEC_NO_FOLD
         /* A speculative lane that meets a run of failing bits decodes the codeword behind the run
          * in its next iteration; when run + codeword fit the window, one entry does both
          * (DEC_E_NOCW clear), which helps data with short codes (uniform bytes 2.61 -> 2.48 ms). */
@@ -969,13 +961,9 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                     sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 1u);
             }
         }
-#endif
     }
     __syncthreads();
     DPROF_ADD(1, pt);
-#if defined(DEC_ABLATE) && DEC_ABLATE == 2
-    *end_bits = 0; return HUFE_OK;
-#endif
     /* ---- 4. payload ---- */
     uint64_t true_start = 0;      /* bit where the next undecoded codeword starts */
     uint64_t produced = 0;        /* symbols written so far */

@@ -206,21 +206,6 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
  * their value, the result is complete in lane 63. */
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#ifdef TREE_DPP_BUILTIN
-    auto step = [](uint32_t x, int sel) {
-        uint32_t o;
-        switch (sel) {
-        case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false); break;
-        case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false); break;
-        case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false); break;
-        case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false); break;
-        case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xa, 0xf, false); break;
-        default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xc, 0xf, false); break;
-        }
-        return dmin(x, o);
-    };
-    for (int k = 0; k < 6; k++) v = step(v, k);
-#else
     asm volatile("s_nop 1\n\t"
                  "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
@@ -235,7 +220,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
                  "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
                  "s_nop 1"
                  : "+v"(v));
-#endif
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 

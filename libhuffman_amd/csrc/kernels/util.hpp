@@ -57,11 +57,7 @@ __device__ __forceinline__ void store_stream16(uint4 *p, uint4 v)
  * config 2: decode 0.250 -> 0.21 ms when the 128 MiB stream is still cached). */
 __device__ __forceinline__ void store_pack16(uint4 *p, uint4 v)
 {
-#ifdef HUF_PACK_NT_STORE
-    store_stream16(p, v);
-#else
     *p = v;
-#endif
 }
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)

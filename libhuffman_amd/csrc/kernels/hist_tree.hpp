@@ -48,7 +48,7 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     constexpr size_t UBYTES = (HBYTES > TOT_OFF + TBYTES) ? HBYTES : TOT_OFF + TBYTES;
     static_assert(TOT_OFF >= sizeof(TreeLds) && TOT_OFF % 16 == 0, "totals must survive the tree's initialisation");
     __shared__ __attribute__((aligned(16))) uint8_t s_union[UBYTES];
-    __shared__ uint32_t s_side[THREADS];       /* a lane's count of its wave's most frequent byte (see below) */
+    __shared__ uint32_t s_side[2 * THREADS];   /* a lane's counts of its wave's two most frequent bytes (see below) */
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_union);
     uint32_t *s_tot = reinterpret_cast<uint32_t *>(s_union + TOT_OFF);
 
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     const int tid = (int)threadIdx.x;
 
     for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
-    s_side[tid] = 0;
+    s_side[2 * tid] = 0;
+    s_side[2 * tid + 1] = 0;
     __syncthreads();
     uint32_t *mine;
     uint32_t one = 1u;
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = (uint64_t)tid;
-    uint32_t hot = 0x100u;                                       /* no byte is singled out yet */
-    const int side = (int)(&s_side[tid] - mine);
+    uint32_t hot = 0x100u, hot1 = 0x100u;                        /* no byte is singled out yet */
+    const int side = (int)(&s_side[2 * tid] - mine);
     if (i + 3 * THREADS < nvec) {                                /* the first four chunks, then a look at the counts */
         const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                     v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
         hist_add_chunk(mine, v2, one);
         hist_add_chunk(mine, v3, one);
         i += 4 * THREADS;
-        /* the wave's most frequent byte so far (its own copies; a wave's LDS operations are in
-         * order): from 1/16 of the 4 KiB seen on, its occurrences are counted per lane */
+        /* the wave's two most frequent bytes so far (its own copies; a wave's LDS operations are
+         * in order): from 1/16 of the 4 KiB seen on, their occurrences are counted per lane */
         constexpr int ARR = PACKED ? HTP_ARRAYS : HT_COPIES;
         const uint32_t *wave_hist = s_hist + (tid >> 6) * ARR * HUF_NSYM;
-        uint32_t best = 0;
+        uint32_t cand[4];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             const uint32_t bin = (uint32_t)(tid & 63) + 64u * qd;
@@ -98,23 +99,33 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
                 const uint32_t x = wave_hist[a * HUF_NSYM + bin];
                 c += PACKED ? ((x & 0xffffu) + (x >> 16)) : x;
             }
-            best = dmax(best, (c << 8) | bin);
+            cand[qd] = (c << 8) | bin;
         }
+        uint32_t best = dmax(dmax(cand[0], cand[1]), dmax(cand[2], cand[3]));
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) best = dmax(best, (uint32_t)__shfl_xor((int)best, o));
-        if ((best >> 8) >= 256u && (best >> 8) < 4096u) hot = best & 0xffu;   /* (all 4 096 equal: the run paths take it) */
+        if ((best >> 8) >= 256u && (best >> 8) < 4096u) {        /* (all 4 096 equal: the run paths take it) */
+            hot = best & 0xffu;
+            uint32_t second = 0;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) second = dmax(second, cand[qd] == best ? 0u : cand[qd]);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) second = dmax(second, (uint32_t)__shfl_xor((int)second, o));
+            if ((second >> 8) >= 256u) hot1 = second & 0xffu;
+        }
     }
     if (hot < 0x100u) {
         for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {
             const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                         v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-            hist_add_chunk_hot(mine, v0, one, hot, side);
-            hist_add_chunk_hot(mine, v1, one, hot, side);
-            hist_add_chunk_hot(mine, v2, one, hot, side);
-            hist_add_chunk_hot(mine, v3, one, hot, side);
+            hist_add_chunk_hot(mine, v0, one, hot, hot1, side);
+            hist_add_chunk_hot(mine, v1, one, hot, hot1, side);
+            hist_add_chunk_hot(mine, v2, one, hot, hot1, side);
+            hist_add_chunk_hot(mine, v3, one, hot, hot1, side);
         }
-        for (; i < nvec; i += THREADS) hist_add_chunk_hot(mine, load_stream16(q + i), one, hot, side);
-        atomicAdd(&mine[hot], s_side[tid]);                      /* a lane's own word: the value is final */
+        for (; i < nvec; i += THREADS) hist_add_chunk_hot(mine, load_stream16(q + i), one, hot, hot1, side);
+        atomicAdd(&mine[hot], s_side[2 * tid]);                  /* a lane's own words: the values are final */
+        if (hot1 < 0x100u) atomicAdd(&mine[hot1], s_side[2 * tid + 1]);
     }
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
         const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),

@@ -55,32 +55,36 @@ __device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t on
     hist_add_bytes(h, v.w, one);
 }
 
-/* The same with one byte value `hot` taken out of the conflicts: its occurrences go to a word of
- * the lane's own (`side` = that word's index relative to h) instead of the shared bin.  On skewed
- * data the lanes of a wave that meet the most frequent byte in one ds_add serialise on its bin -
- * 72 % of the LDS cycles of the Zipf histogram were such conflicts. */
-__device__ __forceinline__ void hist_add_bytes_hot(uint32_t *h, uint32_t w, uint32_t one, uint32_t hot, int side)
+/* The same with two byte values (hot0, hot1; 0x100 = none) taken out of the conflicts: their
+ * occurrences go to words of the lane's own (side, side + 1 = those words' indices relative to h)
+ * instead of the shared bins.  On skewed data the lanes of a wave that meet a frequent byte in one
+ * ds_add serialise on its bin - 72 % of the LDS cycles of the Zipf histogram were such conflicts. */
+__device__ __forceinline__ int hist_hot_index(uint32_t b, uint32_t hot0, uint32_t hot1, int side)
 {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t b = (w >> (8 * k)) & 0xffu;
-        atomicAdd(&h[(b == hot) ? side : (int)b], one);
-    }
+    return (b == hot0) ? side : ((b == hot1) ? side + 1 : (int)b);
 }
 
-__device__ __forceinline__ void hist_add_chunk_hot(uint32_t *h, uint4 v, uint32_t one, uint32_t hot, int side)
+__device__ __forceinline__ void hist_add_bytes_hot(uint32_t *h, uint32_t w, uint32_t one, uint32_t hot0,
+                                                   uint32_t hot1, int side)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) atomicAdd(&h[hist_hot_index((w >> (8 * k)) & 0xffu, hot0, hot1, side)], one);
+}
+
+__device__ __forceinline__ void hist_add_chunk_hot(uint32_t *h, uint4 v, uint32_t one, uint32_t hot0,
+                                                   uint32_t hot1, int side)
 {
     const uint32_t b = v.x & 0xffu;
     const uint32_t rep = b * 0x01010101u;
     const bool uni = (v.x == rep) & (v.y == rep) & (v.z == rep) & (v.w == rep);
     if (uni) {
-        atomicAdd(&h[(b == hot) ? side : (int)b], one * 16u);
+        atomicAdd(&h[hist_hot_index(b, hot0, hot1, side)], one * 16u);
         return;
     }
-    hist_add_bytes_hot(h, v.x, one, hot, side);
-    hist_add_bytes_hot(h, v.y, one, hot, side);
-    hist_add_bytes_hot(h, v.z, one, hot, side);
-    hist_add_bytes_hot(h, v.w, one, hot, side);
+    hist_add_bytes_hot(h, v.x, one, hot0, hot1, side);
+    hist_add_bytes_hot(h, v.y, one, hot0, hot1, side);
+    hist_add_bytes_hot(h, v.z, one, hot0, hot1, side);
+    hist_add_bytes_hot(h, v.w, one, hot0, hot1, side);
 }
 
 template <int THREADS>

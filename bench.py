@@ -1,14 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the Huffman block-codec hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload const41|zipf255|uniform256|uniform255|logtext]
+    python bench.py --gpus N --steps K --warmup W [--workload zipf255|uniform256|const41|uniform255|logtext]
 
 One "step" = one encode + one decode of the rank's shard (default 1 GiB, 64 KiB blocks) with
-the input already resident in HBM.  N > 1 is launched by torch.distributed.run with one rank
-per GPU; blocks are independent, so every rank owns a contiguous range of blocks of the one
-logical input (weak scaling: bytes per GPU are fixed).  The only exchange between ranks is the
-all-gather of the per-rank compressed sizes that places each rank's stream in the global
-stream (RCCL, 8 bytes per rank per step).
+the input already resident in HBM.  The headline workload is `zipf255` (BASELINE.json configs[2]:
+text-like bytes, every block a full 255-symbol tree; the unmodified reference can decode it, so it
+is the workload the CPU baseline is timed on); `uniform256` (configs[3], per-GPU share) and
+`const41` (configs[1], the degenerate one-symbol tree) run in the same process with the same K/W
+and are reported under "secondary" of the same JSON line.
+
+N > 1: one rank per GPU.  Either the driver starts the ranks (torch.distributed.run sets
+WORLD_SIZE), or `python bench.py --gpus N` alone starts them itself - as a child process, before
+this process touches a GPU - and relays rank 0's line.  Blocks are independent, so every rank owns
+a contiguous range of blocks of the one logical input (weak scaling: bytes per GPU are fixed) and
+the timed step needs ONE exchange: the all-gather of the per-rank compressed sizes that places each
+rank's stream in the job's stream (RCCL, 8 bytes per rank).  Beside that resident-data figure
+(`value`), "root_placement" times the form north_star words: the input scattered from rank 0 over
+xGMI, encoded, the compressed shards gathered on rank 0, scattered again, decoded, and the output
+gathered on rank 0.
 
 Prints ONE JSON line on rank 0.  `value` = uncompressed bytes of the whole job per second of
 (encode + decode), in GiB/s.  `roofline` is the dominant kernel's algorithmic HBM bytes over
@@ -18,8 +28,10 @@ reference library (oracle/_ref) timed on this box's host CPU on a bounded sample
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,17 +44,18 @@ PROFILE_EVERY = 4              # steps of the timed region that carry per-kernel
 
 WORKLOADS = {
     # name -> (BASELINE.json config it is, description)
-    "const41": "configs[1]: 1 GiB repeating 0x41, blocksize=64KiB (degenerate one-symbol tree)",
     "zipf255": "configs[2]: 1 GiB Zipf-distributed bytes (zipf255 seed 3), blocksize=64KiB",
     "uniform256": "configs[3] per-GPU share: uniform-random bytes (uniform256 seed 1), blocksize=64KiB, relaxed-tree decode",
+    "const41": "configs[1]: 1 GiB repeating 0x41, blocksize=64KiB (degenerate one-symbol tree)",
     "uniform255": "config 4b: uniform over 255 symbols (seed 2), blocksize=64KiB",
     "logtext": "configs[4] per-GPU share: synthetic log text (16 MiB generator tile repeated), blocksize=1MiB",
 }
+DEFAULT_SECONDARY = {"zipf255": ["uniform256", "const41"]}
 
 
 def cpu_baseline(workload: str, blocksize: int) -> dict:
     """Unmodified reference (oracle/_ref/libhuffman_ref.so) on ONE host core, bounded sample."""
-    import numpy as np
+    import numpy as np  # noqa: F401
     from libhuffman_amd import datagen
     from oracle.oracle import Oracle, Reference
     sample_bytes = {"const41": 256 << 20, "zipf255": 64 << 20, "uniform255": 64 << 20,
@@ -103,17 +116,324 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
             "decode_GiBps": round(sample_bytes / GIB / t_dec, 5)}
 
 
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources: the stamp profiles/traffic.json carries, so that counter
+    values of an older build are never printed as this build's."""
+    csrc = os.path.join(ROOT, "libhuffman_amd", "csrc")
+    h = hashlib.sha256()
+    names = sorted(os.listdir(os.path.join(csrc, "kernels")))
+    for path in [os.path.join(csrc, "kernels", f) for f in names] + [os.path.join(csrc, "hufgpu_api.hip")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload: str, kernel: str, n: int, bs: int):
+    """HBM bytes per launch of `kernel` from the TCC counters (tools/gpu_traffic.sh: separate
+    rocprofv3 --pmc passes of this same command, FETCH_SIZE doubled per the gfx950 correction).
+    Null unless the committed table was collected for exactly these kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t.get("kernel_source_digest") != kernel_source_digest():
+            return None
+        if n != (1 << 30) or bs != t.get("blocksize", 65536):
+            return None
+        return round(t["workloads"][workload][kernel]["hbm"])
+    except Exception:
+        return None
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD process (this
+    process has not touched a GPU and never will) and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)                 # banners of the launcher / RCCL: not part of the result
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
+
+
+class Bench:
+    def __init__(self, args, torch, dist, codec, rank, world, local_rank, use_dist):
+        self.a, self.torch, self.dist, self.codec = args, torch, dist, codec
+        self.rank, self.world, self.local_rank, self.use_dist = rank, world, local_rank, use_dist
+        self.dev = torch.device("cuda", local_rank)
+
+    def make_input(self, workload: str, n: int, first: int):
+        torch = self.torch
+        if workload == "logtext":
+            # the text generator runs on the host: one 16 MiB tile, repeated on the device
+            from libhuffman_amd import datagen
+            tile = torch.from_numpy(datagen.logtext(16 << 20)).to(self.dev)
+            return tile.repeat((n + tile.numel() - 1) // tile.numel())[:n].contiguous()
+        data = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.codec.fill(data, workload, first=first)
+        return data
+
+    def run(self, workload: str, steps: int, warmup: int) -> dict:
+        """K timed steps of one workload on every rank; returns rank 0's result record."""
+        from libhuffman_amd.sharding import shard_range
+        a, torch, dist, codec = self.a, self.torch, self.dist, self.codec
+        world, rank, dev = self.world, self.rank, self.dev
+        bs = a.blocksize or ((1 << 20) if workload == "logtext" else 65536)
+        n_total = a.bytes_per_gpu * world
+        lo, hi = shard_range(n_total, bs, rank, world)          # contiguous block range of this rank
+        n = hi - lo
+        nb = codec.block_count(n, bs)
+        relaxed = workload == "uniform256"
+        use_sub = a.decode == "sub"
+
+        data = self.make_input(workload, n, lo)
+        out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
+        offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        sub = codec.new_sub_index(n, bs) if use_sub else None
+        RING = 8
+        sizes = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(RING)]
+        snaps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(RING)]
+        pending = [None] * RING
+        self._k = 0
+
+        def step():
+            codec.encode(data, bs, out=out, offsets=offs, sync=False, sub_index=sub)
+            if self.use_dist:
+                # the one real exchange: every rank learns where its stream starts in the job's stream.
+                # Nothing on this rank's decode depends on it, so it runs on RCCL's stream beside the
+                # decode.  The next encode rewrites `offs`, so the size is snapshot on the compute
+                # stream first; a ring of buffers keeps the collectives of neighbouring steps apart.
+                j = self._k % RING
+                if pending[j] is not None:
+                    pending[j].wait()
+                snaps[j].copy_(offs[nb:nb + 1])
+                pending[j] = dist.all_gather_into_tensor(sizes[j], snaps[j], async_op=True)
+                self._k += 1
+            codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False,
+                         sub_index=sub, raw_size=n, blocksize=bs)
+
+        def drain():
+            for j in range(RING):
+                if pending[j] is not None:
+                    pending[j].wait()
+                    pending[j] = None
+
+        for _ in range(warmup):
+            step()
+        drain()
+        if warmup:
+            codec.decode_result()
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+        # HIP events around every kernel cost ~5 us each, so inside the timed region every
+        # PROFILE_EVERY-th step carries them; the per-kernel averages are over those steps
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for k in range(steps):
+            codec.set_profiling(k % PROFILE_EVERY == 0, resume=k > 0)
+            step()
+        drain()
+        ev1.record()
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        raw = codec.decode_result()
+        assert raw == n, f"decode produced {raw} of {n} bytes"
+        enc_prof, enc_calls = codec.profile("encode")
+        dec_prof, dec_calls = codec.profile("decode")
+        codec.set_profiling(False)
+
+        if self.use_dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        comp_len = int(offs[nb].item())
+        bit_exact = None
+        if not a.no_verify:
+            bit_exact = bool(torch.equal(back, data))      # full-size round trip on every rank
+            if self.use_dist:
+                ok = torch.tensor([1 if bit_exact else 0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                bit_exact = bool(ok.item())
+
+        # the other decoder on the same stream, outside the timed region: what a stream without the
+        # encoder's sub-index costs (and the other way round)
+        other_ms = None
+        if rank == 0 and use_sub and not a.no_other_decode:
+            codec.set_profiling(True)
+            for _ in range(3):
+                codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False)
+            codec.decode_result()
+            p, c = codec.profile("decode")
+            codec.set_profiling(False)
+            other_ms = p["decode"] / max(c, 1)
+
+        rec = None
+        if rank == 0:
+            K = steps
+            value = n_total * K / GIB / elapsed
+            # per-launch algorithmic bytes (SURVEY §8d): encode reads N writes C, decode reads C writes N
+            alg = {"pack": n + comp_len, "decode": comp_len + n, "hist256": n, "tree": nb * (1024 + 2048 + 2064),
+                   "scan_sizes": nb * 24, "prepare_scan": nb * (16 + 10 + 28)}
+            if workload == "const41":
+                alg["pack"] = comp_len          # one-symbol blocks: the input is not read again, the payload is zeros
+            # blocks below 4 MiB take the fused histogram+tree kernel: its time is reported once
+            fused = bs < (1 << 22)
+            if fused:
+                enc_prof = dict(enc_prof)
+                # (the "tree" and "scan_sizes" stages are empty event gaps: that work runs inside the fused kernel)
+                enc_prof["hist_tree"] = enc_prof.pop("hist256") + enc_prof.pop("tree") + enc_prof.pop("scan_sizes")
+                alg["hist_tree"] = n
+            kernels = {}
+            for name, ms in list(enc_prof.items()) + list(dec_prof.items()):
+                calls = enc_calls if name in enc_prof else dec_calls
+                avg_ms = ms / max(calls, 1)
+                kernels[name] = {"avg_ms": round(avg_ms, 4),
+                                 "alg_GBps": round(alg[name] / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None}
+            if other_ms is not None:
+                kernels["decode_selfsync"] = {
+                    "avg_ms": round(other_ms, 4), "alg_GBps": round(alg["decode"] / 1e9 / (other_ms / 1e3), 1),
+                    "note": "outside the timed region"}
+            dom = max((k for k in ("pack", "decode", "hist256", "tree", "hist_tree") if k in kernels),
+                      key=lambda k: kernels[k]["avg_ms"])
+            achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
+            kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_kernel", "pack": "pack_kernel",
+                            "hist_tree": "hist_tree_kernel", "hist256": "hist256_kernel", "tree": "tree_kernel"}
+            pipeline_bytes = 2 * (n + comp_len)
+            gpu_ms = ev0.elapsed_time(ev1) / K
+            # encode-only / decode-only (SURVEY 8d): this rank's bytes over the kernels of each half
+            enc_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in enc_prof)
+            dec_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in dec_prof)
+            rec = {
+                "value": round(value, 3),
+                "ms_per_step": round(elapsed / K * 1e3, 4),
+                "config": {"workload": WORKLOADS[workload], "generator": workload,
+                           "bytes_per_gpu": n, "blocksize": bs, "blocks_per_gpu": nb,
+                           "compressed_bytes_per_gpu": comp_len, "ratio": round(comp_len / n, 5),
+                           "parallelism": f"block-sharded x{world}", "bit_exact_roundtrip": bit_exact,
+                           "decoder": "sub-index (verified), one table pass per symbol" if use_sub
+                                      else "self-synchronising (block index only)"},
+                "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                             "traffic": measured_traffic(workload, dom, n, bs),
+                             "alg_bytes_per_launch": alg[dom],
+                             "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},
+                "kernels": kernels,
+                "encode_only_GiBps_per_gpu": round(n / GIB / (enc_ms / 1e3), 1) if enc_ms > 0 else None,
+                "decode_only_GiBps_per_gpu": round(n / GIB / (dec_ms / 1e3), 1) if dec_ms > 0 else None,
+                "gpu_ms_per_step_rank0": round(gpu_ms, 4),
+                "profiled_steps": max(enc_calls, dec_calls),
+            }
+        del data, out, offs, back, sub
+        torch.cuda.empty_cache()
+        return rec
+
+    def root_placement(self, workload: str, steps: int) -> dict:
+        """The path with the data starting and ending on rank 0 (north_star: "RCCL scatter/gather of
+        block buffers over xGMI"): scatter input shards -> encode -> gather compressed shards (+ the
+        size all-gather that places them) -> scatter them again -> decode -> gather the output.  Each
+        movement is ONE variable-size all-to-all (grouped send/recv inside RCCL; RCCL has no gatherv)."""
+        from libhuffman_amd import sharding
+        a, torch, dist, codec = self.a, self.torch, self.dist, self.codec
+        world, rank, dev = self.world, self.rank, self.dev
+        bs = a.blocksize or ((1 << 20) if workload == "logtext" else 65536)
+        n_total = a.bytes_per_gpu * world
+        plan = sharding.shard_plan(n_total, bs, world)
+        lo, hi = plan[rank]
+        n = hi - lo
+        nb = codec.block_count(n, bs)
+        relaxed = workload == "uniform256"
+        full = self.make_input(workload, n_total, 0) if rank == 0 else None
+        shard = torch.empty(n, dtype=torch.uint8, device=dev)
+        out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
+        offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        sub = codec.new_sub_index(n, bs)
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        result = torch.empty(n_total if rank == 0 else 0, dtype=torch.uint8, device=dev)
+        in_sizes = [h - l for l, h in plan]
+        gathered = None
+        legs = {"scatter_in": 0.0, "encode": 0.0, "gather_stream": 0.0, "scatter_stream": 0.0, "decode": 0.0,
+                "gather_out": 0.0}
+
+        def timed(name, fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            legs[name] += time.perf_counter() - t
+            return r
+
+        total = 0.0
+        for k in range(steps + 1):
+            if k == 1:                                  # step 0 is the warm-up (RCCL sets its channels up)
+                legs = {key: 0.0 for key in legs}
+                total = 0.0
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            timed("scatter_in", lambda: sharding.scatter_from_root(full, in_sizes, shard, 0))
+            timed("encode", lambda: codec.encode(shard, bs, out=out, offsets=offs, sync=False, sub_index=sub))
+            clen = int(offs[nb].item())
+            gathered, csizes = timed("gather_stream", lambda: sharding.gatherv_to_root(out, clen, 0))
+            timed("scatter_stream", lambda: sharding.scatter_from_root(gathered, csizes, out[:clen], 0))
+            timed("decode", lambda: codec.decode(out, clen, offs, nb, back, relaxed=relaxed, sync=True,
+                                                 sub_index=sub, raw_size=n, blocksize=bs))
+            timed("gather_out", lambda: sharding.gather_to_root(back, in_sizes, result, 0))
+            torch.cuda.synchronize()
+            dist.barrier()
+            total += time.perf_counter() - t0
+        tmax = torch.tensor([total], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ok = True
+        if rank == 0 and not a.no_verify:
+            ok = bool(torch.equal(result, full))
+        if rank != 0:
+            return None
+        sec = float(tmax.item()) / steps
+        return {"value": round(n_total / GIB / sec, 3), "unit": "GiB/s", "ms_per_step": round(sec * 1e3, 3),
+                "steps": steps, "bit_exact_roundtrip": ok, "stream_bytes": int(sum(csizes)),
+                "legs_ms_rank0": {key: round(v / steps * 1e3, 3) for key, v in legs.items()},
+                "note": "input and output live on rank 0; every leg is synchronised (no overlap between legs)"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="const41", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="zipf255", choices=sorted(WORKLOADS))
+    ap.add_argument("--secondary", default=None,
+                    help="comma-separated workloads reported under 'secondary' (default: uniform256,const41 "
+                         "beside zipf255; 'none' = only the headline workload)")
+    ap.add_argument("--decode", default="sub", choices=["sub", "selfsync"],
+                    help="sub = with the encoder's sub-index (verified on the device); selfsync = block index only")
     ap.add_argument("--bytes-per-gpu", type=int, default=1 << 30)
     ap.add_argument("--blocksize", type=int, default=None, help="default 64 KiB (1 MiB for logtext)")
+    ap.add_argument("--placement", default="auto", choices=["auto", "resident", "root"],
+                    help="root = also time the scatter/gather form (default when more than one rank runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-other-decode", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -134,158 +454,54 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from libhuffman_amd.codec import GpuCodec
-    from libhuffman_amd.sharding import shard_range
 
     codec = GpuCodec(local_rank)
-    bs = args.blocksize or ((1 << 20) if args.workload == "logtext" else 65536)
-    n_total = args.bytes_per_gpu * world
-    lo, hi = shard_range(n_total, bs, rank, world)          # contiguous block range of this rank
-    n = hi - lo
-    nb = codec.block_count(n, bs)
-    relaxed = args.workload == "uniform256"
-
-    dev = torch.device("cuda", local_rank)
-    if args.workload == "logtext":
-        # the text generator runs on the host: one 16 MiB tile, repeated on the device
-        from libhuffman_amd import datagen
-        tile = torch.from_numpy(datagen.logtext(16 << 20)).to(dev)
-        data = tile.repeat((n + tile.numel() - 1) // tile.numel())[:n].contiguous()
+    bench = Bench(args, torch, dist, codec, rank, world, local_rank, use_dist)
+    if args.secondary is None:
+        secondary = DEFAULT_SECONDARY.get(args.workload, [])
     else:
-        data = torch.empty(n, dtype=torch.uint8, device=dev)
-        codec.fill(data, args.workload, first=lo)
-    out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
-    offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
-    back = torch.empty(n, dtype=torch.uint8, device=dev)
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        secondary = [w for w in args.secondary.split(",") if w and w != "none"]
+    for w in secondary:
+        if w not in WORKLOADS:
+            raise SystemExit(f"unknown secondary workload {w}")
 
-    pending = []
-
-    def step():
-        codec.encode(data, bs, out=out, offsets=offs, sync=False)
-        if use_dist:
-            # the one real exchange: every rank learns where its stream starts in the job's stream.
-            # Nothing on this rank's decode depends on it, so it runs on RCCL's stream beside the
-            # decode (it waits for the encode by itself) and is only waited for at the end.
-            if os.environ.get("BENCH_SYNC_GATHER") == "1":          # (A/B switch: the collective in line)
-                dist.all_gather_into_tensor(sizes, offs[nb:nb + 1])
-            else:
-                pending.append(dist.all_gather_into_tensor(sizes, offs[nb:nb + 1], async_op=True))
-        codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False)
-
-    def drain():
-        while pending:
-            pending.pop().wait()
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    raw = codec.decode_result() if args.warmup else None
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-
-    # HIP events around every kernel cost ~5 us each (~6 % of a config-2 step), so inside the timed
-    # region every PROFILE_EVERY-th step carries them; the per-kernel averages are over those steps
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(args.steps):
-        codec.set_profiling(k % PROFILE_EVERY == 0, resume=k > 0)
-        step()
-    drain()
-    ev1.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    raw = codec.decode_result()
-    assert raw == n, f"decode produced {raw} of {n} bytes"
-    enc_prof, enc_calls = codec.profile("encode")
-    dec_prof, dec_calls = codec.profile("decode")
-    codec.set_profiling(False)
-
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    comp_len = int(offs[nb].item())
-    bit_exact = None
-    if not args.no_verify:
-        bit_exact = bool(torch.equal(back, data))      # full-size round trip on every rank
-        if use_dist:
-            ok = torch.tensor([1 if bit_exact else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            bit_exact = bool(ok.item())
-
-    if rank == 0:
-        K = args.steps
-        value = n_total * K / GIB / elapsed
-        # per-launch algorithmic bytes: encode reads N writes C, decode reads C writes N
-        alg = {"pack": n + comp_len, "decode": comp_len + n, "hist256": n, "tree": nb * (1024 + 2048 + 2064),
-               "scan_sizes": nb * 24, "prepare_scan": nb * (16 + 10 + 28)}
-        if args.workload == "const41":
-            alg["pack"] = comp_len          # one-symbol blocks: the input is not read again, the payload is zeros
-        # blocks below 4 MiB take the fused histogram+tree kernel: its time is reported once
-        fused = bs < (1 << 22)
-        if fused:
-            enc_prof = dict(enc_prof)
-            # (the "tree" and "scan_sizes" stages are empty event gaps: that work runs inside the fused kernel)
-            enc_prof["hist_tree"] = enc_prof.pop("hist256") + enc_prof.pop("tree") + enc_prof.pop("scan_sizes")
-            alg["hist_tree"] = n
-        kernels = {}
-        for name, ms in list(enc_prof.items()) + list(dec_prof.items()):
-            calls = enc_calls if name in enc_prof else dec_calls
-            avg_ms = ms / max(calls, 1)
-            kernels[name] = {"avg_ms": round(avg_ms, 4),
-                             "alg_GBps": round(alg[name] / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None}
-        dom = max((k for k in ("pack", "decode", "hist256", "tree", "hist_tree") if k in kernels),
-                  key=lambda k: kernels[k]["avg_ms"])
-        achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
-        # HBM bytes of that kernel from the TCC counters (separate rocprofv3 --pmc passes of this same
-        # command, tools/gpu_traffic.sh -> profiles/traffic.json); null when not collected for the workload
-        traffic = None
+    main_rec = bench.run(args.workload, args.steps, args.warmup)
+    sec_recs = {w: bench.run(w, args.steps, args.warmup) for w in secondary}
+    root_rec = None
+    if use_dist and args.placement in ("auto", "root"):
         try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                t = json.load(f)["workloads"][args.workload][dom]
-            if n == (1 << 30) and bs == 65536:
-                traffic = round(t["hbm"])
-        except Exception:
-            traffic = None
-        pipeline_bytes = 2 * (n + comp_len)
-        gpu_ms = ev0.elapsed_time(ev1) / K
-        # encode-only / decode-only: this rank's bytes over the kernels of each half
-        enc_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in enc_prof)
-        dec_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in dec_prof)
+            root_rec = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
+        except Exception as e:                      # the extra figure never takes the headline down with it
+            root_rec = {"error": repr(e)}
+
+    result = None
+    if rank == 0:
+        bs = main_rec["config"]["blocksize"]
         result = {
             "metric": "encode+decode GiB/s (uncompressed) on %s blocks" % ("64KiB" if bs == 65536 else "%dKiB" % (bs >> 10)),
-            "value": round(value, 3),
+            "value": main_rec["value"],
             "unit": "GiB/s",
             "n_gpus": world,
-            "steps": K,
+            "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "ms_per_step": main_rec["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload], "generator": args.workload,
-                       "bytes_per_gpu": n, "blocksize": bs, "blocks_per_gpu": nb,
-                       "compressed_bytes_per_gpu": comp_len, "ratio": round(comp_len / n, 5),
-                       "parallelism": f"block-sharded x{world}", "bit_exact_roundtrip": bit_exact},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": alg[dom],
-                         "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},
-            "kernels": kernels,
-            "encode_only_GiBps_per_gpu": round(n / GIB / (enc_ms / 1e3), 1) if enc_ms > 0 else None,
-            "decode_only_GiBps_per_gpu": round(n / GIB / (dec_ms / 1e3), 1) if dec_ms > 0 else None,
-            "gpu_ms_per_step_rank0": round(gpu_ms, 4),
-            "profiled_steps": max(enc_calls, dec_calls),
         }
+        result.update({k: v for k, v in main_rec.items() if k not in ("value", "ms_per_step")})
+        result["secondary"] = {
+            w: {"value": r["value"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                "ratio": r["config"]["ratio"], "bit_exact_roundtrip": r["config"]["bit_exact_roundtrip"],
+                "roofline": {"kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
+                             "achieved": r["roofline"]["achieved"], "traffic": r["roofline"]["traffic"],
+                             "pipeline_frac": r["roofline"]["pipeline_frac"]},
+                "kernels": {k: v["avg_ms"] for k, v in r["kernels"].items()}}
+            for w, r in sec_recs.items()}
+        if root_rec is not None:
+            result["root_placement"] = root_rec
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, bs)
 

@@ -93,7 +93,30 @@ int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
                   void *d_out, uint64_t out_cap, uint32_t flags,
                   uint64_t *raw_len, void *stream);
 
-/* Synchronise and report the outcome of the last enqueued hufgpu_decode(). */
+/*
+ * The same pair with the encoder's SUB-INDEX: besides the block index the encoder can hand over
+ * where, inside every block's payload, each group of 32 symbols starts (2 bytes per 32 symbols +
+ * 8 bytes per 8 192 symbols; hufgpu_sub_index_bytes() bytes, 8-byte aligned, in HBM).  Like the
+ * block index it is in-process side information - the stream is the reference's, byte for byte.
+ * With it hufgpu_decode_sub() decodes every symbol once instead of finding the codeword starts by
+ * decoding speculatively (src/decoder.c:34-96 has the same information implicitly: it walks the
+ * bits in order).  The sub-index is VERIFIED while it is used: a group must decode to exactly its
+ * recorded bit count with every walk inside the tree and inside the payload; a block for which
+ * that fails (stale or foreign sub-index, damaged stream) is decoded again without it, so results
+ * and error codes are those of hufgpu_decode() for ANY content of d_sub_index.
+ *   raw_size, blocksize : the n and blocksize of the encode that produced stream and sub-index
+ *                         (they fix the block count and the layout of d_sub_index).
+ */
+uint64_t hufgpu_sub_index_bytes(uint64_t n, uint64_t blocksize);
+int hufgpu_encode_sub(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                      void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
+                      void *d_sub_index, uint64_t *out_len, void *stream);
+int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                      const uint64_t *d_block_offsets, uint64_t raw_size, uint64_t blocksize,
+                      const void *d_sub_index, void *d_out, uint64_t out_cap, uint32_t flags,
+                      uint64_t *raw_len, void *stream);
+
+/* Synchronise and report the outcome of the last enqueued hufgpu_decode() / hufgpu_decode_sub(). */
 int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
 
 /*

@@ -66,7 +66,8 @@ GPU_SYMBOLS = """hufgpu_device_count hufgpu_ctx_create hufgpu_ctx_destroy hufgpu
 hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_decode
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_set_profiling
-hufgpu_get_profile huf_gpu_set_relaxed_tree huf_gpu_memwrap""".split()
+hufgpu_get_profile hufgpu_sub_index_bytes hufgpu_encode_sub hufgpu_decode_sub
+huf_gpu_set_relaxed_tree huf_gpu_memwrap""".split()
 
 
 def so_path() -> str:
@@ -112,6 +113,10 @@ def load() -> C.CDLL:
     L.hufgpu_histogram.argtypes = [vp, vp, u64, u64, vp, vp]
     L.hufgpu_encode.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.POINTER(u64), vp]
     L.hufgpu_decode.argtypes = [vp, vp, u64, vp, u64, vp, u64, C.c_uint32, C.POINTER(u64), vp]
+    L.hufgpu_sub_index_bytes.restype = u64
+    L.hufgpu_sub_index_bytes.argtypes = [u64, u64]
+    L.hufgpu_encode_sub.argtypes = [vp, vp, u64, u64, vp, u64, vp, vp, C.POINTER(u64), vp]
+    L.hufgpu_decode_sub.argtypes = [vp, vp, u64, vp, u64, u64, vp, vp, u64, C.c_uint32, C.POINTER(u64), vp]
     L.hufgpu_decode_result.argtypes = [vp, C.POINTER(u64)]
     L.hufgpu_decode_stream.argtypes = [vp, vp, u64, u64, vp, u64, C.c_uint32, C.POINTER(u64),
                                        C.POINTER(u64), vp]

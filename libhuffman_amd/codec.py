@@ -65,6 +65,13 @@ class GpuCodec:
     def encode_bound(self, n: int, blocksize: int) -> int:
         return int(self.lib.hufgpu_encode_bound(n, blocksize))
 
+    def sub_index_bytes(self, n: int, blocksize: int) -> int:
+        """Size of the optional sub-index of an encode of n bytes (see include/huffman_gpu.h)."""
+        return int(self.lib.hufgpu_sub_index_bytes(n, blocksize))
+
+    def new_sub_index(self, n: int, blocksize: int) -> torch.Tensor:
+        return torch.empty(max(1, (self.sub_index_bytes(n, blocksize) + 7) // 8), dtype=torch.int64, device=self.tdev)
+
     # -- hot path ---------------------------------------------------------------------------
     def histogram(self, data: torch.Tensor, blocksize: int) -> torch.Tensor:
         n = data.numel()
@@ -75,8 +82,9 @@ class GpuCodec:
         return hist
 
     def encode(self, data: torch.Tensor, blocksize: int, out: torch.Tensor | None = None,
-               offsets: torch.Tensor | None = None, sync: bool = True):
-        """Returns (stream tensor view, offsets tensor[nblocks+1], length or None)."""
+               offsets: torch.Tensor | None = None, sync: bool = True, sub_index: torch.Tensor | None = None):
+        """Returns (stream tensor view, offsets tensor[nblocks+1], length or None).  `sub_index`
+        (from new_sub_index) also receives the encoder's sub-index for decode(..., sub_index=)."""
         assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
         n = data.numel()
         nb = self.block_count(n, blocksize)
@@ -85,22 +93,37 @@ class GpuCodec:
         if offsets is None:
             offsets = torch.empty(nb + 1, dtype=torch.int64, device=self.tdev)
         out_len = C.c_uint64(0)
-        err = self.lib.hufgpu_encode(self._ctx, data.data_ptr(), n, blocksize, out.data_ptr(),
-                                     out.numel(), offsets.data_ptr(),
-                                     C.byref(out_len) if sync else None, self._stream())
+        if sub_index is not None:
+            assert sub_index.numel() * sub_index.element_size() >= self.sub_index_bytes(n, blocksize)
+            err = self.lib.hufgpu_encode_sub(self._ctx, data.data_ptr(), n, blocksize, out.data_ptr(),
+                                             out.numel(), offsets.data_ptr(), sub_index.data_ptr(),
+                                             C.byref(out_len) if sync else None, self._stream())
+        else:
+            err = self.lib.hufgpu_encode(self._ctx, data.data_ptr(), n, blocksize, out.data_ptr(),
+                                         out.numel(), offsets.data_ptr(),
+                                         C.byref(out_len) if sync else None, self._stream())
         self._check(err, "Failed to encode the data")
         if sync:
             return out[: out_len.value], offsets, int(out_len.value)
         return out, offsets, None
 
     def decode(self, stream: torch.Tensor, stream_len: int, offsets: torch.Tensor, nblocks: int,
-               out: torch.Tensor, relaxed: bool = False, sync: bool = True):
-        """Indexed decode. Returns bytes written (sync) or None (enqueued only)."""
+               out: torch.Tensor, relaxed: bool = False, sync: bool = True,
+               sub_index: torch.Tensor | None = None, raw_size: int = 0, blocksize: int = 0):
+        """Indexed decode. Returns bytes written (sync) or None (enqueued only).  With `sub_index`
+        (as written by encode of `raw_size` bytes in blocks of `blocksize`) every symbol is decoded
+        once; the sub-index is verified on the device, never trusted."""
         raw = C.c_uint64(0)
-        err = self.lib.hufgpu_decode(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
-                                     nblocks, out.data_ptr(), out.numel(),
-                                     _native.RELAXED_TREE if relaxed else _native.STRICT_TREE,
-                                     C.byref(raw) if sync else None, self._stream())
+        flags = _native.RELAXED_TREE if relaxed else _native.STRICT_TREE
+        if sub_index is not None:
+            assert self.block_count(raw_size, blocksize) == nblocks
+            err = self.lib.hufgpu_decode_sub(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
+                                             raw_size, blocksize, sub_index.data_ptr(), out.data_ptr(),
+                                             out.numel(), flags, C.byref(raw) if sync else None, self._stream())
+        else:
+            err = self.lib.hufgpu_decode(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
+                                         nblocks, out.data_ptr(), out.numel(), flags,
+                                         C.byref(raw) if sync else None, self._stream())
         self._check(err, "Failed to decode the data")
         return int(raw.value) if sync else None
 

@@ -1270,6 +1270,7 @@ static huf_error_t decode_locked(huf_decoder_t *dec)
     membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(dec->config->writer) : NULL;
     size_t avail = 0;
     const char *in_ptr = NULL;              /* host bytes [0, avail) of the input */
+    const size_t start_off = rmem ? rmem->off : 0;
     if (rmem) {
         const size_t left = rmem->len - rmem->off;
         in_ptr = (const char *)*rmem->buf + rmem->off;
@@ -1310,6 +1311,10 @@ static huf_error_t decode_locked(huf_decoder_t *dec)
             TRY(read_upto(dec->config->reader, (uint8_t *)g_stage.h_a + avail, more_want, &more));
             if (more) { avail += more; continue; }
         }
+        /* the reference's unbuffered reader stops right behind the last block it took (src/decoder.c:
+         * 218-276 pulls bytes on demand): the bytes looked at speculatively beyond that stay unread, so
+         * that a caller can decode consecutive streams from one memstream */
+        if (rmem) rmem->off = start_off + (size_t)(used < avail ? used : avail);
         /* bytes of the blocks that decoded completely are delivered even when a later block
          * fails, as the reference's unbuffered writer would have done */
         if (raw && wmem) {

@@ -51,6 +51,9 @@ struct hufgpu_ctx {
     uint64_t *d_out_offsets;
     int32_t *d_status;
     TwoLevel dec_lens;            /* two-level prefix sums of the block lengths */
+    uint32_t *d_fix_count;        /* decode_sub_kernel: blocks its sub-index could not verify */
+    uint32_t *d_fix_blocks;
+    uint32_t *d_fix_flag;
 
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
@@ -208,6 +211,8 @@ static void free_decode_ws(hufgpu_ctx *c)
     (void)hipFree(c->d_dmeta);
     (void)hipFree(c->d_out_offsets);
     (void)hipFree(c->d_status);
+    (void)hipFree(c->d_fix_count); (void)hipFree(c->d_fix_blocks); (void)hipFree(c->d_fix_flag);
+    c->d_fix_count = NULL; c->d_fix_blocks = NULL; c->d_fix_flag = NULL;
     c->d_dmeta = NULL; c->d_out_offsets = NULL; c->d_status = NULL;
     c->dws_blocks = 0;
 }
@@ -284,6 +289,11 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipMalloc((void **)&c->d_dmeta, cap * sizeof(HufDecodeMeta)));
     HIP_OK(c, hipMalloc((void **)&c->d_out_offsets, (cap + 1) * sizeof(uint64_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_fix_count, sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_fix_blocks, cap * sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_fix_flag, cap * sizeof(uint32_t)));
+    HIP_OK(c, hipMemset(c->d_fix_count, 0, sizeof(uint32_t)));
+    HIP_OK(c, hipMemset(c->d_fix_flag, 0, cap * sizeof(uint32_t)));
     int rc2 = alloc_two_level(c, &c->dec_lens, cap, true);
     if (rc2) return rc2;
     c->dws_blocks = cap;
@@ -378,13 +388,42 @@ extern "C" int hufgpu_histogram(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n,
     return HUFE_OK;
 }
 
-extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
-                             void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
-                             uint64_t *out_len, void *stream)
+/* where the two arrays of a sub-index live inside the caller's buffer */
+static HufSubIndex sub_index_view(void *d_sub, uint64_t n, uint64_t blocksize)
+{
+    HufSubIndex v;
+    memset(&v, 0, sizeof(v));
+    if (!d_sub || n == 0) return v;
+    if (blocksize == 0) blocksize = n;
+    const uint64_t nb = hufgpu_block_count(n, blocksize);
+    v.gpb = (blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
+    v.tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
+    v.tile_bits = (uint64_t *)d_sub;
+    v.group_bits = (uint16_t *)((uint64_t *)d_sub + nb * v.tpb);
+    return v;
+}
+
+extern "C" uint64_t hufgpu_sub_index_bytes(uint64_t n, uint64_t blocksize)
+{
+    if (n == 0) return 0;
+    if (blocksize == 0) blocksize = n;
+    const uint64_t nb = hufgpu_block_count(n, blocksize);
+    const uint64_t gpb = (blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
+    const uint64_t tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
+    return nb * tpb * sizeof(uint64_t) + nb * gpb * sizeof(uint16_t);
+}
+
+static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                       void *d_out, uint64_t out_cap, uint64_t *d_block_offsets, void *d_sub_index,
+                       uint64_t *out_len, void *stream)
 {
     if (!ctx) return HUFE_ARGUMENT;
     if (n == 0) {                                  /* src/encoder.c:288: nothing to do */
         if (out_len) *out_len = 0;
+        if (d_block_offsets) {                     /* the index of an empty stream: its length, 0 */
+            HIP_OK(ctx, hipSetDevice(ctx->device));
+            HIP_OK(ctx, hipMemsetAsync(d_block_offsets, 0, sizeof(uint64_t), pick_stream(ctx, stream)));
+        }
         return HUFE_OK;
     }
     if (!d_in || !d_out) return HUFE_ARGUMENT;
@@ -406,6 +445,11 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
     hipStream_t s = pick_stream(ctx, stream);
     uint64_t *offs = d_block_offsets ? d_block_offsets : ctx->d_offsets;
     const uint8_t *in = (const uint8_t *)d_in;
+    if (d_sub_index && ((uintptr_t)d_sub_index & 7u)) {
+        set_err(ctx, "the sub-index buffer must be 8-byte aligned");
+        return HUFE_ARGUMENT;
+    }
+    const HufSubIndex sub = sub_index_view(d_sub_index, n, blocksize);
 
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
     TwoLevel sizes = ctx->enc_sizes;
@@ -430,9 +474,9 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
         sizes.local = NULL;              /* pack reads the finished index */
     }
     if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
-        pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out);
+        pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub);
     else
-        pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out);
+        pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub);
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
 
@@ -442,6 +486,20 @@ extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, ui
         *out_len = ctx->h_result[0];
     }
     return HUFE_OK;
+}
+
+extern "C" int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                             void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
+                             uint64_t *out_len, void *stream)
+{
+    return encode_impl(ctx, d_in, n, blocksize, d_out, out_cap, d_block_offsets, NULL, out_len, stream);
+}
+
+extern "C" int hufgpu_encode_sub(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,
+                                 void *d_out, uint64_t out_cap, uint64_t *d_block_offsets,
+                                 void *d_sub_index, uint64_t *out_len, void *stream)
+{
+    return encode_impl(ctx, d_in, n, blocksize, d_out, out_cap, d_block_offsets, d_sub_index, out_len, stream);
 }
 
 extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
@@ -472,9 +530,9 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     return err;
 }
 
-extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
-                             const uint64_t *d_block_offsets, uint64_t nblocks, void *d_out,
-                             uint64_t out_cap, uint32_t flags, uint64_t *raw_len, void *stream)
+static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                       const uint64_t *d_block_offsets, uint64_t nblocks, const HufSubIndex *sub, uint64_t blocksize,
+                       void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len, void *stream)
 {
     if (!ctx) return HUFE_ARGUMENT;
     if (nblocks == 0 || stream_len == 0) {         /* src/decoder.c:218, test/decode_test.c:32-36 */
@@ -498,15 +556,52 @@ extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t s
     lens.total = (uint64_t *)res + 1;
     lens.total2 = ctx->d_out_offsets + nblocks;
     lens.min_out = (uint64_t *)res + 2;
-    decode_prepare_kernel<<<dim3((unsigned)((nblocks + SCAN_GROUP - 1) / SCAN_GROUP)), dim3(SCAN_GROUP), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta, ctx->d_status, lens);
+    decode_prepare_kernel<<<dim3((unsigned)((nblocks + SCAN_GROUP - 1) / SCAN_GROUP)), dim3(SCAN_GROUP), 0, s>>>(st, stream_len, d_block_offsets, nblocks, max_tree, ctx->d_dmeta, ctx->d_status, lens, ctx->d_fix_count);
     STAGE_MARK(ctx, s);
-    decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res);
+    if (sub && sub->tile_bits) {
+        /* the encoder's sub-index: one table pass per symbol, verified; what cannot be verified is
+         * decoded again by the self-synchronising decoder (decode_fix_kernel) */
+        const uint64_t cpb = (blocksize + DSUB_CHUNK_SYMS - 1) / DSUB_CHUNK_SYMS;
+        if (nblocks * cpb > 0x7fffffffull) return HUFE_ARGUMENT;
+        DecFixList fix;
+        fix.count = ctx->d_fix_count;
+        fix.blocks = ctx->d_fix_blocks;
+        fix.flag = ctx->d_fix_flag;
+        decode_sub_kernel<DEC_THREADS><<<dim3((unsigned)(nblocks * cpb)), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, *sub, blocksize, (uint32_t)cpb, fix);
+        const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
+    } else {
+        decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res);
+    }
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
     ctx->decode_pending = 1;
     ctx->last_stream = s;
     if (raw_len) return hufgpu_decode_result(ctx, raw_len);
     return HUFE_OK;
+}
+
+extern "C" int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                             const uint64_t *d_block_offsets, uint64_t nblocks, void *d_out,
+                             uint64_t out_cap, uint32_t flags, uint64_t *raw_len, void *stream)
+{
+    return decode_impl(ctx, d_stream, stream_len, d_block_offsets, nblocks, NULL, 0, d_out, out_cap, flags, raw_len, stream);
+}
+
+extern "C" int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
+                                 const uint64_t *d_block_offsets, uint64_t raw_size, uint64_t blocksize,
+                                 const void *d_sub_index, void *d_out, uint64_t out_cap, uint32_t flags,
+                                 uint64_t *raw_len, void *stream)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (blocksize == 0) blocksize = raw_size;
+    const uint64_t nblocks = hufgpu_block_count(raw_size, blocksize);
+    if (d_sub_index && ((uintptr_t)d_sub_index & 7u)) {
+        set_err(ctx, "the sub-index buffer must be 8-byte aligned");
+        return HUFE_ARGUMENT;
+    }
+    const HufSubIndex sub = sub_index_view((void *)d_sub_index, raw_size, blocksize);
+    return decode_impl(ctx, d_stream, stream_len, d_block_offsets, nblocks, &sub, blocksize, d_out, out_cap, flags, raw_len, stream);
 }
 
 #ifdef DISC_DEBUG

@@ -6,8 +6,9 @@
  * workgroups and the grid is simply the block count.
  *
  *   encode:  hist_tree_kernel -> pack_kernel      (blocks >= 4 MiB: hist256 -> tree -> scan_sizes -> pack)
- *   decode:  decode_prepare_kernel -> decode_kernel
- *            (block index known), or decode_chain_kernel (raw stream, blocks in order)
+ *   decode:  decode_prepare_kernel -> decode_kernel (block index known)
+ *            decode_prepare_kernel -> decode_sub_kernel -> decode_fix_kernel (block index and the
+ *            encoder's sub-index known), or decode_chain_kernel (raw stream, blocks in order)
  *
  * Wave size is 64 throughout (hard-coded, gfx950 only).  All arithmetic is integer.
  */
@@ -23,5 +24,6 @@
 #include "kernels/hist_tree.hpp"
 #include "kernels/pack.hpp"
 #include "kernels/decode.hpp"
+#include "kernels/decode_sub.hpp"
 #include "kernels/discover.hpp"
 #include "kernels/fill.hpp"

@@ -62,11 +62,13 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
                                                                     const uint64_t *__restrict__ offsets,
                                                                     uint64_t nblocks, int max_tree_len,
                                                                     HufDecodeMeta *__restrict__ dmeta,
-                                                                    int32_t *__restrict__ status, TwoLevel lens)
+                                                                    int32_t *__restrict__ status, TwoLevel lens,
+                                                                    uint32_t *__restrict__ fix_count)
 {
     __shared__ uint64_t s_part[SCAN_GROUP / 64];
     __shared__ unsigned long long s_bad;
     if (threadIdx.x == 0) s_bad = ~0ull;
+    if (fix_count && blockIdx.x == 0 && threadIdx.x == 0) *fix_count = 0;   /* decode_sub_kernel's work list starts empty */
     const uint64_t b = (uint64_t)blockIdx.x * SCAN_GROUP + threadIdx.x;
     HufDecodeMeta m;
     m.block_len = 0;
@@ -743,19 +745,17 @@ __device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const u
     return HUFE_OK;
 }
 
-/* Decode one block whose header has been parsed.  `tree` points at the tree_len int16 entries,
- * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
- * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
- * symbol (valid on success); *produced_out = symbols delivered (also on failure). */
-template <int THREADS, bool STORE = true>
-__device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
-                            uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits,
-                            uint64_t *produced_out)
+/* Steps 0-3 of a block's decode: child links from the serialized tree, then the lookup table.
+ * Returns HUFE_OK with the tables in sh (*single_leaf = -1), HUFE_OK with *single_leaf = the byte of
+ * a tree whose root has one leaf child on the left (no table is built: the payload is all zero
+ * bits), or HUFE_CORRUPTED for a NULL root.  SPEC = the table also folds "failing run + the codeword
+ * behind it" into one entry, which only the speculative (self-synchronising) lanes profit from. */
+template <int THREADS, bool SPEC = true>
+__device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, int *single_leaf)
 {
     constexpr int ENT = DecShared<THREADS>::ENT;
-    constexpr int COLS = DecShared<THREADS>::COLS;
     const int tid = (int)threadIdx.x;
-    *produced_out = 0;
+    *single_leaf = -1;
 
     /* ---- 0. the tree every one-symbol block carries, [root, leaf, -1, -1, -1],
      *         is recognised straight from its five entries; other shapes of single-leaf trees are
@@ -763,9 +763,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
     unsigned long long pt = DPROF_T();
     if (tree_len == 5) {
         const int leaf = single_leaf_symbol(tree);
-        if (leaf >= 0)
-            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)leaf, tree + 10, block_len, pay_bytes, gout,
-                                                      end_bits, produced_out);
+        if (leaf >= 0) { *single_leaf = leaf; return HUFE_OK; }
     }
 
     /* ---- 1. tree ---- */
@@ -866,16 +864,15 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
      * the decision is BTREE_CORRUPTED */
     if (!(eff > 0 && sh.ent[0] != -1)) return HUFE_CORRUPTED;
 
-    const uint8_t *pay = tree + 2 * tree_len;
-    const uint64_t pay_bits = pay_bytes * 8ull;
     DPROF_ADD(0, pt); pt = DPROF_T();
 
     /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
     {
         const uint32_t l0 = sh.left[0];
-        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL)
-            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)(uint8_t)sh.ent[l0], pay, block_len, pay_bytes, gout,
-                                               end_bits, produced_out);
+        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL) {
+            *single_leaf = (int)(uint8_t)sh.ent[l0];
+            return HUFE_OK;
+        }
     }
 
     /* ---- 3. lookup table ----
@@ -950,6 +947,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
          * in its next iteration; when run + codeword fit the window, one entry does both
          * (DEC_E_NOCW clear), which helps data with short codes (uniform bytes 2.61 -> 2.48 ms). */
         __syncthreads();
+        if (SPEC) {
 #pragma unroll
         for (int k = 0; k < PERL; k++) {
             const uint32_t e = mine[k];
@@ -961,9 +959,36 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                     sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 1u);
             }
         }
+        }
     }
     __syncthreads();
     DPROF_ADD(1, pt);
+    return HUFE_OK;
+}
+
+/* Decode one block whose header has been parsed.  `tree` points at the tree_len int16 entries,
+ * the payload follows them and at most pay_bytes of it may be read.  Writes block_len bytes
+ * to gout.  Returns HUFE_*; *end_bits = payload bits consumed up to and including the last
+ * symbol (valid on success); *produced_out = symbols delivered (also on failure). */
+template <int THREADS, bool STORE = true>
+__device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len,
+                            uint64_t block_len, uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits,
+                            uint64_t *produced_out)
+{
+    constexpr int COLS = DecShared<THREADS>::COLS;
+    const int tid = (int)threadIdx.x;
+    *produced_out = 0;
+    const uint8_t *pay = tree + 2 * tree_len;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+    {
+        int leaf = -1;
+        const int rc = dec_build_tables<THREADS, true>(sh, tree, tree_len, &leaf);
+        if (rc != HUFE_OK) return rc;
+        if (leaf >= 0)
+            return decode_single_leaf<THREADS, STORE>(sh, (uint32_t)leaf, pay, block_len, pay_bytes, gout, end_bits,
+                                                      produced_out);
+    }
+    unsigned long long pt = DPROF_T();
     /* ---- 4. payload ---- */
     uint64_t true_start = 0;      /* bit where the next undecoded codeword starts */
     uint64_t produced = 0;        /* symbols written so far */

@@ -48,15 +48,19 @@ __device__ __forceinline__ bool tree_grammar_complete(const uint8_t *t, int tl)
 
 /* stream must be 16-byte aligned.  WRITE = false: per-workgroup candidate counts;
  * WRITE = true: candidates written in ascending order at wg_base[workgroup]. */
-/* The same test by a whole wavefront (all 64 lanes call it with the same arguments): 64 entries
+/* The same test by a wavefront (its active lanes, a prefix of the wave, call it with the same arguments): 64 entries
  * per step, open-slot counts by a wave prefix sum.  A lane walking the up to 1 025 entries alone
  * is ~1 000 pairs of dependent byte loads (~0.5 ms), and every real header costs one such walk. */
 __device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl)
 {
     const int lane = lane_id();
+    /* The calling lanes are a prefix of the wave (the stream's last wave has lanes behind scan_len
+     * switched off): entries are dealt over the nact active lanes and the step's total comes from
+     * the last of them - a shuffle from an inactive lane is undefined. */
+    const int nact = __popcll(__ballot(1));
     int open = 1;                                                /* child slots still to be filled */
     bool bad = false;
-    for (int base = 0; base < tl; base += 64) {                  /* uniform */
+    for (int base = 0; base < tl; base += nact) {                /* uniform */
         const int i = base + lane;
         int d = 0;
         if (i < tl) d = (((uint32_t)t[2 * i] | ((uint32_t)t[2 * i + 1] << 8)) != 0xffffu) ? 1 : -1;
@@ -67,7 +71,7 @@ __device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl
             if (lane >= o) inc += up;
         }
         if (i < tl && open + inc - d <= 0) bad = true;           /* an entry behind a complete tree */
-        open += __shfl(inc, 63);
+        open += __shfl(inc, nact - 1);
     }
     return __ballot(bad) == 0ull && open == 0;
 }

@@ -30,6 +30,21 @@ namespace hufgpu {
 #define PACK_SPT 32
 #define PACK_STAGE_WORDS 3328          /* 13 KiB: a 256x32-symbol tile at up to ~12.9 bits per symbol */
 
+/* Sub-index of a block's payload (in-process, like the block index; the wire format is untouched):
+ * the encoder knows where every lane's PACK_SPT symbols start, the decoder would otherwise have to
+ * find out by decoding everything twice (self-synchronisation).  Per group of HUF_SUB_GROUP symbols
+ * the number of payload bits they occupy, per tile of HUF_SUB_TILE symbols the payload bit the tile
+ * starts at.  Block b owns groups [b * gpb, (b+1) * gpb) and tiles [b * tpb, (b+1) * tpb), gpb/tpb =
+ * ceil(blocksize / group or tile).  The decoder VERIFIES what it is told (a group must decode to
+ * exactly its bit count), so a wrong or stale sub-index costs time, never correctness. */
+#define HUF_SUB_GROUP PACK_SPT
+#define HUF_SUB_TILE  (256 * PACK_SPT)
+struct HufSubIndex {
+    uint64_t *tile_bits;      /* NULL = no sub-index */
+    uint16_t *group_bits;
+    uint64_t gpb, tpb;
+};
+
 template <typename CodeT>
 struct PackAcc {
     uint64_t acc;       /* right-aligned bits not yet emitted */
@@ -84,8 +99,10 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                                            const hufcode_t *__restrict__ codes64,
                                            const int16_t *__restrict__ tb, uint32_t tree_len,
                                            uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
-                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage)
+                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage,
+                                           uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
 {
+    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
     constexpr int TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
@@ -173,6 +190,10 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         }
         uint32_t tile_bits;
         const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
+        if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
+            if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
+            if (tid == 0) sub_tiles[t0 / TILE] = bitpos - (uint64_t)hdr_end * 8ull;
+        }
 
         /* ---- shift the codes out ----
          * Finished words go to an LDS stage laid out like the destination (stage word i <-> HBM
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
                                                        const int16_t *__restrict__ treebuf,
                                                        const HufBlockMeta *__restrict__ meta,
                                                        uint64_t *__restrict__ offsets, TwoLevel sizes,
-                                                       uint8_t *__restrict__ out)
+                                                       uint8_t *__restrict__ out, HufSubIndex sub)
 {
     __shared__ hufcode_t s_code[SHORT ? HUF_NSYM / 2 : HUF_NSYM];   /* u32[256] on the short-code path */
     __shared__ uint32_t s_part[THREADS / 64];
@@ -284,12 +305,14 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
         o0 = offsets[blk];
         o1 = offsets[blk + 1];
     }
+    uint64_t *sub_tiles = sub.tile_bits ? sub.tile_bits + blk * sub.tpb : nullptr;
+    uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb : nullptr;
     if (SHORT || m.max_len <= 24)
         pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
-                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage);
+                                      reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
     else if constexpr (!SHORT)
         pack_block<THREADS, hufcode_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
-                                       s_code, s_part, s_tail, s_stage);
+                                       s_code, s_part, s_tail, s_stage, sub_tiles, sub_groups);
 }
 
 }  // namespace hufgpu

@@ -87,3 +87,69 @@ def scatter_input(data: Optional[torch.Tensor], n_total: int, blocksize: int, sr
 
 def shard_plan(n_total: int, blocksize: int, world: int) -> List[Tuple[int, int]]:
     return [shard_range(n_total, blocksize, r, world) for r in range(world)]
+
+
+# ---- whole shards between a root and the ranks: ONE variable-size all-to-all per movement ----------
+# RCCL has neither scatterv nor gatherv; an all-to-all with split sizes is the grouped send/recv it
+# would take to write one, issued as one collective (no per-peer ordering to get wrong, one launch).
+# The split sizes are host integers, so every movement has one host synchronisation in front of it
+# (the sizes of compressed shards come from the size all-gather).
+
+def scatter_from_root(full: Optional[torch.Tensor], sizes: List[int], mine: torch.Tensor, src: int = 0,
+                      group=None) -> torch.Tensor:
+    """Rank `src` holds the concatenation of all shards (`sizes` bytes each, rank order); every
+    rank receives its shard into `mine` (sizes[rank] bytes)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert len(sizes) == world and mine.numel() == sizes[rank]
+    if rank == src:
+        send, in_split = full[: sum(sizes)], list(sizes)
+    else:
+        send, in_split = mine.new_empty(0), [0] * world
+    out_split = [sizes[rank] if r == src else 0 for r in range(world)]
+    dist.all_to_all_single(mine, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    return mine
+
+
+def gather_to_root(local: torch.Tensor, sizes: List[int], out: Optional[torch.Tensor], dst: int = 0,
+                   group=None) -> Optional[torch.Tensor]:
+    """Inverse of scatter_from_root with sizes known everywhere: rank r's `local` (sizes[r] bytes)
+    lands at offset sum(sizes[:r]) of `out` on rank `dst`."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert len(sizes) == world and local.numel() == sizes[rank]
+    in_split = [sizes[rank] if r == dst else 0 for r in range(world)]
+    if rank == dst:
+        recv, out_split = out[: sum(sizes)], list(sizes)
+    else:
+        recv, out_split = local.new_empty(0), [0] * world
+    dist.all_to_all_single(recv, local, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    return out if rank == dst else None
+
+
+def gatherv_to_root(local: torch.Tensor, local_len: int, dst: int = 0, group=None):
+    """Variable-size gather of the compressed shards: sizes are exchanged first (all-gather of one
+    int64 per rank), then the shards travel.  Returns (stream on `dst` or None, sizes list)."""
+    sizes, _ = exchange_stream_offsets(torch.tensor([local_len], dtype=torch.int64, device=local.device), group)
+    sizes_h = [int(x) for x in sizes.tolist()]
+    rank = dist.get_rank(group)
+    out = torch.empty(sum(sizes_h), dtype=torch.uint8, device=local.device) if rank == dst else None
+    gather_to_root(local[:local_len], sizes_h, out, dst, group)
+    return out, sizes_h
+
+
+def plan_decode_ranges(block_offsets, world: int) -> List[Tuple[int, int]]:
+    """Contiguous block ranges [b0, b1) per rank for DECODING a gathered stream, balanced by
+    compressed bytes: `block_offsets` = the nblocks+1 header offsets of the job's block
+    index (last = stream length).  Rank r gets the blocks whose header offset lies in its 1/world
+    share of the stream; every block goes to exactly one rank, ranks may be empty."""
+    offs = [int(x) for x in block_offsets]
+    nblocks = len(offs) - 1
+    if nblocks <= 0:
+        return [(0, 0)] * world
+    total = offs[-1]
+    import bisect
+    cuts = [0]
+    for r in range(1, world):
+        # first block whose header lies at or behind the r-th share boundary
+        cuts.append(max(cuts[-1], bisect.bisect_left(offs, (total * r + world - 1) // world, 0, nblocks)))
+    cuts.append(nblocks)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]

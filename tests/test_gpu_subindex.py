@@ -1,0 +1,235 @@
+"""GPU parity tests of the sub-index decode path (hufgpu_encode_sub / hufgpu_decode_sub).
+
+The sub-index is side information from the encoder; the decoder verifies it.  So two things are
+tested: with the encoder's own sub-index the output equals the oracle's decode, and with ANY other
+content of the sub-index buffer - garbage, zeros, the sub-index of another input - or a damaged
+stream, results and error codes are those of the plain indexed decode and of the oracle.
+"""
+import numpy as np
+import pytest
+
+from libhuffman_amd import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def codec(torch_mod):
+    from libhuffman_amd.codec import GpuCodec
+    c = GpuCodec(0)
+    yield c
+    c.close()
+
+
+def dev(torch, a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return torch.from_numpy(a).cuda() if a.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+
+
+def encode_sub(torch, codec, data, bs):
+    d = dev(torch, data)
+    sub = codec.new_sub_index(d.numel(), bs)
+    sub.fill_(-1)                                   # what the encoder does not write must not matter
+    stream, offs, length = codec.encode(d, bs, sub_index=sub)
+    return stream, offs, length, sub
+
+
+def decode_sub(torch, codec, stream, length, offs, n, bs, sub, relaxed=False, cap=None):
+    out = torch.zeros(max(cap if cap is not None else n, 1), dtype=torch.uint8, device="cuda")
+    nb = codec.block_count(n, bs)
+    raw = codec.decode(stream, length, offs, nb, out, relaxed=relaxed, sub_index=sub, raw_size=n, blocksize=bs)
+    return raw, out
+
+
+def random_data(rng, n, k, conc):
+    alphabet = rng.choice(256, size=k, replace=False)
+    p = rng.dirichlet(np.full(k, conc))
+    return alphabet[rng.choice(k, size=n, p=p)].astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind,n,bs", [
+    ("zipf255", 262144, 65536), ("uniform256", 262144, 65536), ("uniform255", 262144, 65536),
+    ("const41", 262144, 65536), ("zipf255", 65536 + 1000, 65536), ("zipf255", 2 << 20, 1 << 20),
+    ("logtext", 3 << 20, 1 << 20), ("zipf255", 300001, 0), ("uniform256", 1 << 20, 0),
+    ("zipf255", 100000, 1000), ("uniform255", 70001, 4097), ("zipf255", 5000, 37), ("const41", 1 << 20, 0),
+])
+def test_sub_index_roundtrip_equals_oracle(torch_mod, codec, oracle, kind, n, bs):
+    torch = torch_mod
+    data = datagen.GENERATORS[kind](n)
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    want = oracle.encode(data, bs)
+    got = stream.cpu().numpy()
+    assert got.size == want.size and np.array_equal(got, want)       # the stream does not change with the sub-index
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, sub, relaxed=True)
+    assert raw == n
+    assert torch.equal(out[:n], dev(torch, data))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sub_index_random_shapes(torch_mod, codec, oracle, seed):
+    torch = torch_mod
+    rng = np.random.default_rng(4200 + seed)
+    n = int(rng.integers(1, 400000))
+    k = int(rng.integers(1, 257))
+    data = random_data(rng, n, k, float(rng.choice([0.02, 0.3, 1.0, 10.0])))
+    bs = int(rng.choice([0, 31, 32, 33, 256, 1000, 8192, 16384, 16385, 65536, 100000, 131072]))
+    if bs and n // bs > 3000:
+        data = data[: bs * 3000]
+        n = data.size
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    want = oracle.encode(data, bs)
+    assert np.array_equal(stream.cpu().numpy(), want)
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, sub, relaxed=True)
+    assert raw == n and torch.equal(out[:n], dev(torch, data)), (n, k, bs)
+
+
+def test_sub_index_deep_codes(torch_mod, codec):
+    """Fibonacci-weighted symbols: codes far beyond the 12 table bits, groups of many hundred bits."""
+    torch = torch_mod
+    for bs, nsym in ((65536, 22), (1 << 20, 28), (8 << 20, 32)):
+        fib = [1, 1]
+        while len(fib) < nsym:
+            fib.append(fib[-1] + fib[-2])
+        w = np.array(fib[:nsym], dtype=np.float64)
+        counts = np.maximum(1, np.floor(w / w.sum() * bs)).astype(np.int64)
+        counts[-1] += bs - counts.sum()
+        block = np.repeat(np.arange(nsym, dtype=np.uint8), counts)
+        rng = np.random.default_rng(bs)
+        # rare (deep) symbols first, so that whole tiles hold long codes only
+        data = np.concatenate([block, rng.permutation(block)])
+        stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+        raw, out = decode_sub(torch, codec, stream, length, offs, data.size, bs, sub)
+        assert raw == data.size and torch.equal(out[:data.size], dev(torch, data)), bs
+
+
+@pytest.mark.parametrize("what", ["garbage", "zeros", "ones", "other_input", "shifted", "one_group_off", "tile_off"])
+def test_wrong_sub_index_costs_time_not_correctness(torch_mod, codec, what):
+    torch = torch_mod
+    n, bs = 5 * 65536 + 777, 65536
+    data = datagen.zipf255(n)
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    bad = sub.clone()
+    nb = codec.block_count(n, bs)
+    tiles = nb * ((bs + 8191) // 8192)               # int64 words of tile starts in front of the group counts
+    if what == "garbage":
+        bad = torch.randint(-2**62, 2**62, bad.shape, dtype=torch.int64, device="cuda")
+    elif what == "zeros":
+        bad.zero_()
+    elif what == "ones":
+        bad.fill_(-1)
+    elif what == "other_input":
+        _, _, _, bad = encode_sub(torch, codec, datagen.uniform255(n), bs)
+    elif what == "shifted":
+        bad = torch.roll(sub, 1)
+    elif what == "one_group_off":
+        v = bad.view(torch.int16)
+        g = 4 * tiles + 3 * 2048 + 100               # group 100 of block 3: one bit moves to its neighbour
+        v[g] += 1
+        v[g + 1] -= 1
+    elif what == "tile_off":
+        bad[2 * 8 + 5] += 8                          # tile 5 of block 2
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, bad)
+    assert raw == n and torch.equal(out[:n], dev(torch, data)), what
+    # and the codec context is as good as new afterwards
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, sub)
+    assert raw == n and torch.equal(out[:n], dev(torch, data))
+
+
+def test_damaged_stream_with_sub_index_matches_plain_decode(torch_mod, codec, oracle):
+    """A stream damaged after the encode: error code and delivered blocks are those of the decode
+    without the sub-index (which the other tests pin to the reference)."""
+    torch = torch_mod
+    n, bs = 6 * 65536, 65536
+    rng = np.random.default_rng(77)
+    for kind in ("zipf255", "uniform255", "const41"):
+        data = datagen.GENERATORS[kind](n)
+        stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+        offs_h = offs.cpu().numpy()
+        nb = codec.block_count(n, bs)
+        for trial in range(12):
+            s = stream[:length].clone()
+            b = int(rng.integers(0, nb))
+            lo, hi = int(offs_h[b]), int(offs_h[b + 1])
+            mode = trial % 4
+            if mode == 0:                             # a flipped payload bit
+                pos = int(rng.integers(lo + (hi - lo) // 2, hi))
+                s[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:                           # payload bytes of 0xff (walks leave the tree at once)
+                pos = int(rng.integers(lo + (hi - lo) // 2, hi - 8))
+                s[pos:pos + 8] = 0xff
+            elif mode == 2:                           # a damaged tree entry
+                pos = lo + 10 + 2 * int(rng.integers(0, 5))
+                s[pos] ^= 0x55
+            else:                                     # a damaged block length
+                s[lo + 1] ^= 0x01
+            out_a = torch.zeros(n + 65536, dtype=torch.uint8, device="cuda")
+            out_b = torch.zeros(n + 65536, dtype=torch.uint8, device="cuda")
+            from libhuffman_amd.codec import HuffmanGpuError
+            res = []
+            for out, kw in ((out_a, {}), (out_b, dict(sub_index=sub, raw_size=n, blocksize=bs))):
+                try:
+                    raw = codec.decode(s, length, offs, nb, out, **kw)
+                    res.append((0, raw))
+                except HuffmanGpuError as e:
+                    res.append((e.err, codec.decode_result() if False else None))
+            assert res[0][0] == res[1][0], (kind, trial, res)
+            if res[0][0] == 0:
+                assert res[0][1] == res[1][1] and torch.equal(out_a, out_b), (kind, trial)
+            else:
+                # blocks before the failing one are delivered by both
+                first_bad = b * bs
+                assert torch.equal(out_a[:first_bad], out_b[:first_bad]), (kind, trial)
+                assert torch.equal(out_b[:first_bad], dev(torch, data[:first_bad])), (kind, trial)
+
+
+def test_sub_index_output_too_small(torch_mod, codec):
+    torch = torch_mod
+    from libhuffman_amd.codec import HuffmanGpuError
+    n, bs = 4 * 65536, 65536
+    data = datagen.zipf255(n)
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    with pytest.raises(HuffmanGpuError) as ei:
+        decode_sub(torch, codec, stream, length, offs, n, bs, sub, cap=n - 1)
+    assert ei.value.err == 1                          # HUF_ERROR_MEMORY_ALLOCATION, like hufgpu_decode
+
+
+def test_sub_index_unaligned_output(torch_mod, codec):
+    torch = torch_mod
+    n, bs = 3 * 65536 + 5, 65536
+    data = datagen.zipf255(n)
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    nb = codec.block_count(n, bs)
+    for shift in (1, 4, 7, 13):
+        big = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        out = big[shift:shift + n]
+        raw = codec.decode(stream, length, offs, nb, out, sub_index=sub, raw_size=n, blocksize=bs)
+        assert raw == n and torch.equal(out, dev(torch, data)), shift
+        assert int(big[:shift].sum()) == 0 and int(big[shift + n:].sum()) == 0
+
+
+def test_full_size_sub_index_roundtrip(torch_mod, codec):
+    """BASELINE configs 2-4 at 1 GiB: encode with the sub-index, decode with it, compare all bytes."""
+    torch = torch_mod
+    n, bs = 1 << 30, 65536
+    data = torch.empty(n, dtype=torch.uint8, device="cuda")
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device="cuda")
+    sub = codec.new_sub_index(n, bs)
+    nb = codec.block_count(n, bs)
+    for kind in ("zipf255", "uniform256", "const41"):
+        codec.fill(data, kind)
+        stream, offs, length = codec.encode(data, bs, out=out, sub_index=sub)
+        back.zero_()
+        raw = codec.decode(out, length, offs, nb, back, relaxed=True, sub_index=sub, raw_size=n, blocksize=bs)
+        assert raw == n and torch.equal(back, data), kind
+        # the plain indexed decode of the same stream agrees
+        back.zero_()
+        raw = codec.decode(out, length, offs, nb, back, relaxed=True)
+        assert raw == n and torch.equal(back, data), kind

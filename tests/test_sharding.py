@@ -67,6 +67,25 @@ def _worker(rank, world, port, n_total, bs, q):
             assert torch.equal(whole, torch.cat(parts))
         else:
             assert whole is None
+        # 4. the same movements as ONE variable-size all-to-all each (what bench.py's root placement times)
+        from libhuffman_amd.sharding import scatter_from_root, gather_to_root, gatherv_to_root, shard_plan
+        in_sizes = [h - l for l, h in shard_plan(n_total, bs, world)]
+        mine2 = torch.empty(hi - lo, dtype=torch.uint8)
+        scatter_from_root(full if rank == 0 else None, in_sizes, mine2, 0)
+        assert torch.equal(mine2, full[lo:hi])
+        whole2, sizes2 = gatherv_to_root(padded, comp_len, 0)
+        assert sizes2 == want_sizes
+        if rank == 0:
+            assert torch.equal(whole2, torch.cat(parts))
+        else:
+            assert whole2 is None
+        back_shard = torch.empty(comp_len, dtype=torch.uint8)
+        scatter_from_root(whole2, sizes2, back_shard, 0)                    # compressed shards out again
+        assert torch.equal(back_shard, comp)
+        result = torch.empty(n_total, dtype=torch.uint8) if rank == 0 else None
+        gather_to_root(mine2, in_sizes, result, 0)
+        if rank == 0:
+            assert torch.equal(result, full)
         q.put((rank, "ok"))
     except Exception as e:            # pragma: no cover
         q.put((rank, repr(e)))
@@ -86,3 +105,21 @@ def test_exchange_over_gloo(world, n_total, bs):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def test_decode_ranges_balanced_by_compressed_bytes():
+    from libhuffman_amd.sharding import plan_decode_ranges
+    # 8 blocks: the first four compress 4x better than the last four
+    sizes = [100, 100, 100, 100, 400, 400, 400, 400]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    plan = plan_decode_ranges(offs, 2)
+    assert plan == [(0, 6), (6, 8)]                    # by bytes: 1000 | 1000, not 4 blocks | 4 blocks
+    for world in (1, 2, 3, 5, 8, 16):
+        plan = plan_decode_ranges(offs, world)
+        assert len(plan) == world and plan[0][0] == 0 and plan[-1][1] == 8
+        assert all(plan[r][1] == plan[r + 1][0] for r in range(world - 1))      # every block exactly once, in order
+        share = [offs[b1] - offs[b0] for b0, b1 in plan]
+        assert max(share) <= offs[-1] / world + max(sizes)
+    assert plan_decode_ranges([0], 4) == [(0, 0)] * 4

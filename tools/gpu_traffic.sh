@@ -3,12 +3,13 @@
 # MI355X_MICROARCH.md prescribes; FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 # wide coalesced reads at half their bytes -> doubled below, WRITE_SIZE is exact for 16-B stores).
 WL=${1:-const41}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/traffic_$WL
+OUT=$ROOT/gpurun_out/traffic_$WL
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o rd -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --workload $WL --no-cpu-baseline --no-verify > $OUT/rd.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o wr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --workload $WL --no-cpu-baseline --no-verify > $OUT/wr.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o rd -- python3 $ROOT/bench.py --steps 3 --warmup 1 --workload $WL --no-cpu-baseline --no-verify > $OUT/rd.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o wr -- python3 $ROOT/bench.py --steps 3 --warmup 1 --workload $WL --no-cpu-baseline --no-verify > $OUT/wr.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 res = collections.defaultdict(dict)

@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO_PATH
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
+           "-Wall", "-Wno-unused-function"] + os.environ.get("HUF_EXTRA_FLAGS", "").split() + [   # tooling experiments only
            "-x", "hip", os.path.join(CSRC, "hufgpu_api.hip"),
            "-x", "hip", os.path.join(CSRC, "huf_host.cpp"),
            "-o", SO_PATH + ".tmp", "-lpthread"]

@@ -396,7 +396,7 @@ static HufSubIndex sub_index_view(void *d_sub, uint64_t n, uint64_t blocksize)
     if (!d_sub || n == 0) return v;
     if (blocksize == 0) blocksize = n;
     const uint64_t nb = hufgpu_block_count(n, blocksize);
-    v.gpb = (blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
+    v.gpb = ((blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP + 7) & ~7ull;   /* rows of 16-byte multiples */
     v.tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
     v.tile_bits = (uint64_t *)d_sub;
     v.group_bits = (uint16_t *)((uint64_t *)d_sub + nb * v.tpb);
@@ -408,7 +408,7 @@ extern "C" uint64_t hufgpu_sub_index_bytes(uint64_t n, uint64_t blocksize)
     if (n == 0) return 0;
     if (blocksize == 0) blocksize = n;
     const uint64_t nb = hufgpu_block_count(n, blocksize);
-    const uint64_t gpb = (blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
+    const uint64_t gpb = ((blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP + 7) & ~7ull;
     const uint64_t tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
     return nb * tpb * sizeof(uint64_t) + nb * gpb * sizeof(uint16_t);
 }

@@ -172,11 +172,12 @@ struct DecShared {
     uint16_t left[ENT];
     uint16_t right[ENT];
     uint16_t lut[1 << DEC_LUT_BITS];
-    uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
+    __attribute__((aligned(16))) uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
                                             (a padded linear layout has a cheaper address but costs 2 KiB = one workgroup per CU) */
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
     uint32_t wend[THREADS / 64];         /* end position of the last lane of each wave (neighbours use shuffles) */
     uint32_t part[THREADS / 64];
+    uint32_t wtile[32];                  /* decode_sub: payload bits of the chunk's wave tiles */
     int efflen;
     uint32_t badsym;                     /* segment symbol index of the first walk that left the tree */
     uint32_t firstone;                   /* single-leaf trees: first set payload bit */

@@ -34,6 +34,7 @@ namespace hufgpu {
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
 #define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: 31 table codewords + two refills of a lane that runs wild */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
+#define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
 
 /* 64-bit left-aligned bit buffer over the linearly staged payload words (big-endian words) */
 struct LinReader {
@@ -114,139 +115,251 @@ __device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, LinR
     return e;
 }
 
-/* The symbols [sym0, sym1) of a block (sym0 a multiple of THREADS * 32) with the block's sub-index.
- * Tables are in sh.  Returns true (workgroup-uniform) when everything was verified; *end_bit = the
- * payload bit behind the chunk's last symbol. */
+/* LDS of the sub-index path inside DecShared: the area of the self-synchronising decoder's payload
+ * image and marks holds one private slice of staged payload words per WAVE and, at its end, the
+ * chunk's group bit counts (fetched by LDS-DMA while the tables are built; the table build's
+ * scratch lies in front of them). */
+template <int THREADS>
+struct DsubLds {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr uint32_t AREA_WORDS = (uint32_t)((sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark)) / sizeof(uint32_t));
+    static constexpr uint32_t GROUPS = DSUB_CHUNK_SYMS / DSUB_SPL;          /* groups per chunk */
+    static constexpr uint32_t WTILES = GROUPS / 64;                         /* wave tiles (64 groups) per chunk */
+    static constexpr uint32_t GB_WORDS = GROUPS / 2;                        /* two 16-bit counts per word */
+    static constexpr uint32_t SLICE_WORDS = ((AREA_WORDS - GB_WORDS) / WAVES) & ~3u;
+    static constexpr uint32_t CAP_BITS = (SLICE_WORDS - DSUB_SLACK_WORDS - 2 - 4) * 32u;   /* (- 4: slices are written 16 bytes at a time) */
+    static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
+    static_assert(offsetof(DecShared<THREADS>, pay) % 16 == 0 && SLICE_WORDS % 4 == 0, "16-byte slice stores");
+    static_assert(CAP_BITS >= DSUB_MAX_GROUP_BITS + 32u, "one lane's group always fits a slice");
+    static_assert(SLICE_WORDS <= 3 * 256, "three staging steps of 64 lanes x 4 words cover a slice");
+    static_assert((AREA_WORDS - GB_WORDS) * 4 >= ((DecShared<THREADS>::ENT + 1) / 2) * 4 + 2 * 2048 * 2, "the table build's scratch lies in front of the group counts");
+    static_assert(WTILES <= 64 && WTILES % WAVES == 0 && WTILES <= sizeof(DecShared<THREADS>::wtile) / 4, "a wave scans the tile totals in one step");
+    __device__ static __forceinline__ uint32_t *slice(DecShared<THREADS> &sh, int wave) { return sh.pay + (uint32_t)wave * SLICE_WORDS; }
+    __device__ static __forceinline__ uint32_t *gb(DecShared<THREADS> &sh) { return sh.pay + (AREA_WORDS - GB_WORDS); }
+};
+
+/* The chunk's group bit counts are requested first (LDS-DMA: no register waits for them), so that
+ * their latency passes under the table build.  grp = the chunk's first count (4-byte aligned: rows
+ * of the sub-index are padded), ngrp = groups the chunk has. */
+template <int THREADS>
+__device__ __forceinline__ void dsub_prefetch(DecShared<THREADS> &sh, const uint16_t *__restrict__ grp, uint32_t ngrp)
+{
+    const uint32_t *g32 = reinterpret_cast<const uint32_t *>(grp);
+    const uint32_t nd = (ngrp + 1u) >> 1;
+    const uint32_t wave = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t k = 0; k < DsubLds<THREADS>::GB_WORDS / THREADS; k++) {
+        const uint32_t d = k * THREADS + threadIdx.x;
+        if (d < nd) __builtin_amdgcn_global_load_lds(g32 + d, DsubLds<THREADS>::gb(sh) + k * THREADS + wave * 64u, 4, 0, 0);
+    }
+}
+
+/* Inclusive prefix sum over the wave by DPP: shifts inside the rows of 16 lanes, then lane 15 of a
+ * row into the next row, then lane 31 into the upper half (six VALU instructions, no LDS, and no
+ * per-step lane address to keep - the ds_bpermute form of __shfl_up had its six address registers
+ * hoisted out of the tile loop, spilled, and reloaded from scratch for every tile). */
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1, 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_lane_u32(uint32_t v, uint32_t uniform_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uniform_lane);
+}
+
+/* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.
+ * Tables are in sh, dsub_prefetch has been called.  Returns true (workgroup-uniform) when everything
+ * was verified; *end_bit = the payload bit behind the chunk's last symbol.  T0 = the chunk's first
+ * payload bit, as told.
+ *
+ * After one scan of the group counts every WAVE is on its own: a wave tile = 64 groups = 2 048
+ * symbols; wave w takes tiles w, w + 8, ...; it stages the tile's payload words in its private LDS
+ * slice (LDS operations of one wave are in order: no barrier), decodes, stores.  The waves of a
+ * workgroup drift apart, so one wave's memory latency passes under the other waves' decoding; the
+ * version with workgroup-wide tiles spent 2/3 of its time in barriers behind loads. */
 template <int THREADS>
 __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes,
-                                   uint64_t block_len, uint64_t sym0, uint64_t sym1,
-                                   const uint64_t *__restrict__ tile_bits,
-                                   const uint16_t *__restrict__ group_bits, uint8_t *gout, uint64_t *end_bit)
+                                   uint64_t sym0, uint64_t sym1, uint64_t T0, uint8_t *gout, uint64_t *end_bit)
 {
+    typedef DsubLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
-    constexpr int TILE = THREADS * DSUB_SPL;
-    /* the staged words take the place of the self-synchronising decoder's payload image and marks */
-    uint32_t *stage = sh.pay;
-    constexpr uint32_t STAGE_WORDS = (uint32_t)((sizeof(sh.pay) + sizeof(sh.mark)) / sizeof(uint32_t));
-    static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(sh.pay), "stage = pay + mark");
-    constexpr uint32_t CAP_BITS = (STAGE_WORDS - DSUB_SLACK_WORDS - 2) * 32u;
-    static_assert(CAP_BITS >= 64u * DSUB_MAX_GROUP_BITS + 32u, "one wave's groups always fit the stage");
+    constexpr uint32_t CAP_BITS = L::CAP_BITS;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const uint64_t pay_bits = pay_bytes * 8ull;
-    uint32_t *s_wtot = sh.part;                    /* [WAVES] */
+    const uint16_t *s_gb = reinterpret_cast<const uint16_t *>(L::gb(sh));
+    uint32_t *stage = L::slice(sh, wave);
+    const uint32_t ngrp = (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL);
     bool ok = true;
-    (void)block_len;
+    unsigned long long pt = DPROF_T();
 
-    uint64_t T0 = tile_bits[sym0 / HUF_SUB_TILE];  /* first payload bit of the chunk, as told */
+    /* the group counts requested by dsub_prefetch have landed (every wave waits for its own
+     * requests, the barrier makes them everybody's) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (sym0 == 0 && T0 != 0) ok = false;          /* (a) */
 
-    for (uint64_t t0 = sym0; t0 < sym1; t0 += TILE) {
-        const uint64_t my0 = t0 + (uint64_t)tid * DSUB_SPL;
-        uint32_t nsym = 0, gb = 0;
-        if (my0 < sym1) {
-            nsym = (uint32_t)dmin<uint64_t>(DSUB_SPL, sym1 - my0);
-            gb = group_bits[my0 / DSUB_SPL];
-            if (gb > DSUB_MAX_GROUP_BITS) { gb = DSUB_MAX_GROUP_BITS; ok = false; }
-        }
-        /* exclusive sums of the groups' bits: in the wave by shuffles, across waves through LDS */
-        uint32_t inc = gb;
+    /* bits of every wave tile, then their exclusive sums (lane q of every wave holds tile q's) */
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_wtot[wave] = inc;
-        __syncthreads();
-        uint32_t wtot[WAVES], tile_total = 0, mybase = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            wtot[w] = uni32(s_wtot[w]);
-            if (w == wave) mybase = tile_total;
-            tile_total += wtot[w];
-        }
-        const uint32_t ex = mybase + inc - gb;     /* my first bit relative to T0 */
-        if (T0 + tile_total > pay_bits) ok = false;                /* (b): bits past the payload */
+    for (uint32_t k = 0; k < L::WTILES / WAVES; k++) {
+        const uint32_t q = (uint32_t)wave * (L::WTILES / WAVES) + k;
+        const uint32_t g = q * 64u + (uint32_t)lane;
+        uint32_t v = (g < ngrp) ? (uint32_t)s_gb[g] : 0u;
+        if (v > DSUB_MAX_GROUP_BITS) { v = DSUB_MAX_GROUP_BITS; ok = false; }
+        v = wave_lane_u32(wave_incl_scan_u32(v), 63);
+        if (lane == 0) sh.wtile[q] = v;
+    }
+    __syncthreads();
+    const uint32_t tbits_q = ((uint32_t)lane < L::WTILES) ? sh.wtile[lane] : 0u;
+    const uint32_t tincl = wave_incl_scan_u32(tbits_q);
+    const uint32_t tstart_q = tincl - tbits_q;                       /* lane q: first bit of tile q relative to T0 */
+    const uint32_t chunk_bits = wave_lane_u32(tincl, 63);
+    if (T0 + chunk_bits > pay_bits) ok = false;                      /* (b): bits past the payload */
+    DPROF_ADD(8, pt);
 
-        /* One pass stages the bits of all waves; only when they do not fit the stage (codes far
-         * longer than the 9-bit average) every wave gets a pass of its own. */
-        const bool single = (uint32_t)(T0 & 31ull) + tile_total <= CAP_BITS;
-        const int npass = single ? 1 : WAVES;
 #pragma unroll 1
-        for (int ps = 0; ps < npass; ps++) {
-            uint32_t pbase = 0, pbits = tile_total;                /* the pass's first bit (relative to T0) and bit count */
-            if (!single) {
-                pbits = 0;
-#pragma unroll
-                for (int w = 0; w < WAVES; w++) {
-                    if (w < ps) pbase += wtot[w];
-                    if (w == ps) pbits = wtot[w];
-                }
-            }
-            const bool mine = single || wave == ps;
-            const uint64_t first = T0 + pbase;
-            const uint64_t origin = first & ~31ull;                /* payload bit of stage word 0 */
+    for (uint32_t q = (uint32_t)wave; q * 64u < ngrp; q += WAVES) {
+        pt = DPROF_T();
+        const uint32_t g = q * 64u + (uint32_t)lane;
+        const uint64_t my0 = sym0 + (uint64_t)g * DSUB_SPL;
+        uint32_t nsym = 0, gb = 0;
+        if (g < ngrp) {
+            nsym = (uint32_t)dmin<uint64_t>(DSUB_SPL, sym1 - my0);
+            gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
+        }
+        const uint32_t incl = wave_incl_scan_u32(gb);
+        const uint32_t ex = incl - gb;                               /* my first bit relative to the tile's */
+        const uint64_t tstart = T0 + wave_lane_u32(tstart_q, uni32(q));
+
+        /* one pass stages the bits of all 64 lanes; only when they do not fit the slice (codes far
+         * longer than the 9-bit average) the lanes are taken in several runs */
+        uint32_t l0 = 0;
+        while (l0 < 64u) {
+            const uint32_t base = wave_lane_u32(ex, uni32(l0));
+            const uint64_t first = tstart + base;
+            const uint64_t origin = first & ~31ull;                  /* payload bit of stage word 0 */
             const uint32_t lead = (uint32_t)(first - origin);
-            const uint32_t need_bits = lead + pbits;
-            const uint32_t nwords = ((need_bits + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;   /* <= STAGE_WORDS */
+            const unsigned long long over = __ballot((uint32_t)lane >= l0 && lead + (incl - base) > CAP_BITS);
+            const uint32_t l1 = over ? (uint32_t)__builtin_ctzll(over) : 64u;      /* > l0: one group always fits */
+            const uint32_t need_bits = lead + (wave_lane_u32(incl, uni32(l1 - 1u)) - base);
+            const uint32_t nwords = ((need_bits + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;   /* <= SLICE_WORDS - 4 */
             const uint32_t lim = ((need_bits + 31u) >> 5) * 32u + 64u;                  /* bits a walk may look at */
-            /* ---- stage: big-endian words of payload bytes [origin / 8 + 4 i, + 4) ---- */
+#ifndef DSUB_ABLATE_STAGE
             {
+                /* Four words per lane and step: 20 payload bytes at a 4-byte aligned address (one
+                 * 16-byte and one 4-byte load), four v_perm (byte order and the payload's byte
+                 * misalignment in one selector), one 16-byte LDS store; all loads before the first use. */
+                struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
+                constexpr int STEPS = 3;
                 const uint64_t byte0 = origin >> 3;
-                int tl = tid;
-                asm volatile("" : "+v"(tl));
-                if (byte0 + 4ull * nwords + 8ull <= pay_bytes) {
+                if (byte0 + 4ull * nwords + 24ull <= pay_bytes) {
                     const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));
                     const uint32_t m = (uint32_t)(a & 3u);
                     const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(a - m);
-                    for (uint32_t i = (uint32_t)tl; i < nwords; i += THREADS)
-                        stage[i] = __builtin_amdgcn_perm(q[i + 1], q[i], sel);
+                    const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
+                    Q4 v[STEPS];
+                    uint32_t x[STEPS];
+#pragma unroll
+                    for (int k = 0; k < STEPS; k++) {
+                        const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
+                        if (i4 < nwords) {
+#ifdef DSUB_STAGE_DWORDS          /* (diagnostic: five 4-byte loads instead of a 4-byte aligned 16-byte load) */
+                            const volatile uint32_t *vq = qw + i4;
+                            v[k].x = vq[0]; v[k].y = vq[1]; v[k].z = vq[2]; v[k].w = vq[3];
+#else
+                            v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
+#endif
+                            x[k] = qw[i4 + 4];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < STEPS; k++) {
+                        const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
+                        if (i4 < nwords)
+                            *reinterpret_cast<uint4 *>(stage + i4) =
+                                make_uint4(__builtin_amdgcn_perm(v[k].y, v[k].x, sel), __builtin_amdgcn_perm(v[k].z, v[k].y, sel),
+                                           __builtin_amdgcn_perm(v[k].w, v[k].z, sel), __builtin_amdgcn_perm(x[k], v[k].w, sel));
+                    }
                 } else {
-                    for (uint32_t i = (uint32_t)tl; i < nwords; i += THREADS)
+                    for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u)
                         stage[i] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
                 }
             }
-            __syncthreads();
-            if (mine && nsym) {
-                const uint32_t s = lead + (ex - pbase);
+#endif
+            DPROF_ADD(9, pt); pt = DPROF_T();
+#ifdef DSUB_ABLATE_LANES
+            if (false) {
+#else
+            if ((uint32_t)lane >= l0 && (uint32_t)lane < l1 && nsym) {
+#endif
+                const uint32_t s = lead + (ex - base);
                 LinReader rd;
                 rd.st = stage;
                 rd.load(s);
                 uint8_t *dst = gout + my0;
+                uint32_t special = 0;                               /* OR of the table entries: bits 14/15 = not a leaf */
                 if (nsym == DSUB_SPL) {
-                    uint32_t w[8];
+                    /* The common case has no branch: an entry that is not a leaf (a `long` code, a
+                     * walk that leaves the tree) advances by its 5-bit field like a leaf and is only
+                     * remembered; such a lane decodes its group again below, step by step.
+                     * Two rounds of 16 symbols (rolled: the unrolled form does not fit 64 VGPRs), each
+                     * stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half of a
+                     * 32-byte sector and the other half follows a round later; streaming (nt) stores
+                     * then reach HBM as partial writes (1.05 -> 0.81 ms per GiB without nt; turning the
+                     * wave's 2 KiB round in LDS for whole-line nt stores needs 8 more registers, and with
+                     * 80 VGPRs = 3 workgroups per CU the kernel takes 0.97 ms). */
+                    const bool aligned = (((uintptr_t)dst) & 15u) == 0;
+#pragma unroll 1
+                    for (int h = 0; h < 2; h++) {
+                        uint32_t w[4];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        uint32_t acc = 0;
-                        acc = __builtin_amdgcn_alignbit(dsub_next<THREADS>(sh, rd, lim, ok), acc, 8);
-                        acc = __builtin_amdgcn_alignbit(dsub_next<THREADS>(sh, rd, lim, ok), acc, 8);
-                        if (rd.avail <= 32) rd.refill();
-                        acc = __builtin_amdgcn_alignbit(dsub_next<THREADS>(sh, rd, lim, ok), acc, 8);
-                        acc = __builtin_amdgcn_alignbit(dsub_next<THREADS>(sh, rd, lim, ok), acc, 8);
-                        if (rd.avail <= 32) rd.refill();
-                        w[k] = acc;
-                    }
-                    if ((((uintptr_t)dst) & 15u) == 0) {
-                        store_stream16(reinterpret_cast<uint4 *>(dst), make_uint4(w[0], w[1], w[2], w[3]));
-                        store_stream16(reinterpret_cast<uint4 *>(dst) + 1, make_uint4(w[4], w[5], w[6], w[7]));
-                    } else {
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t acc = 0;
 #pragma unroll
-                        for (int k = 0; k < 32; k++) dst[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t e = sh.lut[rd.index()];
+                                special |= e;
+                                acc = __builtin_amdgcn_alignbit(e, acc, 8);
+                                rd.consume((e >> 8) & 31u);
+                                if (j & 1) { if (rd.avail <= 32) rd.refill(); }
+                            }
+                            w[k] = acc;
+                        }
+#ifdef DSUB_ABLATE_STORES
+                        if (w[0] == 0x12345678u && w[3] == 0x9abcdef0u) dst[0] = 1;
+                        else if (false) {
+#else
+                        if (aligned) {
+#endif
+                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                        }
                     }
-                } else {                                            /* the block's last, short group */
-                    for (uint32_t k = 0; k < nsym; k++) {
-                        dst[k] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
-                        if (rd.avail <= 32) rd.refill();
+                }
+                if (__builtin_expect(__ballot(nsym != DSUB_SPL || (special & 0xC000u)) != 0ull, 0)) {
+                    if (nsym != DSUB_SPL || (special & 0xC000u)) {  /* the block's last, short group; groups with long codes */
+                        rd.load(s);
+                        for (uint32_t k = 0; k < nsym; k++) {
+                            dst[k] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+                            if (rd.avail <= 32) rd.refill();
+                        }
                     }
                 }
                 if (rd.pos() - s != gb) ok = false;                 /* (b): exactly the bits of the group */
             }
-            __syncthreads();                                        /* the stage is rewritten by the next pass */
+            DPROF_ADD(10, pt); pt = DPROF_T();
+            l0 = l1;
         }
-        T0 += tile_total;
     }
-    *end_bit = T0;
+    *end_bit = T0 + chunk_bits;
     return __syncthreads_and(ok ? 1 : 0) != 0;
 }
 
@@ -258,10 +371,12 @@ struct DecFixList {
     uint32_t *flag;       /* [nblocks] block already listed */
 };
 
-#define DSUB_CHUNK_SYMS 65536u        /* symbols one workgroup decodes: four tiles of 512 x 32 */
 
+#ifndef DSUB_WAVES_PER_SIMD
+#define DSUB_WAVES_PER_SIMD 8
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_sub_kernel(
+__global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kernel(
     const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
     const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
     uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
@@ -272,8 +387,14 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_sub_kernel
     const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x / cpb;
     const uint32_t c = (uint32_t)(blockIdx.x % cpb);
-    const HufDecodeMeta m = dmeta[blk];
-    const uint64_t obase = lens.gprefix[blk / SCAN_GROUP] + lens.local[blk];
+    /* everything about the block is the same in all lanes: kept in SGPRs (held in VGPRs these
+     * values pushed the tile loop's state out to scratch, 8 reloads per wave tile) */
+    HufDecodeMeta m = dmeta[blk];
+    m.block_len = uni64(m.block_len);
+    m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
+    m.leaf = (int16_t)uni32((uint32_t)(uint16_t)m.leaf);
+    m.status = (int32_t)uni32((uint32_t)m.status);
+    const uint64_t obase = uni64(lens.gprefix[blk / SCAN_GROUP] + lens.local[blk]);
     if (tid == 0 && c == 0) out_offsets[blk] = obase;
     if (m.status != HUFE_OK || m.block_len == 0) return;            /* header errors were recorded by decode_prepare */
     const uint64_t sym0 = (uint64_t)c * DSUB_CHUNK_SYMS;
@@ -292,15 +413,21 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_sub_kernel
         return;
     }
     const uint64_t sym1 = dmin<uint64_t>(m.block_len, sym0 + DSUB_CHUNK_SYMS);
-    const uint64_t o0 = offsets[blk];
-    const uint64_t o1 = dmin<uint64_t>(offsets[blk + 1], stream_len);
+    const uint64_t o0 = uni64(offsets[blk]);
+    const uint64_t o1 = dmin<uint64_t>(uni64(offsets[blk + 1]), stream_len);
     const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
     const uint8_t *tree = stream + o0 + HUF_HEADER_FIXED;
     const uint8_t *pay = tree + 2 * (int)m.tree_len;
     bool good;
     int leaf = m.leaf;
     int rc = HUFE_OK;
+    if (leaf < 0)
+        dsub_prefetch<THREADS>(sh, sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL,
+                               (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
+    const uint64_t T0 = uni64(sub.tile_bits[blk * sub.tpb + sym0 / HUF_SUB_TILE]);   /* first payload bit of the chunk, as told */
+#ifndef DSUB_ABLATE_TABLES      /* (diagnostic builds: what the kernel costs without one of its phases) */
     if (leaf < 0) rc = dec_build_tables<THREADS, false>(sh, tree, m.tree_len, &leaf);
+#endif
     if (rc != HUFE_OK) {
         good = false;
     } else if (leaf >= 0) {
@@ -311,11 +438,13 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_sub_kernel
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
         uint64_t end_bit = 0;
-        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, m.block_len, sym0, sym1, sub.tile_bits + blk * sub.tpb,
-                                           sub.group_bits + blk * sub.gpb, out + obase, &end_bit);
+        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, sym0, sym1, T0, out + obase, &end_bit);
         /* (c) the next chunk starts where this one ends */
         if (good && sym1 < m.block_len && sub.tile_bits[blk * sub.tpb + sym1 / HUF_SUB_TILE] != end_bit) good = false;
     }
+#ifdef DSUB_ABLATE_VERIFY       /* (diagnostic builds with a phase removed produce garbage: do not decode it again) */
+    good = true;
+#endif
     if (!good && tid == 0) {
         if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
     }

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
 #endif
 #define DEC_SUB_BITS (32 * DEC_SUB_WORDS)
 #define DEC_NULL 0xffffu
+#define DEC_LEAF_LR 0xffffffffu       /* lr[] of a childless node */
 #define DEC_XCOLS ((40 + DEC_SUB_WORDS - 1) / DEC_SUB_WORDS + 1)   /* >= 40 extra words > (1025 + LUT_BITS)/32: deepest bit walk */
 #define DEC_EXH 0xffffffffu           /* "a codeword ran past the readable payload" */
 #define DEC_NO_BAD 0xffffffffu
@@ -169,8 +170,7 @@ struct DecShared {
     static constexpr int ENT = HUF_TREE_MAX + 1;
     static constexpr int COLS = THREADS + DEC_XCOLS;
     int16_t ent[ENT];
-    uint16_t left[ENT];
-    uint16_t right[ENT];
+    uint32_t lr[ENT];                    /* children of entry i: left in the low half, right in the high half, DEC_NULL = none */
     uint16_t lut[1 << DEC_LUT_BITS];
     __attribute__((aligned(16))) uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
                                             (a padded linear layout has a cheaper address but costs 2 KiB = one workgroup per CU) */
@@ -304,6 +304,8 @@ struct BufReader {
 
 enum { CW_OK = 0, CW_BAD = 1, CW_EXH = 2 };
 
+__device__ __forceinline__ uint32_t dec_child(uint32_t lr, uint32_t bit) { return bit ? (lr >> 16) : (lr & 0xffffu); }
+
 /* Table entries (uint16):
  *   leaf    (len << 8) | symbol                     len = 1..DEC_LUT_BITS
  *   bad     0x4000 | nocw | (skip << 8) | bits      the walk leaves the tree at bit `bits` of the
@@ -337,10 +339,10 @@ __device__ __forceinline__ uint64_t dec_rare_packed(const DecShared<THREADS> &sh
         const uint32_t w = sh.pay[pay_slot<DecShared<THREADS>::COLS>(p >> 5)];
         const uint32_t bit = (w >> (31u - (p & 31u))) & 1u;
         p++;
-        const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+        const uint32_t nx = dec_child(sh.lr[node], bit);
         if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
         node = nx;
-        if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) break;
+        if (sh.lr[node] == DEC_LEAF_LR) break;
     }
     return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
 }
@@ -771,12 +773,23 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
     __syncthreads();           /* previous user of sh is done */
     uint16_t *s_open = reinterpret_cast<uint16_t *>(&sh.pay[0]);   /* S(i); payload not staged yet */
     static_assert(sizeof(sh.pay) >= ENT * sizeof(uint16_t), "S(i) scratch must fit");
-    for (int i = tid; i < ENT; i += THREADS) {
-        int16_t v = -1;
-        if (i < tree_len) v = (int16_t)((uint16_t)tree[2 * i] | ((uint16_t)tree[2 * i + 1] << 8));
-        sh.ent[i] = v;
-        sh.left[i] = DEC_NULL;
-        sh.right[i] = DEC_NULL;
+    {
+        /* entries 2t and 2t+1 from two aligned 32-bit loads per thread (a dword that holds a tree byte
+         * is readable), shifted by the tree's byte misalignment */
+        const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
+        const uint32_t mis = (uint32_t)(a & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);
+        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;           /* bytes from q[0] to the tree's end */
+        for (int t = tid; 2 * t < ENT; t += THREADS) {
+            const uint32_t lo = (4u * (uint32_t)t < nbytes) ? q[t] : 0u;
+            const uint32_t hi = (4u * (uint32_t)t + 4u < nbytes) ? q[t + 1] : 0u;
+            const uint32_t two = mis ? __builtin_amdgcn_alignbit(hi, lo, 8u * mis) : lo;
+            const int i = 2 * t;
+            sh.ent[i] = (i < tree_len) ? (int16_t)(two & 0xffffu) : (int16_t)-1;
+            if (i + 1 < ENT) sh.ent[i + 1] = (i + 1 < tree_len) ? (int16_t)(two >> 16) : (int16_t)-1;
+            sh.lr[i] = DEC_LEAF_LR;
+            if (i + 1 < ENT) sh.lr[i + 1] = DEC_LEAF_LR;
+        }
     }
     if (tid == 0) { sh.efflen = tree_len; sh.badsym = DEC_NO_BAD; sh.firstone = DEC_NO_BAD; sh.qend = 0; }
     __syncthreads();
@@ -792,7 +805,7 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
         }
         uint32_t tot;
         /* signed values scanned in two's complement */
-        const uint32_t ex = block_excl_scan<THREADS, uint32_t>((uint32_t)sum, sh.part, tot);
+        const uint32_t ex = block_excl_scan_u32<THREADS>((uint32_t)sum, sh.part, tot);
         int run = 1 + (int)ex;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
@@ -842,10 +855,12 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
             for (int h = (N >> 8) - 1; h >= 1; h--) s_min[h] = (uint16_t)dmin<uint32_t>(s_min[2 * h], s_min[2 * h + 1]);
         }
         __syncthreads();
+#ifndef DTAB_ABLATE_SEARCH     /* (diagnostic builds: instruction counts of the table build's parts) */
         for (int j = tid; j < eff; j += THREADS) {
             if (sh.ent[j] == -1) continue;
             const int l = j + 1;
-            if (l < eff && sh.ent[l] != -1) sh.left[j] = (uint16_t)l;
+            uint32_t links = DEC_LEAF_LR;
+            if (l < eff && sh.ent[l] != -1) links = 0xffff0000u | (uint32_t)l;
             const uint32_t s = s_open[j];
             uint32_t k = 0, p = (uint32_t)l;                          /* node (k, p): leaves [p << k, (p + 1) << k) */
             while (s_min[(N >> k) + p] > s) {                         /* nothing in this node: the next one, as high up as it starts */
@@ -857,8 +872,10 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
                 p <<= 1;
                 if (s_min[(N >> k) + p] > s) p++;
             }
-            if ((int)p < eff && sh.ent[p] != -1) sh.right[j] = (uint16_t)p;
+            if ((int)p < eff && sh.ent[p] != -1) links = (links & 0xffffu) | (p << 16);
+            sh.lr[j] = links;
         }
+#endif
     }
     __syncthreads();
     /* tree_len == 0 or a tree that starts with -1 is a NULL root: the reference crashes,
@@ -869,8 +886,9 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
 
     /* ---- 2. single-leaf tree: every symbol is one 0 bit ---- */
     {
-        const uint32_t l0 = sh.left[0];
-        if (l0 != DEC_NULL && sh.right[0] == DEC_NULL && sh.left[l0] == DEC_NULL && sh.right[l0] == DEC_NULL) {
+        const uint32_t lr0 = sh.lr[0];
+        const uint32_t l0 = lr0 & 0xffffu;
+        if (l0 != DEC_NULL && (lr0 >> 16) == DEC_NULL && sh.lr[l0] == DEC_LEAF_LR) {
             *single_leaf = (int)(uint8_t)sh.ent[l0];
             return HUFE_OK;
         }
@@ -881,21 +899,25 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
      * of the index, kept in the low 64 table slots for a moment, then every entry continues
      * from there - half the dependent LDS steps of walking all 12 bits per entry. */
     constexpr int HALF = DEC_LUT_BITS / 2;
+    /* one step of a walk: (node, its children) and the next bit -> verdict, or the child and ITS
+     * children (one dependent LDS read per level; a leaf's byte is a second read at the very end) */
+    auto walk_step = [&](uint32_t &node, uint32_t &lrn, uint32_t bit, int b, uint32_t &e) -> bool {
+        const uint32_t nx = dec_child(lrn, bit);
+        if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); return true; }
+        const uint32_t lrx = sh.lr[nx];
+        if (lrx == DEC_LEAF_LR) { e = ((uint32_t)(b + 1) << 8) | ((uint32_t)(uint8_t)sh.ent[nx]); return true; }
+        node = nx;
+        lrn = lrx;
+        return false;
+    };
     uint32_t hop1 = 0;
     if (tid < (1 << HALF)) {
-        uint32_t node = 0, e = 0;
+        uint32_t node = 0, lrn = sh.lr[0], e = 0;
         bool done = false;
-#pragma unroll 1
+#pragma unroll
         for (int b = 0; b < HALF; b++) {
             const uint32_t bit = ((uint32_t)tid >> (HALF - 1 - b)) & 1u;
-            const uint32_t nx = bit ? sh.right[node] : sh.left[node];
-            if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); done = true; break; }
-            node = nx;
-            if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) {
-                e = ((uint32_t)(b + 1) << 8) | ((uint32_t)(uint8_t)sh.ent[node]);
-                done = true;
-                break;
-            }
+            if (!done) done = walk_step(node, lrn, bit, b, e);
         }
         hop1 = done ? e : ((1u << 14) | node);           /* type 1 here: "continue from node" */
     }
@@ -906,27 +928,39 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
     {
         constexpr int PERL = (1 << DEC_LUT_BITS) / THREADS;
         uint16_t mine[PERL > 0 ? PERL : 1];
+        /* the thread's PERL walks advance level by level TOGETHER: their LDS reads are independent, so
+         * a level costs one LDS latency, not PERL of them (the walks one after the other, three
+         * dependent reads per level, were 14k of the table build's 30k cycles) */
+        uint32_t we[PERL > 0 ? PERL : 1], wnode[PERL > 0 ? PERL : 1], wlr[PERL > 0 ? PERL : 1];
+        bool wdone[PERL > 0 ? PERL : 1];
 #pragma unroll
         for (int k = 0; k < PERL; k++) {
             const int idx = tid + k * THREADS;
-            uint32_t e = s_hop[idx >> HALF];
-            if ((e >> 14) == 1u) {                         /* still inside the tree after the first hop */
-                uint32_t node = e & 0x7ffu;
-                bool done = false;
-#pragma unroll 1
-                for (int b = HALF; b < DEC_LUT_BITS; b++) {
-                    const uint32_t bit = ((uint32_t)idx >> (DEC_LUT_BITS - 1 - b)) & 1u;
-                    const uint32_t nx = bit ? sh.right[node] : sh.left[node];
-                    if (nx == DEC_NULL) { e = (2u << 14) | ((uint32_t)(b + 1) << 8); done = true; break; }
-                    node = nx;
-                    if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) {
-                        e = ((uint32_t)(b + 1) << 8) | ((uint32_t)(uint8_t)sh.ent[node]);
-                        done = true;
-                        break;
-                    }
-                }
-                if (!done) e = (1u << 14) | node;
+            we[k] = s_hop[idx >> HALF];
+            wdone[k] = (we[k] >> 14) != 1u;
+            wnode[k] = we[k] & 0x7ffu;
+        }
+#pragma unroll
+        for (int k = 0; k < PERL; k++) wlr[k] = wdone[k] ? DEC_LEAF_LR : sh.lr[wnode[k]];
+#ifndef DTAB_ABLATE_WALK
+#pragma unroll
+        for (int b = HALF; b < DEC_LUT_BITS; b++)
+#endif
+        {
+#ifdef DTAB_ABLATE_WALK
+            const int b = HALF;
+#endif
+#pragma unroll
+            for (int k = 0; k < PERL; k++) {
+                const int idx = tid + k * THREADS;
+                const uint32_t bit = ((uint32_t)idx >> (DEC_LUT_BITS - 1 - b)) & 1u;
+                if (!wdone[k]) wdone[k] = walk_step(wnode[k], wlr[k], bit, b, we[k]);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < PERL; k++) {
+            const int idx = tid + k * THREADS;
+            uint32_t e = wdone[k] ? we[k] : ((1u << 14) | wnode[k]);
             if ((e >> 14) == 1u) e = DEC_E_LONG | (e & 0x7ffu);
             else if ((e >> 14) == 2u) {
                 /* bad: resume one bit on; when the very first bit fails, every bit of the run of

@@ -82,10 +82,10 @@ __device__ __forceinline__ uint64_t dec_rare_lin(const DecShared<THREADS> &sh, c
         if (p >= lim) return (uint64_t)CW_EXH << 40;
         const uint32_t bit = (st[p >> 5] >> (31u - (p & 31u))) & 1u;
         p++;
-        const uint32_t nx = bit ? sh.right[node] : sh.left[node];
+        const uint32_t nx = dec_child(sh.lr[node], bit);
         if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
         node = nx;
-        if (sh.left[node] == DEC_NULL && sh.right[node] == DEC_NULL) break;
+        if (sh.lr[node] == DEC_LEAF_LR) break;
     }
     return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
 }
@@ -152,25 +152,6 @@ __device__ __forceinline__ void dsub_prefetch(DecShared<THREADS> &sh, const uint
         const uint32_t d = k * THREADS + threadIdx.x;
         if (d < nd) __builtin_amdgcn_global_load_lds(g32 + d, DsubLds<THREADS>::gb(sh) + k * THREADS + wave * 64u, 4, 0, 0);
     }
-}
-
-/* Inclusive prefix sum over the wave by DPP: shifts inside the rows of 16 lanes, then lane 15 of a
- * row into the next row, then lane 31 into the upper half (six VALU instructions, no LDS, and no
- * per-step lane address to keep - the ds_bpermute form of __shfl_up had its six address registers
- * hoisted out of the tile loop, spilled, and reloaded from scratch for every tile). */
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1, 3 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_lane_u32(uint32_t v, uint32_t uniform_lane)
-{
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uniform_lane);
 }
 
 /* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.

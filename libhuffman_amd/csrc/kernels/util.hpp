@@ -70,6 +70,48 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
 __device__ __forceinline__ uint32_t shfl_xor_key(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask); }
 __device__ __forceinline__ uint64_t shfl_xor_key(uint64_t v, int mask) { return shfl_xor_u64(v, mask); }
 
+/* Inclusive prefix sum over the wave by DPP: shifts inside the rows of 16 lanes, then lane 15 of a
+ * row into the next row, then lane 31 into the upper half (six VALU instructions, no LDS, and no
+ * per-step lane address to keep - the ds_bpermute form of __shfl_up had its six address registers
+ * hoisted out of loops, spilled, and reloaded from scratch in every iteration). */
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1, 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
+    return v;
+}
+/* value of a lane given by a wave-uniform index (v_readlane: no LDS, no address register) */
+__device__ __forceinline__ uint32_t wave_lane_u32(uint32_t v, uint32_t uniform_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uniform_lane);
+}
+
+/* Exclusive prefix sum of 32-bit values over the workgroup: DPP inside the waves, one LDS round
+ * across them.  s_part needs THREADS/64 words. */
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *s_part, uint32_t &total)
+{
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) {
+        const uint32_t x = s_part[i];
+        if (i < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
 /* Exclusive prefix sum over the workgroup (THREADS a multiple of 64). s_part needs THREADS/64
  * words. Returns this thread's exclusive prefix; `total` is the workgroup sum. */
 template <int THREADS, typename T>

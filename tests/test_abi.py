@@ -31,7 +31,8 @@ def have_gpu(L) -> bool:
 def test_exports_every_declared_symbol(L):
     """Every function declared in include/*.h is exported by the shared library."""
     declared = set()
-    for hdr in ("huffman.h", "huffman_gpu.h"):
+    split = sorted(os.path.join("huffman", f) for f in os.listdir(os.path.join(ROOT, "include", "huffman")))
+    for hdr in ["huffman_gpu.h"] + split:
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         declared |= set(re.findall(r"\b((?:huf|hufgpu)_[a-z0-9_]+)\s*\(", text))
@@ -42,6 +43,75 @@ def test_exports_every_declared_symbol(L):
     # the reference's full export list, incl. the non-static stream callbacks
     assert not [s for s in N.HOST_SYMBOLS if not hasattr(L, s)]
     assert len(N.HOST_SYMBOLS) == 48   # nm -D of the reference .so lists 48 (SURVEY App. E text says 47)
+
+
+REFERENCE_HEADER_LIST = ["huffman/errors.h", "huffman/io.h", "huffman/config.h", "huffman/common.h",
+                         "huffman/decoder.h", "huffman/encoder.h", "huffman/bufio.h", "huffman/histogram.h",
+                         "huffman/malloc.h", "huffman/symbol.h", "huffman/sys.h", "huffman/tree.h"]
+
+CFFI_PROBE = r'''
+import sys, cffi
+inc, so = sys.argv[1], sys.argv[2]
+headers = sys.argv[3:]
+# the region-cutting loop of the reference's setup_ffi.py:8-23, restated
+src = ""
+for header in headers:
+    keep = False
+    for line in open(inc + "/" + header):
+        if line.startswith("#define CFFI"):
+            keep = True
+            continue
+        if line.startswith("#undef CFFI"):
+            keep = False
+        if keep:
+            src += line
+ffi = cffi.FFI()
+ffi.cdef(src)
+lib = ffi.dlopen(so)
+assert ffi.sizeof("huf_config_t") == 48 and ffi.sizeof("huf_read_writer_t") == 24
+assert ffi.string(lib.huf_error_string(lib.HUF_ERROR_BTREE_CORRUPTED)).startswith(b"Huffman tree is corrupted")
+rw, buf = ffi.new("huf_read_writer_t **"), ffi.new("void **")
+assert lib.huf_memopen(rw, buf, 64) == 0
+assert rw[0].write(rw[0].stream, b"0123456789", 10) == 0
+n = ffi.new("size_t *")
+assert lib.huf_memlen(rw[0], n) == 0 and n[0] == 10
+cfg = ffi.new("huf_config_t **")
+assert lib.huf_config_init(cfg) == 0 and cfg[0].blocksize == 0
+assert lib.huf_config_free(cfg) == 0 and lib.huf_memclose(rw) == 0
+print("cffi ok", len(src.splitlines()), "lines of cdef")
+'''
+
+
+def test_reference_cffi_build_recipe_binds_this_library(L, tmp_path):
+    """The reference's binding (setup_ffi.py:8-43) cuts its cdef() text out of twelve per-file
+    headers between "#define CFFI_x" and "#undef CFFI_x".  The same loop over the same header list,
+    pointed at THIS include/ directory, must give a cdef cffi accepts and a library that binds."""
+    import subprocess
+    for h in REFERENCE_HEADER_LIST:
+        assert os.path.exists(os.path.join(ROOT, "include", h)), h
+    py = "/opt/conda/bin/python3.9"                  # the interpreter of this image that has cffi
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import cffi"], capture_output=True).returncode:
+        pytest.skip("no interpreter with cffi in this image")
+    probe = tmp_path / "probe.py"
+    probe.write_text(CFFI_PROBE)
+    out = subprocess.run([py, str(probe), os.path.join(ROOT, "include"), N.so_path()] + REFERENCE_HEADER_LIST,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "cffi ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_split_headers_compile_alone_and_together(tmp_path):
+    """Every per-file header is self-contained, and <huffman.h> plus all of them compile as C and C++."""
+    import subprocess
+    body = "".join(f"#include <{h}>\n" for h in REFERENCE_HEADER_LIST) + "#include <huffman.h>\n#include <huffman_gpu.h>\n"
+    body += "int main(void) { huf_config_t c; huf_histogram_t h; (void)c; (void)h; return HUF_BTREE_LEN == 1024 ? 0 : 1; }\n"
+    for comp, lang, name in (("gcc", "c", "all.c"), ("g++", "c++", "all.cpp")):
+        f = tmp_path / name
+        f.write_text(body)
+        subprocess.check_call([comp, "-fsyntax-only", "-Wall", "-Werror", "-x", lang, "-I", os.path.join(ROOT, "include"), str(f)])
+    for h in REFERENCE_HEADER_LIST:
+        f = tmp_path / "one.c"
+        f.write_text(f"#include <{h}>\nint x;\n")
+        subprocess.check_call(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(f)])
 
 
 def test_struct_layouts_are_the_reference_abi():

@@ -133,6 +133,11 @@ int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail
                          void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                          uint64_t *consumed, void *stream);
 
+/* Of the last hufgpu_decode_stream() call: the stream bytes and output bytes of the blocks that
+ * decoded COMPLETELY (on success all of them; after an error the position in front of the failing
+ * block - what a caller that feeds a stream piecewise keeps for its next piece). */
+int hufgpu_decode_stream_complete(hufgpu_ctx_t *ctx, uint64_t *raw_len, uint64_t *consumed);
+
 /* Deterministic synthetic inputs of SURVEY §8d, generated in HBM (kind: 0 const41,
  * 1 uniform256, 2 uniform255, 3 zipf255). `first` = index of the first byte of this shard in
  * the global sequence, so shards of one logical input can be produced on different GPUs. */
@@ -166,8 +171,16 @@ int hufgpu_get_profile(hufgpu_ctx_t *ctx, int kind, float *ms_sum, int max_stage
  * (no copy into a huf_memopen() buffer); huf_encode()/huf_decode() send such a stream to the
  * device directly.  Close it with huf_memclose(); the bytes are never written or freed. */
 struct __huf_read_writer;
+struct __huf_encoder_config;
 void huf_gpu_set_relaxed_tree(int enabled);
 int huf_gpu_memwrap(struct __huf_read_writer **self, const void *data, size_t length);
+/* huf_gpu_decode_blocks: huf_decode() for a caller that holds only a PIECE of a stream (a file read
+ * in bounded rounds, src/decoder.c:218 has the whole stream behind its reader): the blocks that lie
+ * completely inside config->length bytes are decoded and written, *consumed = their stream bytes.
+ * A last block that is cut off is not an error here - it is left for the next call (*consumed <
+ * config->length; 0 when not even one block is complete); every other error is huf_decode()'s.
+ * The reader is never asked for more than config->length bytes. */
+int huf_gpu_decode_blocks(const struct __huf_encoder_config *config, uint64_t *consumed);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,7 @@ hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_dec
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_set_profiling
 hufgpu_get_profile hufgpu_sub_index_bytes hufgpu_encode_sub hufgpu_decode_sub
-huf_gpu_set_relaxed_tree huf_gpu_memwrap""".split()
+hufgpu_decode_stream_complete huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_decode_blocks""".split()
 
 
 def so_path() -> str:
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
     L.huf_gpu_set_relaxed_tree.argtypes = [i32]
     L.huf_gpu_set_relaxed_tree.restype = None
     L.huf_gpu_memwrap.argtypes = [C.POINTER(C.POINTER(ReadWriter)), vp, C.c_size_t]
+    L.huf_gpu_decode_blocks.argtypes = [C.POINTER(Config), C.POINTER(u64)]
 
     L.hufgpu_device_count.restype = i32
     L.hufgpu_ctx_create.argtypes = [C.POINTER(vp), i32]
@@ -118,6 +119,7 @@ def load() -> C.CDLL:
     L.hufgpu_encode_sub.argtypes = [vp, vp, u64, u64, vp, u64, vp, vp, C.POINTER(u64), vp]
     L.hufgpu_decode_sub.argtypes = [vp, vp, u64, vp, u64, u64, vp, vp, u64, C.c_uint32, C.POINTER(u64), vp]
     L.hufgpu_decode_result.argtypes = [vp, C.POINTER(u64)]
+    L.hufgpu_decode_stream_complete.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.hufgpu_decode_stream.argtypes = [vp, vp, u64, u64, vp, u64, C.c_uint32, C.POINTER(u64),
                                        C.POINTER(u64), vp]
     L.hufgpu_fill.argtypes = [vp, vp, u64, i32, u64, u64, vp]

@@ -1253,12 +1253,14 @@ static huf_error_t decode_from_fd(huf_decoder_t *dec, int rfd, membuf_t *wmem, i
     return huf_bufio_read_writer_flush(dec->bufio_writer);
 }
 
-static huf_error_t decode_locked(huf_decoder_t *dec)
+/* pieces = NULL: huf_decode().  pieces != NULL: huf_gpu_decode_blocks() - only the blocks that lie
+ * completely inside `length` bytes, *pieces = their stream bytes, a cut-off last block is no error. */
+static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
 {
     const uint64_t length = dec->config->length;
     TRY(session_acquire());
     const uint32_t flags = relaxed_tree() ? HUFGPU_RELAXED_TREE : HUFGPU_STRICT_TREE;
-    if (zero_copy_enabled() && own_fd_of(dec->config->reader, 0) >= 0) {
+    if (!pieces && zero_copy_enabled() && own_fd_of(dec->config->reader, 0) >= 0) {
         membuf_t *wm = own_memstream_writer(dec->config->writer);
         return decode_from_fd(dec, own_fd_of(dec->config->reader, 0), wm, wm ? -1 : own_fd_of(dec->config->writer, 1), flags);
     }
@@ -1293,6 +1295,14 @@ static huf_error_t decode_locked(huf_decoder_t *dec)
             out_cap *= 4;
             continue;
         }
+        if (pieces) {
+            /* a piece of a stream: what counts is the last block boundary inside it */
+            uint64_t good_raw = 0, good_used = 0;
+            TRY(hufgpu_decode_stream_complete(g_ctx, &good_raw, &good_used));
+            if (rc == HUF_ERROR_READ_WRITE) { rc = HUF_ERROR_SUCCESS; raw = good_raw; used = good_used; }
+            *pieces = (rc == HUF_ERROR_SUCCESS) ? used : good_used;
+            if (rc != HUF_ERROR_SUCCESS) raw = good_raw;          /* the blocks in front of a damaged one */
+        } else
         if (rc == HUF_ERROR_READ_WRITE && rmem) {  /* maybe the stream holds more than `length` */
             const size_t more_want = avail < 65536 ? 65536 : avail;
             const size_t left = rmem->len - rmem->off;
@@ -1339,7 +1349,24 @@ huf_error_t huf_decode(const huf_config_t *config)
     huf_error_t err = HUF_ERROR_SUCCESS;
     if (dec->config->length) {                    /* test/decode_test.c:32-36: empty input is fine */
         pthread_mutex_lock(&g_lock);
-        err = decode_locked(dec);
+        err = decode_locked(dec, NULL);
+        pthread_mutex_unlock(&g_lock);
+    }
+    huf_decoder_free(&dec);
+    return err;
+}
+
+int huf_gpu_decode_blocks(const huf_config_t *config, uint64_t *consumed)
+{
+    GUARD(config);
+    GUARD(consumed);
+    *consumed = 0;
+    huf_decoder_t *dec = NULL;
+    TRY(huf_decoder_init(&dec, config));
+    huf_error_t err = HUF_ERROR_SUCCESS;
+    if (dec->config->length) {
+        pthread_mutex_lock(&g_lock);
+        err = decode_locked(dec, consumed);
         pthread_mutex_unlock(&g_lock);
     }
     huf_decoder_free(&dec);

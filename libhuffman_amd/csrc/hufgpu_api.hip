@@ -66,7 +66,8 @@ struct hufgpu_ctx {
     uint64_t *d_walk;             /* 5 result words of walk_kernel */
     uint64_t *d_spec_off;         /* speculative output offsets of the candidates (disc_cands + 1) */
 
-    uint64_t *d_result;           /* 4 words: err, raw_len, failing block, spare */
+    uint64_t *d_result;           /* 8 words: err, raw_len, failing block / consumed, blocks, complete consumed, complete raw */
+    uint64_t complete_used, complete_raw;   /* of the last hufgpu_decode_stream(): see hufgpu_decode_stream_complete() */
     uint64_t *h_result;           /* pinned mirror */
     uint64_t *d_zipf;             /* 255 cumulative weights */
 
@@ -166,7 +167,7 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     ctx->device = device;
     HIP_OK(NULL, hipSetDevice(device));
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
-    HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 4 * sizeof(uint64_t)));
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 8 * sizeof(uint64_t)));
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 8 * sizeof(uint64_t)));
     HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t), hipHostMallocDefault));
 
@@ -612,14 +613,17 @@ extern "C" int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64
 
 /* The exact sequential decoder (one workgroup, blocks in order). */
 static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint8_t *out,
-                        uint64_t out_cap, int max_tree, hipStream_t s, uint64_t *raw, uint64_t *used)
+                        uint64_t out_cap, int max_tree, hipStream_t s, uint64_t *raw, uint64_t *used,
+                        uint64_t *good_used, uint64_t *good_raw)
 {
     decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>(st, avail, length, max_tree, out, out_cap, ctx->d_result, NULL, 0);
     HIP_OK(ctx, hipGetLastError());
-    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_OK(ctx, hipStreamSynchronize(s));
     *raw = ctx->h_result[1];
     *used = ctx->h_result[2];
+    *good_used = ctx->h_result[4];
+    *good_raw = ctx->h_result[5];
     return (int)ctx->h_result[0];
 }
 
@@ -708,25 +712,40 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
             }
         }
     }
+    ctx->complete_used = 0;
+    ctx->complete_raw = 0;
     if (complete) {
         raw = prefix_raw;
         used = resume;
         err = HUFE_OK;
+        ctx->complete_used = used;
+        ctx->complete_raw = raw;
     } else {
         /* ---- exact sequential decoder for what is left (all of it when nothing was validated) ---- */
         uint64_t raw2 = 0, used2 = 0;
         STAGE_BEGIN(ctx, s, PROF_DECODE);
+        uint64_t good_used = 0, good_raw = 0;
         err = decode_chain(ctx, st + resume, avail - resume, length - resume, out + prefix_raw,
-                           out_cap - prefix_raw, max_tree, s, &raw2, &used2);
+                           out_cap - prefix_raw, max_tree, s, &raw2, &used2, &good_used, &good_raw);
         STAGE_MARK(ctx, s);
         raw = prefix_raw + raw2;
         used = resume + used2;
+        ctx->complete_used = resume + good_used;
+        ctx->complete_raw = prefix_raw + good_raw;
     }
     if (raw_len) *raw_len = raw;
     if (consumed) *consumed = used;
     if (err == HUFE_ARGUMENT) set_err(ctx, "a block is longer than the kernels support");
     if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small");
     return err;
+}
+
+extern "C" int hufgpu_decode_stream_complete(hufgpu_ctx_t *ctx, uint64_t *raw_len, uint64_t *consumed)
+{
+    if (!ctx) return HUFE_ARGUMENT;
+    if (raw_len) *raw_len = ctx->complete_raw;
+    if (consumed) *consumed = ctx->complete_used;
+    return HUFE_OK;
 }
 
 extern "C" int hufgpu_fill(hufgpu_ctx_t *ctx, void *d_out, uint64_t n, int kind, uint64_t seed,

@@ -1187,7 +1187,8 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_kernel(con
 /* Raw-stream decode (no index): the block loop of src/decoder.c:218-276 run by ONE workgroup.
  * Blocks are taken strictly in order because a block's end is only known once block_len
  * symbols have been decoded; inside a block all lanes work in parallel.
- * result[0] = error, [1] = bytes written, [2] = reader bytes consumed, [3] = blocks done. */
+ * result[0] = error, [1] = bytes written, [2] = reader bytes consumed, [3] = blocks done,
+ * [4] / [5] = stream bytes / output bytes of the blocks that decoded completely. */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__restrict__ stream,
                                                                uint64_t avail, uint64_t length,
@@ -1198,8 +1199,11 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
 {
     __shared__ DecShared<THREADS> sh;
     uint64_t rd = 0, wr = 0, nblk = 0;
+    uint64_t good_rd = 0, good_wr = 0;                                /* behind the last block that decoded completely */
     int err = HUFE_OK;
     while (length > rd) {                                             /* decoder.c:218 */
+        good_rd = rd;
+        good_wr = wr;
         if (block_offsets && nblk < max_index) {
             if (threadIdx.x == 0) block_offsets[nblk] = rd;
         }
@@ -1236,6 +1240,8 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
         result[1] = wr;
         result[2] = rd;
         result[3] = nblk;
+        result[4] = (err == HUFE_OK) ? rd : good_rd;
+        result[5] = (err == HUFE_OK) ? wr : good_wr;
         if (block_offsets && nblk < max_index) block_offsets[nblk] = rd;
     }
 }

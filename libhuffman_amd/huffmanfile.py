@@ -201,6 +201,26 @@ class HuffmanDecompressor:
             src.close()
             dst.close()
 
+    def decompress_blocks(self, data):
+        """The blocks that lie completely inside `data` -> (their bytes, compressed bytes they took).
+        For callers that hold a stream piece by piece (HuffmanFile.read): a cut-off last block is
+        not an error, it is what the caller puts in front of its next piece."""
+        if self._closed:
+            raise ValueError("Decompressor has been closed")
+        view = memoryview(data).cast("B")
+        n = len(view)
+        if n == 0:
+            return b"", 0
+        src, dst = _WrappedBytes(view), _MemStream(max(min(self._memlimit, 8 * n + 4096), 4 * n))
+        try:
+            cfg = N.Config(n, 0, 0, 0, src.handle, dst.handle)
+            used = C.c_uint64(0)
+            _check(self._lib.huf_gpu_decode_blocks(C.byref(cfg), C.byref(used)), "Failed to decode the data")
+            return dst.getvalue(), int(used.value)
+        finally:
+            src.close()
+            dst.close()
+
     def close(self) -> None:
         self._closed = True
 
@@ -233,7 +253,10 @@ class HuffmanFile(io.BufferedIOBase):
         self._fp = None
         self._mode = _CLOSED
         self._own_fp = False
-        self._plain = None          # decoded contents, filled by the first read
+        self._plain = bytearray()   # decoded, not yet returned (from self._cursor on)
+        self._cursor = 0
+        self._rest = b""            # compressed bytes behind the last whole block decoded so far
+        self._eof = False
         self._cursor = 0
         if mode in ("", "r", "rb"):
             file_mode, state = "rb", _READ
@@ -292,21 +315,42 @@ class HuffmanFile(io.BufferedIOBase):
         return self._mode == _WRITE
 
     # -- I/O --------------------------------------------------------------------------------
-    def _load(self) -> None:
-        if self._plain is None:
-            # block boundaries are only known by decoding (the format stores no payload length),
-            # so the file is decoded in one piece, on the GPU
-            self._plain = self._decompressor.decompress(self._fp.read())
-            self._cursor = 0
+    READ_PIECE = 32 << 20          # compressed bytes taken from the file per round
+
+    def _fill(self, want: int) -> None:
+        """Decode rounds of READ_PIECE compressed bytes until `want` plain bytes are buffered (want <
+        0: until the end of the file).  Block boundaries are only known by decoding (the format
+        stores no payload length), so a round decodes the blocks that are complete in what has been
+        read and keeps the cut-off rest in front of the next piece: memory stays bounded by a round,
+        whatever the size of the file (the reference reads `size` COMPRESSED bytes per call and
+        fails when they do not end on a block boundary, huffmanfile.py:152-162)."""
+        while not self._eof and (want < 0 or len(self._plain) - self._cursor < want):
+            piece = self._fp.read(self.READ_PIECE)
+            if not piece:
+                self._eof = True
+                if self._rest:
+                    # what is left is not a whole block: the error the reference's decoder gives
+                    # when its input ends inside a block
+                    _check(N.HUF_ERROR_READ_WRITE, "Failed to decode the data")
+                break
+            buf = self._rest + piece if self._rest else piece
+            plain, used = self._decompressor.decompress_blocks(buf)
+            self._rest = bytes(memoryview(buf)[used:])
+            if self._cursor:
+                del self._plain[:self._cursor]
+                self._cursor = 0
+            self._plain += plain
 
     def read(self, size: int = -1) -> bytes:
         """Up to `size` uncompressed bytes; everything that is left when size < 0."""
         if not self.readable():
             raise io.UnsupportedOperation("File not open for reading")
-        self._load()
         if size is None or size < 0:
+            self._fill(-1)
             size = len(self._plain) - self._cursor
-        chunk = self._plain[self._cursor:self._cursor + size]
+        else:
+            self._fill(size)
+        chunk = bytes(self._plain[self._cursor:self._cursor + size])
         self._cursor += len(chunk)
         return chunk
 

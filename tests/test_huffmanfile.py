@@ -190,3 +190,59 @@ def test_k256_block_strict_and_relaxed():
         assert huffmanfile.decompress(c) == data
     finally:
         _native.load().huf_gpu_set_relaxed_tree(0)
+
+
+@gpu
+def test_read_is_streaming_in_bounded_rounds(tmp_path, monkeypatch):
+    """HuffmanFile.read(size) (huffmanfile.py:152-162): the file is taken in pieces that
+    end anywhere inside a block; every round decodes the whole blocks it holds and carries the rest.
+    With 7 000-byte pieces over 4 KiB / 64 KiB blocks the carry path runs on nearly every round."""
+    import io as _io
+    data = datagen.zipf255(700001).tobytes()
+    for bs in (4096, 65536):
+        name = tmp_path / f"s{bs}.hm"
+        with huffmanfile.HuffmanFile(name, "w", blocksize=bs) as f:
+            f.write(data)
+        monkeypatch.setattr(huffmanfile.HuffmanFile, "READ_PIECE", 7000)
+        with huffmanfile.HuffmanFile(name, "r") as f:
+            got, peak = bytearray(), 0
+            while True:
+                chunk = f.read(10007)
+                peak = max(peak, len(f._plain), len(f._rest))
+                if not chunk:
+                    break
+                assert len(chunk) <= 10007
+                got += chunk
+            assert bytes(got) == data
+            assert peak < 20 * bs + 8 * 7000          # bounded by rounds, not by the file
+        with huffmanfile.HuffmanFile(name, "r") as f:
+            assert f.read(1) == data[:1] and f.read() == data[1:] and f.read(5) == b""
+        # a file cut inside its last block: the bytes of the whole blocks, then the decoder's error
+        raw = name.read_bytes()
+        with huffmanfile.HuffmanFile(_io.BytesIO(raw[:-3]), "r") as f:
+            with pytest.raises(huffmanfile.HuffmanError) as ei:
+                f.read()
+            assert "read/write" in str(ei.value)
+        monkeypatch.undo()
+
+
+@gpu
+def test_decode_blocks_pieces_through_the_c_api():
+    """huf_gpu_decode_blocks: whole blocks inside the piece are decoded, *consumed stops in front of a
+    cut-off block (no error), a damaged block is still huf_decode's error."""
+    data = datagen.zipf255(5 * 65536 + 100).tobytes()
+    comp = huffmanfile.compress(data, 65536)
+    d = huffmanfile.HuffmanDecompressor()
+    plain, used = d.decompress_blocks(comp)
+    assert plain == data and used == len(comp)
+    cut = len(comp) - 1000                                 # inside the last (short) block or the one before
+    plain, used = d.decompress_blocks(comp[:cut])
+    assert used < cut and data.startswith(plain) and len(plain) % 65536 == 0 and len(plain) >= 4 * 65536
+    rest, used2 = d.decompress_blocks(comp[used:])
+    assert plain + rest == data and used + used2 == len(comp)
+    plain, used = d.decompress_blocks(comp[:5])            # not even a header
+    assert (plain, used) == (b"", 0)
+    bad = bytearray(comp)
+    bad[8] = 0xff; bad[9] = 0x7f                           # tree_len 32767 in the first header
+    with pytest.raises(huffmanfile.HuffmanError):
+        d.decompress_blocks(bytes(bad))

@@ -44,6 +44,9 @@ struct hufgpu_ctx {
     HufBlockMeta *d_meta;
     uint64_t *d_offsets;          /* used when the caller passes no index buffer */
     TwoLevel enc_sizes;           /* two-level prefix sums of the encoded block sizes */
+    uint64_t ws_chunks;           /* blocks >= HUF_BIG_BLOCK: per-chunk counts, payload bits and first bits */
+    uint32_t *d_chunk_hist;
+    uint64_t *d_chunk_tot, *d_chunk_bits;
 
     /* decode workspace */
     uint64_t dws_blocks;
@@ -193,6 +196,8 @@ static void free_encode_ws(hufgpu_ctx *c)
     (void)hipFree(c->d_treebuf);
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_offsets);
+    (void)hipFree(c->d_chunk_hist); (void)hipFree(c->d_chunk_tot); (void)hipFree(c->d_chunk_bits);
+    c->d_chunk_hist = NULL; c->d_chunk_tot = NULL; c->d_chunk_bits = NULL; c->ws_chunks = 0;
     c->d_hist = NULL; c->d_codetab = NULL; c->d_treebuf = NULL; c->d_meta = NULL; c->d_offsets = NULL;
     c->ws_blocks = 0;
 }
@@ -278,6 +283,20 @@ static int ensure_encode_ws(hufgpu_ctx *c, uint64_t nblocks)
     int rc2 = alloc_two_level(c, &c->enc_sizes, cap, false);
     if (rc2) return rc2;
     c->ws_blocks = cap;
+    return HUFE_OK;
+}
+
+static int ensure_chunk_ws(hufgpu_ctx *c, uint64_t nchunks)
+{
+    if (nchunks <= c->ws_chunks) return HUFE_OK;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_chunk_hist); (void)hipFree(c->d_chunk_tot); (void)hipFree(c->d_chunk_bits);
+    c->d_chunk_hist = NULL; c->d_chunk_tot = NULL; c->d_chunk_bits = NULL; c->ws_chunks = 0;
+    const uint64_t cap = nchunks + nchunks / 8 + 16;
+    HIP_OK(c, hipMalloc((void **)&c->d_chunk_hist, cap * HUF_NSYM * sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_chunk_tot, cap * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_chunk_bits, cap * sizeof(uint64_t)));
+    c->ws_chunks = cap;
     return HUFE_OK;
 }
 
@@ -454,7 +473,7 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
 
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
     TwoLevel sizes = ctx->enc_sizes;
-    if (blocksize < (1ull << 22)) {
+    if (blocksize < HUF_BIG_BLOCK) {
         /* counts, tree and the sums of the encoded sizes in one launch (the profile's "tree" and
          * "scan_sizes" stages are then empty) */
         sizes.total = offs + nb;
@@ -466,15 +485,36 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
         STAGE_MARK(ctx, s);
         STAGE_MARK(ctx, s);
     } else {
-        hist256_kernel<HIST_THREADS><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
+        /* blocks of HUF_BIG_BLOCK bytes and more are cut into chunks, one workgroup each (blocksize = 0:
+         * the whole input is ONE block, src/encoder.c:163-165 - the reference's default) */
+        const uint64_t cpb = (blocksize + HUF_CHUNK_SYMS - 1) / HUF_CHUNK_SYMS;
+        const uint64_t nchunks = nb * cpb;
+        if (nchunks > 0x7fffffffull) return HUFE_ARGUMENT;
+        rc = ensure_chunk_ws(ctx, nchunks);
+        if (rc) return rc;
+        ChunkGeom geo;
+        geo.n = n;
+        geo.blocksize = blocksize;
+        geo.cpb = (uint32_t)cpb;
+        chunk_hist_kernel<HIST_THREADS><<<dim3((unsigned)nchunks), dim3(HIST_THREADS), 0, s>>>(in, geo, ctx->d_chunk_hist);
+        block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_hist);
         STAGE_MARK(ctx, s);
         tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
         STAGE_MARK(ctx, s);
         scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
+        chunk_total_kernel<<<dim3((unsigned)nchunks), dim3(64), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_codetab, ctx->d_chunk_tot);
+        chunk_scan_kernel<SCAN_THREADS><<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(ctx->d_chunk_tot, (uint32_t)cpb, ctx->d_chunk_bits);
         STAGE_MARK(ctx, s);
         sizes.local = NULL;              /* pack reads the finished index */
+        PackChunk ck;
+        ck.chunk_bits = ctx->d_chunk_bits;
+        ck.chunk_syms = HUF_CHUNK_SYMS;
+        ck.cpb = (uint32_t)cpb;
+        pack_chunk_kernel<PACK_THREADS, false><<<dim3((unsigned)nchunks), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub, ck);
     }
-    if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
+    if (blocksize >= HUF_BIG_BLOCK) {
+        /* (packed above) */
+    } else if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
         pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub);
     else
         pack_kernel<PACK_THREADS, false><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub);

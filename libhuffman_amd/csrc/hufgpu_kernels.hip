@@ -5,7 +5,9 @@
  * parallelism everywhere: blocks never exchange data, so every kernel maps blocks to
  * workgroups and the grid is simply the block count.
  *
- *   encode:  hist_tree_kernel -> pack_kernel      (blocks >= 4 MiB: hist256 -> tree -> scan_sizes -> pack)
+ *   encode:  hist_tree_kernel -> pack_kernel
+ *            (blocks >= 4 MiB are cut into chunks of 256 KiB, one workgroup each: chunk_hist -> block_hist ->
+ *            tree -> scan_sizes -> chunk_total -> chunk_scan -> pack_chunk)
  *   decode:  decode_prepare_kernel -> decode_kernel (block index known)
  *            decode_prepare_kernel -> decode_sub_kernel -> decode_fix_kernel (block index and the
  *            encoder's sub-index known), or decode_chain_kernel (raw stream, blocks in order)
@@ -23,6 +25,8 @@
 #include "kernels/offsets.hpp"
 #include "kernels/hist_tree.hpp"
 #include "kernels/pack.hpp"
+#include "kernels/hist_chunk.hpp"
+#include "kernels/pack_chunk.hpp"
 #include "kernels/decode.hpp"
 #include "kernels/decode_sub.hpp"
 #include "kernels/discover.hpp"

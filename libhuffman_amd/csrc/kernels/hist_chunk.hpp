@@ -1,0 +1,116 @@
+/* hist_chunk.hpp - the histogram side of chunked blocks: chunk_hist_kernel, block_hist_kernel,
+   chunk_total_kernel, chunk_scan_kernel (src/histogram.c:73-103 for blocks of many MiB).
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "histogram.hpp"
+#include "offsets.hpp"
+
+namespace hufgpu {
+
+/* A block of blocksize >= HUF_BIG_BLOCK bytes is cut into chunks of HUF_CHUNK_SYMS symbols (the
+ * stream's last block may have fewer).  Chunk c of block b = input bytes
+ * [b * blocksize + c * HUF_CHUNK_SYMS, ...).  cpb = chunks per block. */
+#define HUF_CHUNK_SYMS 262144u          /* 32 pack tiles: the sub-index' tiles and groups align with chunks */
+#define HUF_BIG_BLOCK  (1ull << 22)     /* from here on blocks are chunked (as before: from here on 64-bit tree keys) */
+
+struct ChunkGeom {
+    uint64_t n, blocksize;
+    uint32_t cpb;
+    __device__ __forceinline__ bool locate(uint64_t chunk, uint64_t &base, uint64_t &len) const
+    {
+        const uint64_t blk = chunk / cpb, c = chunk % cpb;
+        const uint64_t b0 = blk * blocksize;
+        const uint64_t blen = dmin<uint64_t>(blocksize, n - b0);
+        const uint64_t s0 = c * (uint64_t)HUF_CHUNK_SYMS;
+        if (s0 >= blen) { base = 0; len = 0; return false; }
+        base = b0 + s0;
+        len = dmin<uint64_t>(HUF_CHUNK_SYMS, blen - s0);
+        return true;
+    }
+};
+
+/* byte counts of every chunk: hist256's counting loop (histogram.hpp) on a chunk */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void chunk_hist_kernel(const uint8_t *__restrict__ in, ChunkGeom geo,
+                                                             uint32_t *__restrict__ chunk_hist)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr int COPIES = WAVES * HIST_COPIES;
+    __shared__ uint32_t s_hist[COPIES * HUF_NSYM];
+    const int tid = (int)threadIdx.x;
+    uint64_t base, len;
+    const bool any = geo.locate(blockIdx.x, base, len);
+    for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
+    __syncthreads();
+    if (any) {
+        uint32_t *mine = s_hist + ((tid >> 6) * HIST_COPIES + (tid & (HIST_COPIES - 1))) * HUF_NSYM;
+        const uint8_t *p = in + base;
+        const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
+        if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
+        const uint64_t nvec = (len - head) >> 4;
+        uint64_t i = (uint64_t)tid;
+        for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
+            const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
+                        v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
+            hist_add_chunk(mine, v0);
+            hist_add_chunk(mine, v1);
+            hist_add_chunk(mine, v2);
+            hist_add_chunk(mine, v3);
+        }
+        for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i));
+        const uint64_t tail0 = head + (nvec << 4);
+        if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
+    }
+    __syncthreads();
+    for (int b = tid; b < HUF_NSYM; b += THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < COPIES; w++) sum += s_hist[w * HUF_NSYM + b];
+        chunk_hist[(uint64_t)blockIdx.x * HUF_NSYM + b] = sum;
+    }
+}
+
+/* byte counts of every block = the sums over its chunks (a block is shorter than 2^32 bytes:
+ * HUFGPU_MAX_BLOCK, so 32-bit counts hold) */
+__global__ __launch_bounds__(HUF_NSYM) void block_hist_kernel(const uint32_t *__restrict__ chunk_hist, uint32_t cpb,
+                                                              uint32_t *__restrict__ hist)
+{
+    const uint64_t blk = blockIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t c = 0; c < cpb; c++) sum += chunk_hist[(blk * cpb + c) * HUF_NSYM + threadIdx.x];
+    hist[blk * HUF_NSYM + threadIdx.x] = sum;
+}
+
+/* payload bits of every chunk = sum over the bytes of count * code length (one wave per chunk) */
+__global__ __launch_bounds__(64) void chunk_total_kernel(const uint32_t *__restrict__ chunk_hist, uint32_t cpb,
+                                                         const hufcode_t *__restrict__ codetab,
+                                                         uint64_t *__restrict__ chunk_tot)
+{
+    const uint64_t chunk = blockIdx.x, blk = chunk / cpb;
+    uint64_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int s = lane_id() + 64 * j;
+        bits += (uint64_t)chunk_hist[chunk * HUF_NSYM + s] * (uint64_t)(codetab[blk * HUF_NSYM + s] & 0xffu);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) bits += shfl_xor_u64(bits, o);
+    if (lane_id() == 0) chunk_tot[chunk] = bits;
+}
+
+/* first payload bit of every chunk = exclusive sums of the chunk totals inside each block */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void chunk_scan_kernel(const uint64_t *__restrict__ chunk_tot, uint32_t cpb,
+                                                             uint64_t *__restrict__ chunk_bits)
+{
+    const uint64_t blk = blockIdx.x;
+    const uint64_t *src = chunk_tot + blk * cpb;
+    (void)chunked_excl_scan<THREADS>(cpb, chunk_bits + blk * cpb, [src](uint64_t i) { return src[i]; });
+}
+
+}  // namespace hufgpu

@@ -233,3 +233,69 @@ def test_full_size_sub_index_roundtrip(torch_mod, codec):
         back.zero_()
         raw = codec.decode(out, length, offs, nb, back, relaxed=True)
         assert raw == n and torch.equal(back, data), kind
+
+
+@pytest.mark.parametrize("kind,n,bs", [
+    ("zipf255", 3 * 5000001 + 12345, 5000001),      # chunks that do not divide the block, a short last block
+    ("uniform256", (9 << 20) + 77, 4 << 20),        # exactly chunk-aligned blocks, k = 256
+    ("const41", 12 << 20, 6 << 20),                 # one-symbol blocks, chunked
+    ("logtext", 20 << 20, 0),                       # blocksize 0: ONE block of the whole input (src/encoder.c:163-165)
+    ("zipf255", (4 << 20) + 1, 0),
+])
+def test_big_blocks_are_chunked_bit_exact(torch_mod, codec, oracle, kind, n, bs):
+    """Blocks of 4 MiB and more are cut into 256 KiB chunks (one workgroup each) by the encoder and
+    into 64 KiB chunks by the sub-index decoder; the stream is the oracle's, byte for byte."""
+    torch = torch_mod
+    data = datagen.GENERATORS[kind](n)
+    if kind == "zipf255":                               # a one-symbol block and a two-symbol block among the others
+        data = data.copy()
+        blk = bs if bs else n
+        data[:min(blk, n) // 3] = 7
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    want, woffs = oracle.encode(data, bs, with_offsets=True)
+    got = stream.cpu().numpy()
+    assert got.size == want.size and np.array_equal(got, want), (kind, n, bs)
+    assert np.array_equal(offs.cpu().numpy().astype(np.uint64), woffs)
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, sub, relaxed=True)
+    assert raw == n and torch.equal(out[:n], dev(torch, data))
+    # the plain indexed decode (one workgroup per block) agrees
+    nb = codec.block_count(n, bs)
+    out2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(stream, length, offs, nb, out2, relaxed=True) == n and torch.equal(out2, out[:n])
+    # a damaged chunk start in the sub-index of a big block: found by the chunk in front of it
+    bad = sub.clone()
+    bad[1] += 8                                         # tile 1 of block 0 = not a chunk start: no effect
+    tiles_per_chunk = 65536 // 8192
+    bad[tiles_per_chunk] += 8                           # first tile of decode chunk 1 of block 0
+    raw, out3 = decode_sub(torch, codec, stream, length, offs, n, bs, bad, relaxed=True)
+    assert raw == n and torch.equal(out3[:n], dev(torch, data))
+
+
+def test_one_block_of_256_mib(torch_mod, codec, oracle):
+    """256 MiB of zipf255 as ONE block (blocksize = 0).  Bit-exact against the
+    oracle, and within 3x of the time the same bytes take as 64 KiB blocks."""
+    import time
+    torch = torch_mod
+    n = 256 << 20
+    data = torch.empty(n, dtype=torch.uint8, device="cuda")
+    codec.fill(data, "zipf255")
+    out = torch.empty(codec.encode_bound(n, 65536), dtype=torch.uint8, device="cuda")
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    times = {}
+    for bs in (65536, 0):
+        nb = codec.block_count(n, bs)
+        offs = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+        sub = codec.new_sub_index(n, bs)
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            stream, _, length = codec.encode(data, bs, out=out, offsets=offs, sub_index=sub)
+            raw = codec.decode(out, length, offs, nb, back, sub_index=sub, raw_size=n, blocksize=bs)
+            torch.cuda.synchronize()
+            times[bs] = time.perf_counter() - t0
+        assert raw == n and torch.equal(back, data)
+        if bs == 0:
+            want = oracle.encode(data.cpu().numpy(), 0)
+            got = out[:length].cpu().numpy()
+            assert got.size == want.size and np.array_equal(got, want)
+    assert times[0] < 3 * times[65536] + 1e-3, times

@@ -68,6 +68,20 @@ struct PackAcc {
             emit((uint32_t)(acc >> nacc));
         }
     }
+    /* two codes of at most 16 bits each as ONE push: half as many shifts of the accumulator and
+     * "is a word finished?" tests (a wave runs the emit block whenever any of its lanes finishes a
+     * word, i.e. at nearly every test) */
+    __device__ __forceinline__ void push_pair(uint32_t e0, uint32_t e1)
+    {
+        const uint32_t l1 = e1 & 0xffu;
+        push32(((e0 >> 8) << l1) | (e1 >> 8), (e0 & 0xffu) + l1);
+    }
+    /* three codes of at most 10 bits each (uniform bytes: 9) */
+    __device__ __forceinline__ void push_triple(uint32_t e0, uint32_t e1, uint32_t e2)
+    {
+        const uint32_t l1 = e1 & 0xffu, l2 = e2 & 0xffu;
+        push32(((((e0 >> 8) << l1) | (e1 >> 8)) << l2) | (e2 >> 8), (e0 & 0xffu) + l1 + l2);
+    }
     __device__ __forceinline__ void push(CodeT e)
     {
         uint32_t len = (uint32_t)(e & 0xffu);
@@ -94,7 +108,7 @@ __device__ __forceinline__ uint32_t header_byte(uint32_t j, uint64_t block_len, 
     return (e >> (8 * (j & 1))) & 0xffu;
 }
 
-template <int THREADS, typename CodeT>
+template <int THREADS, typename CodeT, int GROUP = 1>
 __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint64_t len,
                                            const hufcode_t *__restrict__ codes64,
                                            const int16_t *__restrict__ tb, uint32_t tree_len,
@@ -217,8 +231,18 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         uint32_t *const s_first = s_stage + (i_lo + (uint32_t)((s >> 5) - w_lo));
         if (staged) {
             a.gw = s_first;
+            if constexpr (GROUP == 3) {
 #pragma unroll
-            for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);  /* absent symbols have len 0 */
+                for (int k = 0; k + 2 < PACK_SPT; k += 3) a.push_triple((uint32_t)code[k], (uint32_t)code[k + 1], (uint32_t)code[k + 2]);
+                static_assert(PACK_SPT % 3 == 2, "the last two symbols go as a pair");
+                a.push_pair((uint32_t)code[PACK_SPT - 2], (uint32_t)code[PACK_SPT - 1]);
+            } else if constexpr (GROUP == 2) {
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k += 2) a.push_pair((uint32_t)code[k], (uint32_t)code[k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);  /* absent symbols have len 0 */
+            }
         } else {
             a.gw = g_first;
 #pragma unroll
@@ -276,8 +300,11 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
  * Huffman merge order on n <= 121392 symbols gives depth <= 23, plus the wrap-root bit; the
  * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
  * registers, more waves. */
+#ifndef PACK_WAVES_PER_SIMD
+#define PACK_WAVES_PER_SIMD 6          /* 80 VGPRs: the pair form needs 81 when left alone, which costs a workgroup per CU */
+#endif
 template <int THREADS, bool SHORT>
-__global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
+__global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                        uint64_t blocksize,
                                                        const hufcode_t *__restrict__ codetab,
                                                        const int16_t *__restrict__ treebuf,
@@ -307,7 +334,13 @@ __global__ __launch_bounds__(THREADS) void pack_kernel(const uint8_t *__restrict
     }
     uint64_t *sub_tiles = sub.tile_bits ? sub.tile_bits + blk * sub.tpb : nullptr;
     uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb : nullptr;
-    if (SHORT || m.max_len <= 24)
+    if (m.max_len <= 10)                 /* three codes per push */
+        pack_block<THREADS, uint32_t, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                         reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
+    else if (m.max_len <= 16)            /* two codes per push */
+        pack_block<THREADS, uint32_t, 2>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                            reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
+    else if (SHORT || m.max_len <= 24)
         pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                       reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
     else if constexpr (!SHORT)

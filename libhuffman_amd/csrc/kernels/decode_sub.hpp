@@ -154,6 +154,23 @@ __device__ __forceinline__ void dsub_prefetch(DecShared<THREADS> &sh, const uint
     }
 }
 
+/* A group again, step by step with the rare paths (long codes; the block's last, short group).
+ * Out of line: inlined, its state competes with the hot loop's for the 64 VGPRs. */
+template <int THREADS>
+__device__ __noinline__ bool dsub_redo_group(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t s, uint32_t nsym,
+                                             uint32_t lim, uint32_t gb, uint8_t *dst)
+{
+    bool ok = true;
+    LinReader rd;
+    rd.st = stage;
+    rd.load(s);
+    for (uint32_t k = 0; k < nsym; k++) {
+        dst[k] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        if (rd.avail <= 32) rd.refill();
+    }
+    return ok && rd.pos() - s == gb;
+}
+
 /* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.
  * Tables are in sh, dsub_prefetch has been called.  Returns true (workgroup-uniform) when everything
  * was verified; *end_bit = the payload bit behind the chunk's last symbol.  T0 = the chunk's first
@@ -325,16 +342,12 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                         }
                     }
                 }
+                bool group_ok = rd.pos() - s == gb;                 /* (b): exactly the bits of the group */
                 if (__builtin_expect(__ballot(nsym != DSUB_SPL || (special & 0xC000u)) != 0ull, 0)) {
-                    if (nsym != DSUB_SPL || (special & 0xC000u)) {  /* the block's last, short group; groups with long codes */
-                        rd.load(s);
-                        for (uint32_t k = 0; k < nsym; k++) {
-                            dst[k] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
-                            if (rd.avail <= 32) rd.refill();
-                        }
-                    }
+                    if (nsym != DSUB_SPL || (special & 0xC000u))    /* the block's last, short group; groups with long codes */
+                        group_ok = dsub_redo_group<THREADS>(sh, stage, s, nsym, lim, gb, dst);
                 }
-                if (rd.pos() - s != gb) ok = false;                 /* (b): exactly the bits of the group */
+                if (!group_ok) ok = false;
             }
             DPROF_ADD(10, pt); pt = DPROF_T();
             l0 = l1;

@@ -58,32 +58,41 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
     const int tid = (int)threadIdx.x;
 
     for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
-    s_side[2 * tid] = 0;
-    s_side[2 * tid + 1] = 0;
+    s_side[tid] = 0;
+    s_side[THREADS + tid] = 0;
     __syncthreads();
     uint32_t *mine;
     uint32_t one = 1u;
+    /* Array a of a wave keeps the count of byte b at word b ^ rot(a): the frequent bytes of skewed
+     * data then sit in different LDS banks in different arrays.  Without it a wave's arrays all hold
+     * byte 0 in bank 0, byte 1 in bank 1, ... and lanes that meet frequent bytes in one ds_add
+     * collide on those banks even when they use different arrays. */
+    constexpr int ARRS = PACKED ? HTP_ARRAYS : HT_COPIES;
+    const uint32_t arr = PACKED ? ((uint32_t)(tid >> 1) & (HTP_ARRAYS - 1)) : ((uint32_t)tid & (HT_COPIES - 1));
+    const uint32_t rot = arr * (32u / ARRS);
+    const uint32_t rot4 = rot * 0x01010101u;
     if (PACKED) {
-        mine = s_hist + ((tid >> 6) * HTP_ARRAYS + ((tid >> 1) & (HTP_ARRAYS - 1))) * HUF_NSYM;
+        mine = s_hist + ((tid >> 6) * HTP_ARRAYS + arr) * HUF_NSYM;
         one = (tid & 1) ? 0x10000u : 1u;
     } else {
-        mine = s_hist + ((tid >> 6) * HT_COPIES + (tid & (HT_COPIES - 1))) * HUF_NSYM;
+        mine = s_hist + ((tid >> 6) * HT_COPIES + arr) * HUF_NSYM;
     }
+    auto rotated = [rot4](uint4 v) { return make_uint4(v.x ^ rot4, v.y ^ rot4, v.z ^ rot4, v.w ^ rot4); };
     const uint8_t *p = in + base;
     const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
-    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], one);
+    if ((uint64_t)tid < head) atomicAdd(&mine[p[tid] ^ rot], one);
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = (uint64_t)tid;
     uint32_t hot = 0x100u, hot1 = 0x100u;                        /* no byte is singled out yet */
-    const int side = (int)(&s_side[2 * tid] - mine);
+    const int side = (int)(&s_side[tid] - mine);           /* the lane's word for hot0; hot1's is THREADS words on */
     if (i + 3 * THREADS < nvec) {                                /* the first four chunks, then a look at the counts */
         const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                     v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-        hist_add_chunk(mine, v0, one);
-        hist_add_chunk(mine, v1, one);
-        hist_add_chunk(mine, v2, one);
-        hist_add_chunk(mine, v3, one);
+        hist_add_chunk(mine, v0, one, rot4);
+        hist_add_chunk(mine, v1, one, rot4);
+        hist_add_chunk(mine, v2, one, rot4);
+        hist_add_chunk(mine, v3, one, rot4);
         i += 4 * THREADS;
         /* the wave's two most frequent bytes so far (its own copies; a wave's LDS operations are
          * in order): from 1/16 of the 4 KiB seen on, their occurrences are counted per lane */
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
             uint32_t c = 0;
 #pragma unroll
             for (int a = 0; a < ARR; a++) {
-                const uint32_t x = wave_hist[a * HUF_NSYM + bin];
+                const uint32_t x = wave_hist[a * HUF_NSYM + (bin ^ (uint32_t)(a * (32 / ARR)))];
                 c += PACKED ? ((x & 0xffffu) + (x >> 16)) : x;
             }
             cand[qd] = (c << 8) | bin;
@@ -118,32 +127,32 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
         for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {
             const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                         v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-            hist_add_chunk_hot(mine, v0, one, hot, hot1, side);
-            hist_add_chunk_hot(mine, v1, one, hot, hot1, side);
-            hist_add_chunk_hot(mine, v2, one, hot, hot1, side);
-            hist_add_chunk_hot(mine, v3, one, hot, hot1, side);
+            hist_add_chunk_hot(mine, rotated(v0), one, hot ^ rot, hot1 ^ rot, side);
+            hist_add_chunk_hot(mine, rotated(v1), one, hot ^ rot, hot1 ^ rot, side);
+            hist_add_chunk_hot(mine, rotated(v2), one, hot ^ rot, hot1 ^ rot, side);
+            hist_add_chunk_hot(mine, rotated(v3), one, hot ^ rot, hot1 ^ rot, side);
         }
-        for (; i < nvec; i += THREADS) hist_add_chunk_hot(mine, load_stream16(q + i), one, hot, hot1, side);
-        atomicAdd(&mine[hot], s_side[2 * tid]);                  /* a lane's own words: the values are final */
-        if (hot1 < 0x100u) atomicAdd(&mine[hot1], s_side[2 * tid + 1]);
+        for (; i < nvec; i += THREADS) hist_add_chunk_hot(mine, rotated(load_stream16(q + i)), one, hot ^ rot, hot1 ^ rot, side);
+        atomicAdd(&mine[hot ^ rot], s_side[tid]);                /* a lane's own words: the values are final */
+        if (hot1 < 0x100u) atomicAdd(&mine[hot1 ^ rot], s_side[THREADS + tid]);
     }
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
         const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
                     v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-        hist_add_chunk(mine, v0, one);
-        hist_add_chunk(mine, v1, one);
-        hist_add_chunk(mine, v2, one);
-        hist_add_chunk(mine, v3, one);
+        hist_add_chunk(mine, v0, one, rot4);
+        hist_add_chunk(mine, v1, one, rot4);
+        hist_add_chunk(mine, v2, one, rot4);
+        hist_add_chunk(mine, v3, one, rot4);
     }
-    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i), one);
+    for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i), one, rot4);
     const uint64_t tail0 = head + (nvec << 4);
-    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], one);   /* < 16 bytes */
+    if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid] ^ rot], one);   /* < 16 bytes */
     __syncthreads();
     for (int b = tid; b < HUF_NSYM; b += THREADS) {
         uint32_t sum = 0;
 #pragma unroll
         for (int w = 0; w < COPIES; w++) {
-            const uint32_t x = s_hist[w * HUF_NSYM + b];
+            const uint32_t x = s_hist[w * HUF_NSYM + (b ^ ((w % ARRS) * (32 / ARRS)))];
             sum += PACKED ? ((x & 0xffffu) + (x >> 16)) : x;
         }
         s_tot[b] = sum;

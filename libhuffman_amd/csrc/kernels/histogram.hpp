@@ -22,6 +22,10 @@ namespace hufgpu {
 #ifndef HIST_COPIES
 #define HIST_COPIES 4
 #endif
+#ifndef HIST_THREADS
+#define HIST_THREADS 256
+#endif
+#define HIST_SIDE_STRIDE HIST_THREADS      /* hist_tree's per-lane words: [hot0: one per lane][hot1: one per lane], bank = lane */
 
 /* `one` is what a single occurrence adds: 1, or 1 << 16 when two 16-bit counters share a word */
 __device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w, uint32_t one)
@@ -32,7 +36,8 @@ __device__ __forceinline__ void hist_add_bytes(uint32_t *h, uint32_t w, uint32_t
     atomicAdd(&h[w >> 24], one);
 }
 
-__device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t one = 1u)
+/* rot4 = the lane's bank rotation in every byte (0: none): the count of byte b is kept at word b ^ rot */
+__device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t one = 1u, uint32_t rot4 = 0u)
 {
     const uint32_t b = v.x & 0xffu;
     const uint32_t rep = b * 0x01010101u;
@@ -42,17 +47,17 @@ __device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t on
     const unsigned long long same = __ballot(uni && b == b0);
     if (same == act) {                       /* the whole wave step holds one byte value */
         if ((unsigned)lane_id() == (unsigned)__builtin_ctzll(act))
-            atomicAdd(&h[b0], one * 16u * (uint32_t)__popcll(act));
+            atomicAdd(&h[b0 ^ (rot4 & 0xffu)], one * 16u * (uint32_t)__popcll(act));
         return;
     }
     if (uni) {
-        atomicAdd(&h[b], one * 16u);
+        atomicAdd(&h[b ^ (rot4 & 0xffu)], one * 16u);
         return;
     }
-    hist_add_bytes(h, v.x, one);
-    hist_add_bytes(h, v.y, one);
-    hist_add_bytes(h, v.z, one);
-    hist_add_bytes(h, v.w, one);
+    hist_add_bytes(h, v.x ^ rot4, one);
+    hist_add_bytes(h, v.y ^ rot4, one);
+    hist_add_bytes(h, v.z ^ rot4, one);
+    hist_add_bytes(h, v.w ^ rot4, one);
 }
 
 /* The same with two byte values (hot0, hot1; 0x100 = none) taken out of the conflicts: their
@@ -61,7 +66,7 @@ __device__ __forceinline__ void hist_add_chunk(uint32_t *h, uint4 v, uint32_t on
  * ds_add serialise on its bin - 72 % of the LDS cycles of the Zipf histogram were such conflicts. */
 __device__ __forceinline__ int hist_hot_index(uint32_t b, uint32_t hot0, uint32_t hot1, int side)
 {
-    return (b == hot0) ? side : ((b == hot1) ? side + 1 : (int)b);
+    return (b == hot0) ? side : ((b == hot1) ? side + HIST_SIDE_STRIDE : (int)b);
 }
 
 __device__ __forceinline__ void hist_add_bytes_hot(uint32_t *h, uint32_t w, uint32_t one, uint32_t hot0,

@@ -18,7 +18,8 @@ t_end = time.time() + budget
 n_cases = n_corrupt = 0
 
 def make_data():
-    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 1500000)]))
+    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 1500000),
+                        rng.integers(1500000, 9000000)]))           # the last: blocks that are cut into chunks (bs 0 / 4 MiB)
     k = int(rng.choice([1, 2, 3, rng.integers(2, 20), rng.integers(20, 257)]))
     syms = rng.choice(256, size=k, replace=False)
     kind = rng.integers(0, 5)
@@ -35,7 +36,7 @@ def make_data():
 while time.time() < t_end:
     data = make_data()
     n = data.size
-    bs = int(rng.choice([0, 64, 257, 4096, 65536, 131072, 1 << 20]))
+    bs = int(rng.choice([0, 64, 257, 4096, 65536, 131072, 1 << 20, 4 << 20, (4 << 20) + 12345]))
     if bs and n // bs > 30000: bs = 4096
     want, woffs = o.encode(data, bs, with_offsets=True)
     d = torch.from_numpy(data).cuda()
@@ -61,6 +62,21 @@ while time.time() < t_end:
         err, raw, used = c.decode_stream(got, want.size, want.size, back, relaxed=True, sequential=sequential)
         assert (err, raw, used) == (0, n, want.size), ("stream", seed, n_cases, sequential, err, raw, used)
         assert np.array_equal(back[:n].cpu().numpy(), data)
+    # the sub-index path: the encoder's own sub-index (the stream must not change), then the same
+    # sub-index damaged in a random place (results must not change: it is verified, not trusted)
+    sub = c.new_sub_index(n, bs)
+    got2, offs2, len2 = c.encode(d if isinstance(d, torch.Tensor) else torch.from_numpy(data).cuda(), bs, sub_index=sub)
+    assert len2 == want.size and np.array_equal(got2.cpu().numpy(), want), ("encode_sub", seed, n_cases, n, bs)
+    for damage in (False, True):
+        s2 = sub
+        if damage:
+            s2 = sub.clone()
+            v = s2.view(torch.int16)
+            for _ in range(int(rng.integers(1, 4))):
+                v[int(rng.integers(0, v.numel()))] += int(rng.integers(1, 300))
+        back.zero_()
+        raw = c.decode(got2, len2, offs2, nb, back, relaxed=True, sub_index=s2, raw_size=n, blocksize=bs)
+        assert raw == n and np.array_equal(back[:n].cpu().numpy(), data), ("decode_sub", seed, n_cases, n, bs, damage)
     n_cases += 1
     # corruptions: compare error code and delivered bytes with the oracle
     for _ in range(3):

@@ -420,6 +420,7 @@ static HufSubIndex sub_index_view(void *d_sub, uint64_t n, uint64_t blocksize)
     v.tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
     v.tile_bits = (uint64_t *)d_sub;
     v.group_bits = (uint16_t *)((uint64_t *)d_sub + nb * v.tpb);
+    v.lens = (uint8_t *)(v.group_bits + nb * v.gpb);        /* gpb is a multiple of 8: 16-byte aligned */
     return v;
 }
 
@@ -430,7 +431,7 @@ extern "C" uint64_t hufgpu_sub_index_bytes(uint64_t n, uint64_t blocksize)
     const uint64_t nb = hufgpu_block_count(n, blocksize);
     const uint64_t gpb = ((blocksize + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP + 7) & ~7ull;
     const uint64_t tpb = (blocksize + HUF_SUB_TILE - 1) / HUF_SUB_TILE;
-    return nb * tpb * sizeof(uint64_t) + nb * gpb * sizeof(uint16_t);
+    return nb * tpb * sizeof(uint64_t) + nb * gpb * sizeof(uint16_t) + nb * HUF_NSYM;
 }
 
 static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t blocksize,

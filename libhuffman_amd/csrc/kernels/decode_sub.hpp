@@ -90,6 +90,176 @@ __device__ __forceinline__ uint64_t dec_rare_lin(const DecShared<THREADS> &sh, c
     return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
 }
 
+/* ======================================================================================
+ * Tables from the stream's tree AND the encoder's code lengths, in a few parallel steps.
+ *
+ * dec_build_tables (decode.hpp) finds every node's right child by a search and walks the tree once
+ * per table entry: 0.29 of the kernel's 0.78 ms per GiB.  With the code length of every byte value
+ * from the sub-index the same tables follow from prefix sums - and the lengths can be CHECKED
+ * against the serialized tree in parallel, which nothing short of walking it can do without them:
+ *   - the tree has the shape every encoder-made tree has: 4K+1 entries, K leaves (a node followed
+ *     by two -1), 2K nodes, 2K+1 markers, a root with a left child only;
+ *   - with d_k = claimed length of the k-th leaf in preorder, the code of leaf k is the sum of
+ *     2^-d_j over j < k (preorder visits leaves in code order) and the lengths sum to 1/2 exactly;
+ *   - leaf 0 is entry d_0 (its d_0 ancestors precede it), the last leaf is followed only by its
+ *     markers and the root's, and between leaf k and leaf k+1 lie their 3 + d_(k+1) - (d_k - t_k)
+ *     entries, t_k = trailing one bits of leaf k's code (up past t_k right children, then down the
+ *     left spine of the next subtree).
+ * Leaf 0's depth is fixed by the stream, and each further depth by the entry positions and the
+ * depths before it: if every check holds the claimed lengths ARE the tree's.  Anything else -
+ * another shape of tree, a stale sub-index - returns false and the caller walks the tree.
+ * Codes longer than 12 bits get a `long` entry and are decoded by a binary search over the leaves'
+ * codes (dec_rare_fast); the child links are not built.  Lengths above 32 take the walk.
+ * LDS: code[256] (left-aligned in 32 bits), length[256], byte[256] of the leaves in preorder in
+ * sh.lr; sh.fastk = K.
+ * ==================================================================================== */
+template <int THREADS>
+struct DsubFastLds {
+    __device__ static __forceinline__ uint32_t *code(DecShared<THREADS> &sh) { return sh.lr; }
+    __device__ static __forceinline__ uint8_t *len(DecShared<THREADS> &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 256); }
+    __device__ static __forceinline__ uint8_t *sym(DecShared<THREADS> &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 320); }
+    __device__ static __forceinline__ const uint32_t *code(const DecShared<THREADS> &sh) { return sh.lr; }
+    __device__ static __forceinline__ const uint8_t *len(const DecShared<THREADS> &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 256); }
+    __device__ static __forceinline__ const uint8_t *sym(const DecShared<THREADS> &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 320); }
+};
+
+/* largest k < K with code[k] <= v (code[0] = 0) */
+__device__ __forceinline__ uint32_t dsub_leaf_of(const uint32_t *code, uint32_t K, uint32_t v)
+{
+    uint32_t lo = 0, hi = K;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {                     /* K <= 256 */
+        const uint32_t mid = (lo + hi) >> 1;
+        if (hi - lo > 1u) {
+            if (code[mid] <= v) lo = mid; else hi = mid;
+        }
+    }
+    return lo;
+}
+
+template <int THREADS>
+__device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *__restrict__ lens_g)
+{
+    typedef DsubFastLds<THREADS> F;
+    constexpr int ENT = DecShared<THREADS>::ENT;
+    static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256, "two entries per thread");
+    const int tid = (int)threadIdx.x;
+    const uint32_t K = (uint32_t)(tree_len - 1) >> 2;
+    if (tid == 0) sh.fastk = 0;
+    if (tree_len < 9 || tree_len > HUF_TREE_MAX || ((tree_len - 1) & 3) != 0) return false;     /* uniform */
+    uint8_t *s_lens = reinterpret_cast<uint8_t *>(sh.pay);                      /* [256] the claimed lengths by byte value */
+    uint16_t *s_pos = reinterpret_cast<uint16_t *>(sh.pay + 64);                /* [256] entry index of the k-th leaf */
+    __syncthreads();                                                            /* previous user of sh is done */
+    {
+        /* entries 2t and 2t+1 from two aligned 32-bit loads per thread, as in dec_build_tables */
+        const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
+        const uint32_t mis = (uint32_t)(a & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);
+        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;
+        for (int t = tid; 2 * t < ENT; t += THREADS) {
+            const uint32_t lo = (4u * (uint32_t)t < nbytes) ? q[t] : 0u;
+            const uint32_t hi = (4u * (uint32_t)t + 4u < nbytes) ? q[t + 1] : 0u;
+            const uint32_t two = mis ? __builtin_amdgcn_alignbit(hi, lo, 8u * mis) : lo;
+            const int i = 2 * t;
+            sh.ent[i] = (i < tree_len) ? (int16_t)(two & 0xffffu) : (int16_t)-1;
+            if (i + 1 < ENT) sh.ent[i + 1] = (i + 1 < tree_len) ? (int16_t)(two >> 16) : (int16_t)-1;
+        }
+        if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = reinterpret_cast<const uint32_t *>(lens_g)[tid];
+    }
+    __syncthreads();
+    bool ok = true;
+    /* ---- shape: leaves, nodes, markers ---- */
+    {
+        const int i0 = 2 * tid;
+        const int e0 = sh.ent[i0], e1 = sh.ent[i0 + 1], e2 = (i0 + 2 < ENT) ? sh.ent[i0 + 2] : -1, e3 = (i0 + 3 < ENT) ? sh.ent[i0 + 3] : -1;
+        const bool n0 = e0 != -1, n1 = e1 != -1;                                /* (entries at or past tree_len read -1) */
+        const bool l0 = n0 && e1 == -1 && e2 == -1 && i0 + 2 < tree_len;
+        const bool l1 = n1 && e2 == -1 && e3 == -1 && i0 + 3 < tree_len;
+        uint32_t tot;
+        const uint32_t mine = (uint32_t)l0 + (uint32_t)l1 + (((uint32_t)n0 + (uint32_t)n1) << 16);
+        const uint32_t ex = block_excl_scan_u32<THREADS>(mine, sh.part, tot);
+        if ((tot & 0xffffu) != K || (tot >> 16) != 2u * K) ok = false;
+        if (tid == 0 && (sh.ent[0] == -1 || sh.ent[tree_len - 1] != -1)) ok = false;
+        uint32_t k = ex & 0xffffu;
+        if (l0 && k < 256u) { s_pos[k] = (uint16_t)i0; F::sym(sh)[k] = (uint8_t)e0; k++; }
+        if (l1 && k < 256u) { s_pos[k] = (uint16_t)(i0 + 1); F::sym(sh)[k] = (uint8_t)e1; }
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    /* ---- claimed lengths -> codes; they must fill the left half of the code space exactly ---- */
+    uint32_t d = 0;
+    {
+        uint64_t width = 0;
+        if ((uint32_t)tid < K) {
+            d = s_lens[F::sym(sh)[tid]];
+            if (d < 2u || d > 32u) ok = false;
+            else width = 1ull << (32u - d);
+        }
+        uint64_t tot;
+        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(width, reinterpret_cast<uint64_t *>(sh.wtile), tot);
+        if (tot != (1ull << 31)) ok = false;
+        if ((uint32_t)tid < K) {
+            F::code(sh)[tid] = (uint32_t)ex;
+            F::len(sh)[tid] = (uint8_t)d;
+        }
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    /* ---- the entry positions the lengths imply are the stream's ---- */
+    if ((uint32_t)tid < K) {
+        const uint32_t k = (uint32_t)tid;
+        const uint32_t bits = F::code(sh)[k] >> (32u - d);                      /* the d code bits */
+        const uint32_t t = (uint32_t)__builtin_ctz(~bits);                      /* trailing ones (< d: codes start with 0) */
+        const uint32_t pos = s_pos[k];
+        if (k == 0 && pos != d) ok = false;
+        if (k + 1 < K) {
+            const uint32_t dn = F::len(sh)[k + 1];
+            if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
+        } else if (pos + 4u != (uint32_t)tree_len) ok = false;                  /* leaf, its two markers, the root's */
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    /* ---- the table: eight consecutive entries per thread, one 16-byte store ---- */
+    {
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
+        const uint32_t *code = F::code(sh);
+        const uint32_t x0 = (uint32_t)tid * 8u;
+        uint32_t k = dsub_leaf_of(code, K, x0 << (32 - DEC_LUT_BITS));
+        uint32_t e[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t idx = x0 + j;
+            const uint32_t v = idx << (32 - DEC_LUT_BITS);
+            if (v >> 31) {
+                /* the first bit leaves the tree (the root has no right child); the run of bits that fail
+                 * the same way, as in dec_build_tables */
+                const uint32_t skip = dmin<uint32_t>((uint32_t)__clz((int)~v), (uint32_t)DEC_LUT_BITS);
+                e[j] = DEC_E_BAD | DEC_E_NOCW | (skip << 8) | 1u;
+            } else {
+                while (k + 1u < K && code[k + 1u] <= v) k++;
+                const uint32_t dk = F::len(sh)[k];
+                e[j] = (dk <= (uint32_t)DEC_LUT_BITS) ? ((dk << 8) | (uint32_t)F::sym(sh)[k]) : (uint32_t)DEC_E_LONG;
+            }
+        }
+        *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+    if (tid == 0) sh.fastk = K;
+    __syncthreads();
+    return true;
+}
+
+/* a codeword longer than the table's 12 bits with dsub_fast_tables' tables: the leaf whose code
+ * interval holds the 32 bits at the position; result as dec_rare_packed */
+template <int THREADS>
+__device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, const uint32_t *st, uint32_t pos, uint32_t lim)
+{
+    typedef DsubFastLds<THREADS> F;
+    const uint32_t g = pos >> 5, o = pos & 31u;
+    const uint32_t w = o ? ((st[g] << o) | (st[g + 1] >> (32u - o))) : st[g];
+    if (w >> 31) return ((uint64_t)CW_BAD << 40) | (pos + 1u);
+    const uint32_t k = dsub_leaf_of(F::code(sh), sh.fastk, w);
+    const uint32_t p = pos + (uint32_t)F::len(sh)[k];
+    if (p > lim) return (uint64_t)CW_EXH << 40;
+    return ((uint64_t)CW_OK << 40) | ((uint64_t)F::sym(sh)[k] << 32) | p;
+}
+
 /* One table step of a lane: returns the entry (low byte = symbol); *ok is cleared when the lookup is
  * not a codeword.  The rare paths sit behind one wave-uniform branch. */
 template <int THREADS>
@@ -98,7 +268,7 @@ __device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, LinR
     uint32_t e = sh.lut[rd.index()];
     if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
         if (e >= DEC_E_LONG) {
-            const uint64_t r = dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
+            const uint64_t r = sh.fastk ? dec_rare_fast<THREADS>(sh, rd.st, rd.pos(), lim) : dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
             if ((int)(r >> 40) == CW_OK) {
                 rd.load((uint32_t)r);
                 e = (uint32_t)(r >> 32) & 0xffu;           /* advance 0: the reader already stands behind it */
@@ -420,7 +590,12 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
                                (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
     const uint64_t T0 = uni64(sub.tile_bits[blk * sub.tpb + sym0 / HUF_SUB_TILE]);   /* first payload bit of the chunk, as told */
 #ifndef DSUB_ABLATE_TABLES      /* (diagnostic builds: what the kernel costs without one of its phases) */
-    if (leaf < 0) rc = dec_build_tables<THREADS, false>(sh, tree, m.tree_len, &leaf);
+    if (leaf < 0) {
+#ifndef DSUB_NO_FAST_TABLES
+        if (!dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM))
+#endif
+            rc = dec_build_tables<THREADS, false>(sh, tree, m.tree_len, &leaf);
+    }
 #endif
     if (rc != HUFE_OK) {
         good = false;

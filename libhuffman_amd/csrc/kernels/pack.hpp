@@ -42,6 +42,9 @@ namespace hufgpu {
 struct HufSubIndex {
     uint64_t *tile_bits;      /* NULL = no sub-index */
     uint16_t *group_bits;
+    uint8_t *lens;            /* [nblocks][256] code length of every byte value (0: absent): lets the decoder
+                                 build its tables in a few parallel steps and CHECK them against the stream's
+                                 tree (decode_sub.hpp, dsub_fast_tables) instead of walking that tree */
     uint64_t gpb, tpb;
 };
 
@@ -334,6 +337,8 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     }
     uint64_t *sub_tiles = sub.tile_bits ? sub.tile_bits + blk * sub.tpb : nullptr;
     uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb : nullptr;
+    if (sub.tile_bits && m.tree_len != 5)
+        for (int i = (int)threadIdx.x; i < HUF_NSYM; i += THREADS) sub.lens[blk * HUF_NSYM + i] = (uint8_t)(codes[i] & 0xffu);
     if (m.max_len <= 10)                 /* three codes per push */
         pack_block<THREADS, uint32_t, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                          reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);

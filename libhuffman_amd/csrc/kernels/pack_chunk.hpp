@@ -348,6 +348,8 @@ __global__ __launch_bounds__(THREADS, PACK_CHUNK_WAVES_PER_SIMD) void pack_chunk
     const bool first = c == 0, last = sym0 + len == blen;
     uint64_t *sub_tiles = sub.tile_bits ? sub.tile_bits + blk * sub.tpb + sym0 / HUF_SUB_TILE : nullptr;
     uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb + sym0 / HUF_SUB_GROUP : nullptr;
+    if (sub.tile_bits && first && m.tree_len != 5)
+        for (int i = (int)threadIdx.x; i < HUF_NSYM; i += THREADS) sub.lens[blk * HUF_NSYM + i] = (uint8_t)(codes[i] & 0xffu);
     uint32_t *code32 = reinterpret_cast<uint32_t *>(s_code);
     const uint8_t *src = in + base + sym0;
     if (m.max_len <= 16)

@@ -299,3 +299,38 @@ def test_one_block_of_256_mib(torch_mod, codec, oracle):
             got = out[:length].cpu().numpy()
             assert got.size == want.size and np.array_equal(got, want)
     assert times[0] < 3 * times[65536] + 1e-3, times
+
+
+def test_code_lengths_in_the_sub_index_are_checked_against_the_tree(torch_mod, codec):
+    """The sub-index carries the code length of every byte value so that the decoder can build its
+    tables from prefix sums; it checks them against the stream's tree first.  Lengths that are wrong
+    in ways the cheap sums cannot see (two values swapped: the Kraft sum is unchanged) must be
+    caught by the position check, and the decode falls back to walking the tree."""
+    torch = torch_mod
+    n, bs = 4 * 65536, 65536
+    for kind in ("zipf255", "uniform255", "logtext"):
+        data = datagen.GENERATORS[kind](n)
+        stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+        nb = codec.block_count(n, bs)
+        tiles = nb * ((bs + 8191) // 8192)
+        gpb = ((bs + 31) // 32 + 7) & ~7
+        lens0 = 8 * tiles + 2 * nb * gpb                   # byte offset of the lengths
+        v = sub.view(torch.uint8)
+        lens = v[lens0:lens0 + nb * 256].view(nb, 256).clone()
+        assert int(lens.max()) <= 32 and int((lens > 0).sum(1).min()) >= 2
+        rng = np.random.default_rng(5)
+        for trial in range(6):
+            bad = sub.clone()
+            bv = bad.view(torch.uint8)[lens0:lens0 + nb * 256].view(nb, 256)
+            b = int(rng.integers(0, nb))
+            present = torch.nonzero(lens[b] > 0).flatten().cpu().numpy()
+            if trial % 3 == 0:                              # swap the lengths of two present values
+                i, j = rng.choice(present, 2, replace=False)
+                bv[b, i], bv[b, j] = lens[b, j], lens[b, i]
+            elif trial % 3 == 1:                            # one length off by one
+                i = int(rng.choice(present))
+                bv[b, i] = lens[b, i] + 1
+            else:                                           # the lengths of another block
+                bv[b] = lens[(b + 1) % nb].flip(0)
+            raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, bad)
+            assert raw == n and torch.equal(out[:n], dev(torch, data)), (kind, trial)

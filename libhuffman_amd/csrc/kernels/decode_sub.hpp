@@ -483,6 +483,44 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                      * wave's 2 KiB round in LDS for whole-line nt stores needs 8 more registers, and with
                      * 80 VGPRs = 3 workgroups per CU the kernel takes 0.97 ms). */
                     const bool aligned = (((uintptr_t)dst) & 15u) == 0;
+#ifndef DSUB_BUF_READER
+                    /* Position-based window: every two symbols the 64 bits at the position are read
+                     * again from the stage (one ds_read2_b32, one 64-bit shift) - no bit buffer to
+                     * refill, no branch: 8 wave instructions per symbol where the refilled 64-bit buffer
+                     * (-DDSUB_BUF_READER) has 14, most of them in the refill block that some lane needs at
+                     * every test; more LDS reads instead (zipf255 0.65 -> 0.62 ms, uniform bytes +-0). */
+                    uint32_t p = s;
+#pragma unroll 1
+                    for (int h = 0; h < 2; h++) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                const uint32_t *wp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(stage) + ((p >> 3) & ~3u));
+                                uint64_t b = (((uint64_t)wp[0] << 32) | wp[1]) << (p & 31u);
+                                const uint32_t e1 = sh.lut[(uint32_t)(b >> 32) >> (32 - DEC_LUT_BITS)];
+                                const uint32_t l1 = (e1 >> 8) & 31u;
+                                b <<= l1;
+                                const uint32_t e2 = sh.lut[(uint32_t)(b >> 32) >> (32 - DEC_LUT_BITS)];
+                                special |= e1 | e2;
+                                acc = __builtin_amdgcn_alignbit(e1, acc, 8);
+                                acc = __builtin_amdgcn_alignbit(e2, acc, 8);
+                                p += l1 + ((e2 >> 8) & 31u);
+                            }
+                            w[k] = acc;
+                        }
+                        if (aligned) {
+                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                        }
+                    }
+                    rd.load(p);
+                }
+#else
 #pragma unroll 1
                     for (int h = 0; h < 2; h++) {
                         uint32_t w[4];
@@ -512,6 +550,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                         }
                     }
                 }
+#endif
                 bool group_ok = rd.pos() - s == gb;                 /* (b): exactly the bits of the group */
                 if (__builtin_expect(__ballot(nsym != DSUB_SPL || (special & 0xC000u)) != 0ull, 0)) {
                     if (nsym != DSUB_SPL || (special & 0xC000u))    /* the block's last, short group; groups with long codes */

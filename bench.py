@@ -359,13 +359,25 @@ class Bench:
         n = hi - lo
         nb = codec.block_count(n, bs)
         relaxed = workload == "uniform256"
-        full = self.make_input(workload, n_total, 0) if rank == 0 else None
-        shard = torch.empty(n, dtype=torch.uint8, device=dev)
-        out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
-        offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
-        sub = codec.new_sub_index(n, bs)
-        back = torch.empty(n, dtype=torch.uint8, device=dev)
-        result = torch.empty(n_total if rank == 0 else 0, dtype=torch.uint8, device=dev)
+        # every rank allocates first, then all agree that everybody could: a rank that fails alone
+        # (rank 0 holds the whole job's input, stream and output) must not leave the others in a collective
+        alloc_ok, alloc_err = 1, None
+        try:
+            full = self.make_input(workload, n_total, 0) if rank == 0 else None
+            shard = torch.empty(n, dtype=torch.uint8, device=dev)
+            out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
+            offs = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+            sub = codec.new_sub_index(n, bs)
+            back = torch.empty(n, dtype=torch.uint8, device=dev)
+            result = torch.empty(n_total if rank == 0 else 0, dtype=torch.uint8, device=dev)
+            spare = torch.empty(codec.encode_bound(n_total, bs) if rank == 0 else 0, dtype=torch.uint8, device=dev)
+            del spare                                   # what the gathered stream will need on rank 0
+        except Exception as e:
+            alloc_ok, alloc_err = 0, repr(e)
+        flag = torch.tensor([alloc_ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return {"error": "allocation failed on some rank: %s" % alloc_err} if rank == 0 else None
         in_sizes = [h - l for l, h in plan]
         gathered = None
         legs = {"scatter_in": 0.0, "encode": 0.0, "gather_stream": 0.0, "scatter_stream": 0.0, "decode": 0.0,

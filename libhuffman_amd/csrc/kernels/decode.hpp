@@ -847,7 +847,7 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
         s_min[(N >> 2) + tid] = (uint16_t)m;                          /* level 2: one node per thread */
 #pragma unroll
         for (int k = 3; k <= 8; k++) {                                /* levels 3..8 inside the wave */
-            m = dmin<uint32_t>(m, (uint32_t)__shfl_xor((int)m, 1 << (k - 3)));
+            m = dmin<uint32_t>(m, wave_xor_any(m, 1 << (k - 3)));
             if ((tid & ((1 << (k - 2)) - 1)) == 0) s_min[(N >> k) + (tid >> (k - 2))] = (uint16_t)m;
         }
         __syncthreads();
@@ -1076,7 +1076,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         DPROF_ADD(3, pt); pt = DPROF_T();
         for (;;) {
             /* left neighbour's end: a shuffle inside the wave, LDS across the wave seams */
-            uint32_t ns = (uint32_t)__shfl_up((int)tr.end, 1);
+            uint32_t ns = wave_up1_u32(tr.end);
             if ((tid & 63) == 0) ns = (tid == 0) ? first_start : sh.wend[(tid >> 6) - 1];
             const int changed = (ns != tr.start);
             __syncthreads();                               /* everyone has read sh.wend */

@@ -112,14 +112,14 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
         }
         uint32_t best = dmax(dmax(cand[0], cand[1]), dmax(cand[2], cand[3]));
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) best = dmax(best, (uint32_t)__shfl_xor((int)best, o));
+        for (int o = 1; o < 64; o <<= 1) best = dmax(best, wave_xor_any(best, o));
         if ((best >> 8) >= 256u && (best >> 8) < 4096u) {        /* (all 4 096 equal: the run paths take it) */
             hot = best & 0xffu;
             uint32_t second = 0;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) second = dmax(second, cand[qd] == best ? 0u : cand[qd]);
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) second = dmax(second, (uint32_t)__shfl_xor((int)second, o));
+            for (int o = 1; o < 64; o <<= 1) second = dmax(second, wave_xor_any(second, o));
             if ((second >> 8) >= 256u) hot1 = second & 0xffu;
         }
     }

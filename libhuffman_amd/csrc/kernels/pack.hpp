@@ -206,7 +206,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
             for (int k = 0; k < PACK_SPT; k++) code[k] = 0;
         }
         uint32_t tile_bits;
-        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(mybits, s_part, tile_bits);
+        const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
         if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
             if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
             if (tid == 0) sub_tiles[t0 / TILE] = bitpos - (uint64_t)hdr_end * 8ull;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
 
         /* ---- tails hop one lane to the right ---- */
-        uint32_t in_tail = (uint32_t)__shfl_up((int)tail_val, 1);
+        uint32_t in_tail = wave_up1_u32(tail_val);
         if (lane == 63) s_tail[wave] = tail_val;
         __syncthreads();
         if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];

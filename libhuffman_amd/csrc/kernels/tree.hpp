@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         bits += shfl_xor_u64(bits, o);
-        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+        maxlen = dmax(maxlen, wave_xor_any(maxlen, o));
     }
     int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
     for (int i = lane; i < tree_len; i += 64) tb[i] = s_tree[i];
@@ -238,7 +238,11 @@ __device__ __forceinline__ void wave_sort256(uint32_t (&k)[4])
                 const bool lower = (lane & (jj >> 2)) == 0u;              /* I hold the pair's lower position */
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)k[r], (int)(jj >> 2));
+                    /* the partner lane's key by DPP / ds_swizzle (util.hpp): 72 of a sort's 84 exchanges
+                     * need no LDS round trip any more (the loops are unrolled: d is a constant) */
+                    const uint32_t d = jj >> 2;
+                    const uint32_t o = d == 1 ? wave_xor_u32<1>(k[r]) : d == 2 ? wave_xor_u32<2>(k[r]) : d == 4 ? wave_xor_u32<4>(k[r])
+                                     : d == 8 ? wave_xor_u32<8>(k[r]) : d == 16 ? wave_xor_u32<16>(k[r]) : wave_xor_u32<32>(k[r]);
                     k[r] = (lower == up) ? dmin(k[r], o) : dmax(k[r], o);
                 }
             } else {
@@ -302,7 +306,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
 #pragma unroll
             for (int j = 0; j < 4; j++) cnt += rate[j];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+            for (int o = 1; o < 64; o <<= 1) cnt += wave_xor_any(cnt, o);
             /* pack_kernel never looks codes up for a 5-entry tree (all-zero payload), so the 2 KiB
              * code table of this block is not written */
             int16_t *tb1 = treebuf + blk * HUF_TREE_STRIDE;
@@ -469,7 +473,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         bits += shfl_xor_u64(bits, o);
-        maxlen = dmax(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+        maxlen = dmax(maxlen, wave_xor_any(maxlen, o));
     }
     HufBlockMeta mm;
     mm.tree_len = (uint32_t)tree_len;

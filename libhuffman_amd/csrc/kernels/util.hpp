@@ -60,12 +60,10 @@ __device__ __forceinline__ void store_pack16(uint4 *p, uint4 v)
     *p = v;
 }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
+__device__ __forceinline__ uint32_t wave_xor_any(uint32_t v, int o);
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)      /* mask: a power of two, constant after unrolling */
 {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = (uint32_t)__shfl_xor((int)lo, mask);
-    hi = (uint32_t)__shfl_xor((int)hi, mask);
-    return ((uint64_t)hi << 32) | lo;
+    return ((uint64_t)wave_xor_any((uint32_t)(v >> 32), mask) << 32) | wave_xor_any((uint32_t)v, mask);
 }
 __device__ __forceinline__ uint32_t shfl_xor_key(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask); }
 __device__ __forceinline__ uint64_t shfl_xor_key(uint64_t v, int mask) { return shfl_xor_u64(v, mask); }
@@ -84,6 +82,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
     return v;
 }
+/* Value of lane (lane ^ D), D a power of two: DPP inside a row of 16 lanes (quad_perm for 1 and 2,
+ * two row rotations and a select for 4, one rotation for 8), ds_swizzle for 16 (no address register),
+ * ds_bpermute only for 32.  __shfl_xor is a ds_bpermute with a computed address for every distance:
+ * an LDS round trip per exchange - 84 of them per 256-key bitonic sort (tree.hpp). */
+template <int D>
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);        /* quad_perm:[1,0,3,2] */
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   /* quad_perm:[2,3,0,1] */
+    else if constexpr (D == 4) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);             /* row_ror:4  */
+        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12C, 0xf, 0xf, false);             /* row_ror:12 */
+        return (lane_id() & 4) ? a : b;
+    } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); /* row_ror:8 */
+    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                   /* bit mode: xor 16, and 31 */
+    else return (uint32_t)__shfl_xor((int)v, D);
+}
+
+/* the same for a distance that is a constant after unrolling (for (o = 1; o < 64; o <<= 1) ...) */
+__device__ __forceinline__ uint32_t wave_xor_any(uint32_t v, int o)
+{
+    return o == 1 ? wave_xor_u32<1>(v) : o == 2 ? wave_xor_u32<2>(v) : o == 4 ? wave_xor_u32<4>(v)
+         : o == 8 ? wave_xor_u32<8>(v) : o == 16 ? wave_xor_u32<16>(v) : wave_xor_u32<32>(v);
+}
+/* value of the lane below (lane 0 keeps its own): wave_shr:1 */
+__device__ __forceinline__ uint32_t wave_up1_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 /* value of a lane given by a wave-uniform index (v_readlane: no LDS, no address register) */
 __device__ __forceinline__ uint32_t wave_lane_u32(uint32_t v, uint32_t uniform_lane)
 {

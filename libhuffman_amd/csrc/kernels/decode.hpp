@@ -1090,7 +1090,7 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         DPROF_ADD(4, pt); pt = DPROF_T();
         /* output positions */
         uint32_t seg_total;
-        const uint32_t ex = block_excl_scan<THREADS, uint32_t>(tr.cnt, sh.part, seg_total);
+        const uint32_t ex = block_excl_scan_u32<THREADS>(tr.cnt, sh.part, seg_total);
         const uint64_t remaining = block_len - produced;
         /* the first walk that left the tree, in stream order, is a real error if it happens
          * before the block is complete (src/decoder.c:69-71); later ones are padding/garbage.

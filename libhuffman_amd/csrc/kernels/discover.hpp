@@ -158,7 +158,7 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
         }
     }
     uint32_t total;
-    const uint32_t ex = block_excl_scan<DISC_THREADS, uint32_t>((uint32_t)__popcll(mask), s_part, total);
+    const uint32_t ex = block_excl_scan_u32<DISC_THREADS>((uint32_t)__popcll(mask), s_part, total);
     if (!WRITE) {
         masks[slot] = mask;
         if (threadIdx.x == 0) wg_counts[blockIdx.x] = total;

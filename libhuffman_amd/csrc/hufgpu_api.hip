@@ -69,6 +69,13 @@ struct hufgpu_ctx {
     uint64_t *d_walk;             /* 5 result words of walk_kernel */
     uint64_t *d_spec_off;         /* speculative output offsets of the candidates (disc_cands + 1) */
 
+    /* blocks of many MiB in a raw stream: the sub-index built for them (kernels/spec_index.hpp) */
+    uint64_t big_lanes, big_groups, big_sub_bytes;
+    uint64_t *d_big_entry, *d_big_exit, *d_big_pre, *d_big_gstart;
+    uint32_t *d_big_cnt;
+    void *d_big_sub;
+    uint64_t *d_big_offs;         /* SPEC_WORDS status words, then the two-entry block index */
+
     uint64_t *d_result;           /* 8 words: err, raw_len, failing block / consumed, blocks, complete consumed, complete raw */
     uint64_t complete_used, complete_raw;   /* of the last hufgpu_decode_stream(): see hufgpu_decode_stream_complete() */
     uint64_t *h_result;           /* pinned mirror */
@@ -211,6 +218,17 @@ static void free_disc_ws(hufgpu_ctx *c, int which)
     }
 }
 
+static void free_big_ws(hufgpu_ctx *c, int which)
+{
+    if (which & 1) {
+        (void)hipFree(c->d_big_entry); (void)hipFree(c->d_big_exit); (void)hipFree(c->d_big_pre); (void)hipFree(c->d_big_cnt);
+        c->d_big_entry = c->d_big_exit = c->d_big_pre = NULL; c->d_big_cnt = NULL; c->big_lanes = 0;
+    }
+    if (which & 2) { (void)hipFree(c->d_big_gstart); c->d_big_gstart = NULL; c->big_groups = 0; }
+    if (which & 4) { (void)hipFree(c->d_big_sub); c->d_big_sub = NULL; c->big_sub_bytes = 0; }
+    if (which & 8) { (void)hipFree(c->d_big_offs); c->d_big_offs = NULL; }
+}
+
 static void free_decode_ws(hufgpu_ctx *c)
 {
     free_two_level(&c->dec_lens);
@@ -231,6 +249,7 @@ extern "C" int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx)
     free_encode_ws(ctx);
     free_decode_ws(ctx);
     free_disc_ws(ctx, 3);
+    free_big_ws(ctx, 15);
     (void)hipFree(ctx->d_walk);
     (void)hipFree(ctx->d_result);
     (void)hipFree(ctx->d_zipf);
@@ -668,6 +687,111 @@ static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint
     return (int)ctx->h_result[0];
 }
 
+/* Leading blocks of HUF_BIG_BLOCK symbols and more (blocksize = 0 makes the whole input ONE block,
+ * src/encoder.c:163-165): one workgroup per block would leave the device idle, so a sub-index is
+ * built for each such block (kernels/spec_index.hpp) and decode_sub_kernel decodes - and verifies -
+ * it chunk by chunk.  Stops at the first block this does not apply to or does not work for; the
+ * caller's general path takes over at *pos / *rawpos and reports whatever is wrong there. */
+static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint8_t *out,
+                             uint64_t out_cap, uint32_t flags, hipStream_t s, void *stream, uint64_t *pos_io,
+                             uint64_t *rawpos_io)
+{
+    const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
+    uint64_t pos = *pos_io, rawpos = *rawpos_io;
+    if (!ctx->d_big_offs) HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_offs, (SPEC_WORDS + 2) * sizeof(uint64_t)));
+    unsigned long long *d_status = (unsigned long long *)ctx->d_big_offs;
+    uint64_t *d_offs = ctx->d_big_offs + SPEC_WORDS;
+    while (pos < length && avail - pos >= HUF_HEADER_FIXED) {
+        spec_head_kernel<<<dim3(1), dim3(64), 0, s>>>(st, avail, pos, d_status);
+        HIP_OK(ctx, hipGetLastError());
+        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, d_status, SPEC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipStreamSynchronize(s));
+        const uint64_t block_len = ctx->h_result[SPEC_BLOCK_LEN];
+        const long long tl = (long long)ctx->h_result[SPEC_TREE_LEN];
+        const long long leaf = (long long)ctx->h_result[SPEC_LEAF];
+        if (ctx->h_result[SPEC_FAIL] || block_len < HUF_BIG_BLOCK || block_len > HUFGPU_MAX_BLOCK) break;
+        if (tl < 1 || tl > max_tree || block_len > out_cap - rawpos) break;
+        const uint64_t pay_off = pos + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+        if (pay_off > avail) break;
+        const uint64_t pay_bytes = avail - pay_off;
+
+        const uint64_t sub_bytes = hufgpu_sub_index_bytes(block_len, block_len);
+        if (sub_bytes > ctx->big_sub_bytes) {
+            free_big_ws(ctx, 4);
+            HIP_OK(ctx, hipMalloc(&ctx->d_big_sub, sub_bytes));
+            ctx->big_sub_bytes = sub_bytes;
+        }
+        const HufSubIndex sub = sub_index_view(ctx->d_big_sub, block_len, block_len);
+        uint64_t o1;
+        if (leaf >= 0) {
+            /* one 0 bit per symbol: nothing to find out */
+            o1 = pay_off + ((block_len + 7) >> 3);
+            if (o1 > avail) break;
+            const uint64_t h_offs[2] = {pos, o1};
+            HIP_OK(ctx, hipMemcpyAsync(d_offs, h_offs, sizeof(h_offs), hipMemcpyHostToDevice, s));
+            HIP_OK(ctx, hipStreamSynchronize(s));
+        } else {
+            /* an encoder-made payload has at most 9 bits per symbol (8 + the wrap root's) */
+            uint64_t max_bits = pay_bytes * 8;
+            if (max_bits > 9 * block_len + 64) max_bits = 9 * block_len + 64;
+            const uint64_t nlanes = (max_bits + SPEC_LANE_BITS - 1) / SPEC_LANE_BITS;
+            const uint64_t ngroups = (block_len + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
+            if (nlanes == 0) break;
+            if (nlanes > ctx->big_lanes) {
+                free_big_ws(ctx, 1);
+                const uint64_t cap = nlanes + nlanes / 8 + 16;
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_entry, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_exit, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_pre, (cap + 1) * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_cnt, cap * sizeof(uint32_t)));
+                ctx->big_lanes = cap;
+            }
+            if (ngroups > ctx->big_groups) {
+                free_big_ws(ctx, 2);
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_gstart, (ngroups + 1) * sizeof(uint64_t)));
+                ctx->big_groups = ngroups;
+            }
+            SpecJob j;
+            j.tree = st + pos + HUF_HEADER_FIXED;
+            j.tree_len = (int)tl;
+            j.pay = st + pay_off;
+            j.pay_bytes = pay_bytes;
+            j.max_bits = max_bits;
+            j.block_len = block_len;
+            j.nlanes = nlanes;
+            j.entry = ctx->d_big_entry;
+            j.exitp = ctx->d_big_exit;
+            j.cnt = ctx->d_big_cnt;
+            j.pre = ctx->d_big_pre;
+            j.gstart = ctx->d_big_gstart;
+            j.status = d_status;
+            const unsigned lane_wgs = (unsigned)((nlanes + DEC_THREADS - 1) / DEC_THREADS);
+            spec_scan_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
+            spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j);
+            spec_mark_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
+            spec_groups_kernel<<<dim3((unsigned)((sub.gpb + 255) / 256)), dim3(256), 0, s>>>(j, sub, pos, pay_off, d_offs);
+            HIP_OK(ctx, hipGetLastError());
+            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, d_status, SPEC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_OK(ctx, hipStreamSynchronize(s));
+            if (ctx->h_result[SPEC_FAIL] || !ctx->h_result[SPEC_FOUND]) break;
+            o1 = pay_off + ((ctx->h_result[SPEC_END_BITS] + 7) >> 3);
+            if (o1 > avail) break;
+        }
+        uint64_t got = 0;
+        const int err = decode_impl(ctx, st, o1, d_offs, 1, &sub, block_len, out + rawpos, out_cap - rawpos, flags, &got, stream);
+        if (err != HUFE_OK || got != block_len) break;   /* the general path decodes it again and says what is wrong */
+        pos = o1;
+        rawpos += block_len;
+    }
+    *pos_io = pos;
+    *rawpos_io = rawpos;
+    return HUFE_OK;
+}
+
+static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
+                                 void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
+                                 uint64_t *consumed, void *stream);
+
 extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                                     void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                                     uint64_t *consumed, void *stream)
@@ -678,6 +802,33 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
     if (length == 0) return HUFE_OK;                  /* src/decoder.c:218 */
     if ((!d_stream && avail) || (!d_out && out_cap)) return HUFE_ARGUMENT;
     HIP_OK(ctx, hipSetDevice(ctx->device));
+    uint64_t pos = 0, rawpos = 0;
+    if (!(flags & HUFGPU_SEQUENTIAL) && avail >= HUF_BIG_BLOCK / 8) {
+        const int rc = decode_big_blocks(ctx, (const uint8_t *)d_stream, avail, length, (uint8_t *)d_out, out_cap, flags,
+                                         pick_stream(ctx, stream), stream, &pos, &rawpos);
+        if (rc != HUFE_OK) return rc;
+    }
+    ctx->complete_used = pos;
+    ctx->complete_raw = rawpos;
+    if (pos >= length) {
+        if (raw_len) *raw_len = rawpos;
+        if (consumed) *consumed = pos;
+        return HUFE_OK;
+    }
+    uint64_t raw2 = 0, used2 = 0;
+    const int err = decode_stream_general(ctx, (const uint8_t *)d_stream + pos, avail - pos, length - pos,
+                                          (uint8_t *)d_out + rawpos, out_cap - rawpos, flags, &raw2, &used2, stream);
+    ctx->complete_used += pos;
+    ctx->complete_raw += rawpos;
+    if (raw_len) *raw_len = rawpos + raw2;
+    if (consumed) *consumed = pos + used2;
+    return err;
+}
+
+static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
+                                 void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
+                                 uint64_t *consumed, void *stream)
+{
     hipStream_t s = pick_stream(ctx, stream);
     const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
     const uint8_t *st = (const uint8_t *)d_stream;

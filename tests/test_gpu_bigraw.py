@@ -1,0 +1,186 @@
+"""Raw-stream decode (no block index, no sub-index: what huf_decode() gets, src/decoder.c:205-283) of
+blocks of many MiB - the reference's default blocksize = 0 makes the whole input ONE block
+(src/encoder.c:163-165).  The library builds a sub-index for such a block on the device
+(kernels/spec_index.hpp) and decodes it chunk by chunk; every result is compared with the input, the
+error cases with the in-order decoder of the same library (which the other tests pin to the oracle)."""
+import time
+
+import numpy as np
+import pytest
+
+from libhuffman_amd import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def codec(torch_mod):
+    from libhuffman_amd.codec import GpuCodec
+    c = GpuCodec(0)
+    yield c
+    c.close()
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).cuda()
+
+
+def fibonacci_bytes(n, k=24):
+    """byte i occurs ~fib(i) times: codes up to k - 1 bits (longer than the decoder's 12-bit table)"""
+    f = [1, 1]
+    while len(f) < k:
+        f.append(f[-1] + f[-2])
+    rep = max(1, n // sum(f))
+    one = np.concatenate([np.full(c, i, np.uint8) for i, c in enumerate(f)])
+    rng = np.random.default_rng(5)
+    data = np.tile(one, rep + 1)[:n].copy()
+    rng.shuffle(data)
+    return data
+
+
+@pytest.mark.parametrize("kind", ["zipf255", "uniform256", "const41", "two", "fib"])
+def test_one_block_raw_stream(torch_mod, codec, kind):
+    torch = torch_mod
+    n = (48 << 20) + 12345
+    if kind == "two":
+        data = dev(torch, (datagen.uniform256(n) & 1) * 7)
+    elif kind == "fib":
+        data = dev(torch, fibonacci_bytes(n))
+    else:
+        data = codec.fill(torch.empty(n, dtype=torch.uint8, device="cuda"), kind)
+    stream, offs, length = codec.encode(data, 0)                 # blocksize 0: one block
+    assert offs.numel() == 2
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    res = codec.decode_stream(stream, length, length, out, relaxed=True)
+    assert res == (0, n, length), (kind, res)
+    assert torch.equal(out[:n], data), kind
+    # again, timed: one workgroup for the whole block would take tens of milliseconds here
+    out.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = codec.decode_stream(stream, length, length, out, relaxed=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert res == (0, n, length) and torch.equal(out[:n], data), kind
+    print(f"\n  raw stream, one block of {n >> 20} MiB of {kind}: {ms:.2f} ms = {n / ms / 1.074e6:.1f} GiB/s")
+    assert ms < 15.0, (kind, ms)
+
+
+def test_several_big_blocks_then_small(torch_mod, codec):
+    """big blocks of different statistics in a row (the lanes behind a short payload decode the next
+    block's header as if it were payload - and must not matter), a short last block, and a tail of
+    small blocks appended as a second stream"""
+    torch = torch_mod
+    bs = (6 << 20) + 77
+    parts = [datagen.zipf255(bs), (datagen.uniform256(bs) & 1) * 9, datagen.uniform256(bs), np.full(bs, 3, np.uint8),
+             datagen.zipf255(bs // 5)]
+    data = np.concatenate(parts)
+    d = dev(torch, data)
+    stream, offs, length = codec.encode(d, bs)
+    tail = dev(torch, datagen.zipf255(300000))
+    stream2, _, length2 = codec.encode(tail, 65536)
+    both = torch.cat([stream[:length], stream2[:length2]])
+    out = torch.zeros(data.size + 300000 + 64, dtype=torch.uint8, device="cuda")
+    for sequential in (False, True):
+        res = codec.decode_stream(both, both.numel(), both.numel(), out.zero_(), relaxed=True, sequential=sequential)
+        assert res == (0, data.size + 300000, both.numel()), (sequential, res)
+        assert torch.equal(out[:data.size], d) and torch.equal(out[data.size:data.size + 300000], tail), sequential
+    # `length` ends inside the second block: blocks that begin before it are decoded whole
+    cut = int(offs[1].item()) + 5
+    res = codec.decode_stream(both, both.numel(), cut, out.zero_(), relaxed=True)
+    ref = codec.decode_stream(both, both.numel(), cut, torch.zeros_like(out), relaxed=True, sequential=True)
+    assert res == ref and res[0] == 0 and res[1] == 2 * bs, (res, ref)
+    assert torch.equal(out[:2 * bs], d[:2 * bs])
+
+
+def test_damaged_big_blocks_match_the_in_order_decoder(torch_mod, codec):
+    torch = torch_mod
+    bs = 5 << 20
+    data = dev(torch, np.concatenate([datagen.zipf255(bs), datagen.zipf255(bs)[::-1], datagen.zipf255(bs // 2)]))
+    stream, offs, length = codec.encode(data, bs)
+    o = [int(x) for x in offs.cpu().tolist()]
+    good = stream[:length].clone()
+    out = torch.zeros(data.numel() + 64, dtype=torch.uint8, device="cuda")
+    ref_out = torch.zeros_like(out)
+
+    def both(s, avail, ln):
+        a = codec.decode_stream(s, avail, ln, out.zero_())
+        b = codec.decode_stream(s, avail, ln, ref_out.zero_(), sequential=True)
+        assert a == b, (a, b)
+        n = a[1]
+        assert torch.equal(out[:n], ref_out[:n])
+        return a
+
+    # payload damage in the middle of the second block: zipf255's tree is full, so the bits still
+    # decode to SOMETHING - the block's symbol count and the following header decide
+    bad = good.clone()
+    mid = (o[1] + o[2]) // 2
+    bad[mid:mid + 64] ^= 0x5a
+    both(bad, bad.numel(), bad.numel())
+    # the tree of the second block damaged
+    bad = good.clone()
+    bad[o[1] + 12] ^= 0xff
+    both(bad, bad.numel(), bad.numel())
+    # block_len of the first block one too large / far too large
+    for delta in (1, 1 << 33):
+        bad = good.clone()
+        v = int.from_bytes(bytes(bad[:8].cpu().tolist()), "little") + delta
+        bad[:8] = torch.tensor(list(v.to_bytes(8, "little")), dtype=torch.uint8, device="cuda")
+        both(bad, bad.numel(), bad.numel())
+    # truncated inside the first block's payload, inside the second block's tree, right after the second block
+    for avail in (o[1] - 1000, o[1] + 40, o[2]):
+        both(good, avail, avail)
+    # output too small for the second block
+    small = torch.zeros(bs + 100, dtype=torch.uint8, device="cuda")
+    a = codec.decode_stream(good, good.numel(), good.numel(), small)
+    b = codec.decode_stream(good, good.numel(), good.numel(), torch.zeros_like(small), sequential=True)
+    assert a == b, (a, b)
+
+
+def test_c_api_default_blocksize_is_one_block(torch_mod):
+    """huf_encode() then huf_decode() through memory streams with blocksize = 0 (README.md:50-52 leaves
+    it at the default): ONE block of 96 MiB; the stream equals the oracle's byte for byte."""
+    import ctypes as C
+    from libhuffman_amd import _native as N
+    from oracle.oracle import Oracle
+    L = N.load()
+    n = (96 << 20) + 321
+    data = datagen.zipf255(n)
+    want = Oracle().encode(data, 0)
+    rin, rout, rback = C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)()
+    bin_, bout, bback = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.huf_memopen(C.byref(rin), C.byref(bin_), n) == 0
+    assert L.huf_memopen(C.byref(rout), C.byref(bout), n) == 0
+    assert L.huf_memopen(C.byref(rback), C.byref(bback), n) == 0
+    assert rin.contents.write(rin.contents.stream, data.ctypes.data_as(C.c_void_p), n) == 0
+    cfg = N.Config(n, 0, 0, 0, rin, rout)
+    t0 = time.perf_counter()
+    assert L.huf_encode(C.byref(cfg)) == 0
+    t1 = time.perf_counter()
+    m = C.c_size_t()
+    L.huf_memlen(rout, C.byref(m))
+    enc = np.frombuffer(C.string_at(bout.value, m.value), np.uint8)
+    assert enc.size == want.size and np.array_equal(enc, want)
+    assert int.from_bytes(enc[:8].tobytes(), "little") == n          # one block
+    dcfg = N.Config(m.value, 0, 0, 0, rout, rback)
+    t2 = time.perf_counter()
+    assert L.huf_decode(C.byref(dcfg)) == 0
+    t3 = time.perf_counter()
+    L.huf_memlen(rback, C.byref(m))
+    assert m.value == n
+    assert np.array_equal(np.frombuffer(C.string_at(bback.value, n), np.uint8), data)
+    print(f"\n  C API, blocksize 0, {n >> 20} MiB: huf_encode {(t1 - t0) * 1e3:.1f} ms, huf_decode {(t3 - t2) * 1e3:.1f} ms "
+          f"(host memory streams, PCIe included)")
+    for r in (rin, rout, rback):
+        L.huf_memclose(C.byref(r))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for b in (bin_, bout, bback):
+        libc.free(b)

@@ -182,6 +182,15 @@ int huf_gpu_memwrap(struct __huf_read_writer **self, const void *data, size_t le
  * The reader is never asked for more than config->length bytes. */
 int huf_gpu_decode_blocks(const struct __huf_encoder_config *config, uint64_t *consumed);
 
+/* huf_gpu_sessions: huf_encode()/huf_decode() calls hold one SESSION (a device context and its staging
+ * buffers) each.  The environment decides how many there are: HUF_GPU_DEVICE=k (default 0) = one
+ * session on device k, concurrent calls take turns; HUF_GPU_DEVICES="0,1,2" or "all" = one session per
+ * listed device ("0,0" = two on device 0), and concurrent calls - disjoint configs on different
+ * threads, parallel in the reference (src/encoder.c:379-392 has no global state) - run side by side
+ * on different sessions, so a multi-threaded caller uses every listed GPU.  Returns the sessions that
+ * hold a context so far; *configured = the length of the list. */
+int huf_gpu_sessions(int *configured);
+
 #ifdef __cplusplus
 }
 #endif

@@ -677,24 +677,95 @@ huf_error_t huf_tree_deserialize(huf_tree_t *self, const int16_t *buf, size_t le
     return HUF_ERROR_SUCCESS;
 }
 
-/* ------------------------------------------------------------------ GPU session shared by huf_encode/huf_decode */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static hufgpu_ctx_t *g_ctx = NULL;
-static int g_relaxed = -1;
-
+/* ------------------------------------------------------------------ GPU sessions of huf_encode/huf_decode
+ * A session = one device context plus its staging buffers; a call holds one session from start to
+ * end.  By default there is ONE session on device HUF_GPU_DEVICE (0): concurrent calls take turns.
+ * HUF_GPU_DEVICES = "0,1,2" / "all" makes one session per listed device ("0,0": two on device 0), and
+ * concurrent calls - disjoint configs on different threads are legal and parallel in the
+ * reference, which has no global state (src/encoder.c:379-392) - run side by side, each on the
+ * first session that is free: a multi-threaded C caller uses every listed GPU. */
 typedef struct {
     void *h_a, *h_b;           /* pinned staging */
     size_t h_a_cap, h_b_cap;
     void *d_a, *d_b, *d_c;     /* device staging (d_c: one round of a descriptor-fed decode) */
     size_t d_a_cap, d_b_cap, d_c_cap;
 } staging_t;
-static staging_t g_stage;
+
+#define HUF_MAX_SESSIONS 32
+typedef struct {
+    int device;
+    int busy;
+    hufgpu_ctx_t *ctx;
+    staging_t stage;
+} session_t;
+
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_pool_cv = PTHREAD_COND_INITIALIZER;
+static session_t g_sessions[HUF_MAX_SESSIONS];
+static int g_nsessions = 0;
+static int g_relaxed = -1;
+static __thread session_t *t_session = NULL;       /* the session the calling thread holds */
+#define g_ctx (t_session->ctx)
+#define g_stage (t_session->stage)
+
+/* the device list, read once (no GPU call: a process without a GPU still gets its loud error from
+ * session_acquire) */
+static void session_pool_init(void)
+{
+    if (g_nsessions) return;
+    const char *list = getenv("HUF_GPU_DEVICES");
+    if (list && *list) {
+        if (strcmp(list, "all") == 0) {
+            int n = hufgpu_device_count();
+            if (n > HUF_MAX_SESSIONS) n = HUF_MAX_SESSIONS;
+            for (int i = 0; i < n; i++) g_sessions[g_nsessions++].device = i;
+        } else {
+            const char *p = list;
+            while (*p && g_nsessions < HUF_MAX_SESSIONS) {
+                char *end = NULL;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                if (v >= 0) g_sessions[g_nsessions++].device = (int)v;
+                p = end;
+                while (*p == ',' || *p == ' ') p++;
+            }
+        }
+    }
+    if (!g_nsessions) {
+        const char *dev = getenv("HUF_GPU_DEVICE");
+        g_sessions[g_nsessions++].device = dev ? atoi(dev) : 0;
+    }
+}
+
+static void session_enter(void)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    session_pool_init();
+    for (;;) {
+        for (int i = 0; i < g_nsessions; i++)
+            if (!g_sessions[i].busy) {
+                g_sessions[i].busy = 1;
+                t_session = &g_sessions[i];
+                pthread_mutex_unlock(&g_pool_lock);
+                return;
+            }
+        pthread_cond_wait(&g_pool_cv, &g_pool_lock);
+    }
+}
+
+static void session_leave(void)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    t_session->busy = 0;
+    t_session = NULL;
+    pthread_cond_signal(&g_pool_cv);
+    pthread_mutex_unlock(&g_pool_lock);
+}
 
 static huf_error_t session_acquire(void)
 {
     if (g_ctx) return HUF_ERROR_SUCCESS;
-    const char *dev = getenv("HUF_GPU_DEVICE");
-    int rc = hufgpu_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
+    int rc = hufgpu_ctx_create(&g_ctx, t_session->device);
     if (rc != HUF_ERROR_SUCCESS) {
         fprintf(stderr, "libhuffman: the codec needs an MI355X (gfx950) GPU and has no CPU fallback: %s\n",
                 hufgpu_last_error(NULL));
@@ -709,7 +780,8 @@ static huf_error_t grow_host(void **p, size_t *cap, size_t want)
     if (*cap >= want) return HUF_ERROR_SUCCESS;
     if (*p) (void)hipHostFree(*p);
     *p = NULL; *cap = 0;
-    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipSetDevice(t_session->device);
+    if (hipHostMalloc(p, want, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         return HUF_ERROR_MEMORY_ALLOCATION;
     }
@@ -1082,9 +1154,9 @@ huf_error_t huf_encode(const huf_config_t *config)
     TRY(huf_encoder_init(&enc, config));
     huf_error_t err = HUF_ERROR_SUCCESS;
     if (enc->config->length) {                    /* length 0: nothing is read or written */
-        pthread_mutex_lock(&g_lock);
+        session_enter();
         err = encode_locked(enc);
-        pthread_mutex_unlock(&g_lock);
+        session_leave();
     }
     huf_encoder_free(&enc);
     return err;
@@ -1348,9 +1420,9 @@ huf_error_t huf_decode(const huf_config_t *config)
     TRY(huf_decoder_init(&dec, config));
     huf_error_t err = HUF_ERROR_SUCCESS;
     if (dec->config->length) {                    /* test/decode_test.c:32-36: empty input is fine */
-        pthread_mutex_lock(&g_lock);
+        session_enter();
         err = decode_locked(dec, NULL);
-        pthread_mutex_unlock(&g_lock);
+        session_leave();
     }
     huf_decoder_free(&dec);
     return err;
@@ -1365,12 +1437,24 @@ int huf_gpu_decode_blocks(const huf_config_t *config, uint64_t *consumed)
     TRY(huf_decoder_init(&dec, config));
     huf_error_t err = HUF_ERROR_SUCCESS;
     if (dec->config->length) {
-        pthread_mutex_lock(&g_lock);
+        session_enter();
         err = decode_locked(dec, consumed);
-        pthread_mutex_unlock(&g_lock);
+        session_leave();
     }
     huf_decoder_free(&dec);
     return err;
+}
+
+/* sessions that hold a device context right now, and how many the device list allows */
+int huf_gpu_sessions(int *configured)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    session_pool_init();
+    int live = 0;
+    for (int i = 0; i < g_nsessions; i++) live += g_sessions[i].ctx != NULL;
+    if (configured) *configured = g_nsessions;
+    pthread_mutex_unlock(&g_pool_lock);
+    return live;
 }
 
 }  /* extern "C" */

@@ -184,3 +184,23 @@ def test_c_api_default_blocksize_is_one_block(torch_mod):
     libc.free.argtypes = [C.c_void_p]
     for b in (bin_, bout, bback):
         libc.free(b)
+
+
+@pytest.mark.parametrize("devices,threads,want_live", [("0,0,0", 3, 3), (None, 3, 1)])
+def test_concurrent_calls_take_different_sessions(torch_mod, devices, threads, want_live):
+    """HUF_GPU_DEVICES lists one session per entry; concurrent huf_encode/huf_decode calls from
+    different threads run side by side on different sessions (here: three on the one GPU of the
+    box), bit-exact with the oracle; without the variable there is one session and they take turns."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("HUF_GPU_DEVICES", None)
+    if devices:
+        env["HUF_GPU_DEVICES"] = devices
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sessions_child.py"), root, str(threads)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    print("\n  " + r.stdout.strip().replace("\n", "\n  "))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"sessions live={want_live} configured={want_live if devices else 1}" in r.stdout, r.stdout

@@ -45,8 +45,9 @@ typedef struct hufgpu_ctx hufgpu_ctx_t;
 #define HUFGPU_SEQUENTIAL   2u  /* hufgpu_decode_stream only: skip the parallel block discovery and take the
                                    blocks strictly in order (diagnostics; results are identical) */
 
-/* Largest block the kernels take (bytes).  Larger blocks -> HUF_ERROR_INVALID_ARGUMENT. */
-#define HUFGPU_MAX_BLOCK ((uint64_t)1 << 30)
+/* Largest block the kernels take (bytes): per-block byte counts are 32-bit.  Larger blocks ->
+ * HUF_ERROR_INVALID_ARGUMENT. */
+#define HUFGPU_MAX_BLOCK (((uint64_t)1 << 32) - 1)
 
 /* Number of usable gfx950 devices; 0 when HIP is unusable (never an error by itself). */
 int hufgpu_device_count(void);

@@ -204,3 +204,47 @@ def test_concurrent_calls_take_different_sessions(torch_mod, devices, threads, w
     print("\n  " + r.stdout.strip().replace("\n", "\n  "))
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"sessions live={want_live} configured={want_live if devices else 1}" in r.stdout, r.stdout
+
+
+def test_one_block_of_3_5_gib(torch_mod, codec):
+    """A block just below the kernels' limit (2^32 - 1 bytes, include/huffman_gpu.h) - blocksize = 0 on a
+    multi-GiB input.  The oracle cannot encode that in test time; parity comes from two properties:
+    (1) counts scaled by a common factor give the same tree (every comparison of src/tree.c:292-427
+    scales with them), so the tree of P repeated 8 m times is the tree of P repeated 8 times;
+    (2) the payload of 8 copies of P is a whole number of bytes, so the payload of 8 m copies is
+    that byte string m times.  P x 8 (128 MiB, one block) is what the oracle encodes."""
+    torch = torch_mod
+    from oracle.oracle import Oracle
+    p_len, m = 16 << 20, 28                                   # 8 * 28 * 16 MiB = 3.5 GiB
+    P = datagen.zipf255(p_len)
+    want = Oracle().encode(np.tile(P, 8), 0)
+    tl = int.from_bytes(want[8:10].tobytes(), "little", signed=True)
+    hdr = 10 + 2 * tl
+    period = want.size - hdr                                  # payload bytes of 8 copies, no padding bits
+    data = dev(torch, P).repeat(8 * m)
+    n = data.numel()
+    assert n == 8 * m * p_len and n < (1 << 32)
+    sub = codec.new_sub_index(n, 0)
+    stream, offs, length = codec.encode(data, 0, sub_index=sub)
+    assert offs.numel() == 2 and length == hdr + m * period
+    head = stream[:hdr].cpu().numpy()
+    assert int.from_bytes(head[:8].tobytes(), "little") == n
+    assert np.array_equal(head[8:], want[8:hdr]), "tree differs from the oracle's tree of the same proportions"
+    assert torch.equal(stream[hdr:hdr + period], dev(torch, want[hdr:])), "first period differs from the oracle's payload"
+    assert torch.equal(stream[hdr:length - period], stream[hdr + period:length]), "payload is not periodic"
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    # with the encoder's sub-index, then as a raw stream (the sub-index is built on the device)
+    assert codec.decode(stream, length, offs, 1, out, sub_index=sub, raw_size=n, blocksize=0) == n
+    assert torch.equal(out, data)
+    out.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = codec.decode_stream(stream, length, length, out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert res == (0, n, length) and torch.equal(out, data)
+    print(f"\n  raw stream, one block of {n / 2**30:.2f} GiB: {ms:.1f} ms")
+    assert ms < 200.0
+    # one byte more than the limit is an argument error, not a wrong stream
+    with pytest.raises(Exception):
+        codec.encode(torch.zeros(1 << 32, dtype=torch.uint8, device="cuda"), 0)

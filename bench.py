@@ -479,12 +479,29 @@ def main() -> None:
 
     main_rec = bench.run(args.workload, args.steps, args.warmup)
     sec_recs = {w: bench.run(w, args.steps, args.warmup) for w in secondary}
-    root_rec = None
+    # The scatter/gather form is an extra figure: it runs on a helper thread with a deadline, so that
+    # a collective that never returns (a rank that failed alone) cannot take the headline with it -
+    # the line is then printed without it and the ranks leave without the final barrier.
+    root_box = {"rec": None, "done": False}
     if use_dist and args.placement in ("auto", "root"):
-        try:
-            root_rec = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
-        except Exception as e:                      # the extra figure never takes the headline down with it
-            root_rec = {"error": repr(e)}
+        import threading
+
+        def extra():
+            try:
+                torch.cuda.set_device(local_rank)
+                root_box["rec"] = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
+            except Exception as e:                  # the extra figure never takes the headline down with it
+                root_box["rec"] = {"error": repr(e)}
+            root_box["done"] = True
+
+        th = threading.Thread(target=extra, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("BENCH_EXTRA_TIMEOUT", "300")))
+        if not root_box["done"]:
+            root_box["rec"] = {"error": "timed out (BENCH_EXTRA_TIMEOUT)"}
+    else:
+        root_box["done"] = True
+    root_rec = root_box["rec"]
 
     result = None
     if rank == 0:
@@ -523,6 +540,11 @@ def main() -> None:
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
+    if not root_box["done"]:
+        # a collective of the extra figure is stuck: no barrier, no teardown (both would wait for it)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        os._exit(0)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

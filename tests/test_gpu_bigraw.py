@@ -248,3 +248,46 @@ def test_one_block_of_3_5_gib(torch_mod, codec):
     # one byte more than the limit is an argument error, not a wrong stream
     with pytest.raises(Exception):
         codec.encode(torch.zeros(1 << 32, dtype=torch.uint8, device="cuda"), 0)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_big_blocks_against_the_in_order_decoder(torch_mod, codec, seed):
+    """random alphabets, skews and block sizes around 4-7 MiB; each stream also with random damage
+    (bit flips anywhere, truncation): the parallel path (device-built sub-index) and the in-order
+    decoder must agree on the error, the bytes written, the bytes consumed and the output"""
+    torch = torch_mod
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(5):
+        k = int(rng.choice([2, 3, 5, 17, 64, 200, 256]))
+        skew = float(rng.choice([0.0, 0.5, 1.0, 2.0, 4.0]))
+        w = 1.0 / np.arange(1, k + 1) ** skew
+        bs = int(rng.integers(4 << 20, 7 << 20))
+        nblk = int(rng.integers(1, 4))
+        n = bs * (nblk - 1) + int(rng.integers(1, bs + 1))
+        syms = rng.permutation(256)[:k].astype(np.uint8)
+        data = syms[rng.choice(k, size=n, p=w / w.sum())]
+        d = dev(torch, data)
+        stream, offs, length = codec.encode(d, bs)
+        good = stream[:length].clone()
+        out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        ref = torch.zeros_like(out)
+        a = codec.decode_stream(good, length, length, out, relaxed=True)
+        assert a == (0, n, length) and torch.equal(out[:n], d), (seed, case, k, skew, bs, a)
+        for trial in range(4):
+            bad = good.clone()
+            avail = length
+            kind = int(rng.integers(0, 4))
+            if kind == 0:                                   # a burst of bit flips somewhere
+                pos = int(rng.integers(0, length - 16))
+                bad[pos:pos + int(rng.integers(1, 16))] ^= int(rng.integers(1, 256))
+            elif kind == 1:                                 # inside a header or tree
+                b = int(rng.integers(0, nblk))
+                bad[int(offs[b].item()) + int(rng.integers(0, 40))] ^= int(rng.integers(1, 256))
+            elif kind == 2:                                 # truncated
+                avail = int(rng.integers(1, length))
+            else:                                           # a single flipped bit
+                bad[int(rng.integers(0, length))] ^= 1 << int(rng.integers(0, 8))
+            a = codec.decode_stream(bad, avail, avail, out.zero_(), relaxed=True)
+            b = codec.decode_stream(bad, avail, avail, ref.zero_(), relaxed=True, sequential=True)
+            assert a == b, (seed, case, trial, kind, k, skew, bs, a, b)
+            assert torch.equal(out[:a[1]], ref[:a[1]]), (seed, case, trial, kind)

@@ -433,18 +433,15 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                     const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
                     Q4 v[STEPS];
                     uint32_t x[STEPS];
+                    /* every lane loads (lanes past the needed words load the last ones again and do not
+                     * store them): a load under a condition leaves its 15 destination registers
+                     * "maybe unchanged", which the compiler then carries around the whole tile loop */
+                    const uint32_t last4 = (nwords - 1u) & ~3u;
 #pragma unroll
                     for (int k = 0; k < STEPS; k++) {
-                        const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
-                        if (i4 < nwords) {
-#ifdef DSUB_STAGE_DWORDS          /* (diagnostic: five 4-byte loads instead of a 4-byte aligned 16-byte load) */
-                            const volatile uint32_t *vq = qw + i4;
-                            v[k].x = vq[0]; v[k].y = vq[1]; v[k].z = vq[2]; v[k].w = vq[3];
-#else
-                            v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
-#endif
-                            x[k] = qw[i4 + 4];
-                        }
+                        const uint32_t i4 = dmin<uint32_t>(4u * ((uint32_t)lane + 64u * (uint32_t)k), last4);
+                        v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
+                        x[k] = qw[i4 + 4];
                     }
 #pragma unroll
                     for (int k = 0; k < STEPS; k++) {
@@ -489,6 +486,67 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                      * refill, no branch: 8 wave instructions per symbol where the refilled 64-bit buffer
                      * (-DDSUB_BUF_READER) has 14, most of them in the refill block that some lane needs at
                      * every test; more LDS reads instead (zipf255 0.65 -> 0.62 ms, uniform bytes +-0). */
+#ifndef DSUB_WINDOW_V1
+                    /* The position register holds (payload bit - 1) + 8 * (LDS byte address of the
+                     * stage): (Q >> 3) & ~3 IS the LDS address of the word pair, and the 32 bits at the
+                     * position are ONE v_alignbit_b32 of the pair by ~Q (shift amounts 0..31: the pair
+                     * is the one that holds bit position - 1, so the position is never the pair's first
+                     * bit).  The second table index comes from a 32-bit shift of that register: 13 simple
+                     * instructions per two symbols where the 64-bit window (-DDSUB_WINDOW_V1) had 15 with
+                     * two 64-bit shifts (zipf255 0.643 -> 0.626 ms).
+                     * (Measured and dropped: a lane decoding the two halves of its group side by side -
+                     * the encoder also wrote the bits of every group's first half - to have two
+                     * independent chains of LDS reads per lane.  At 64 VGPRs the tile loop spills
+                     * (0.88 ms), at 78 VGPRs = 3 workgroups per CU it takes 0.72 ms: the loop is bound by
+                     * VALU + LDS throughput, not by the latency of its dependent reads.) */
+                    typedef const __attribute__((address_space(3))) uint32_t *lds_words;
+                    typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
+                    const uint32_t q0 = s - 1u + 8u * (uint32_t)(uintptr_t)(lds_words)stage;
+                    const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
+#define DSUB_WINDOW(Q, acc)                                                                                   \
+                    {                                                                                         \
+                        lds_words wp_ = (lds_words)(uintptr_t)(((Q) >> 3) & ~3u);                              \
+                        const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[0], wp_[1], ~(Q));                 \
+                        const uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));    \
+                        const uint32_t l1_ = (e1_ >> 8) & 31u;                                                \
+                        const uint32_t d2_ = d1_ << l1_;                                                      \
+                        const uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));    \
+                        special |= e1_ | e2_;                                                                 \
+                        acc = __builtin_amdgcn_alignbit(e1_, acc, 8);                                         \
+                        acc = __builtin_amdgcn_alignbit(e2_, acc, 8);                                         \
+                        (Q) += l1_ + ((e2_ >> 8) & 31u);                                                      \
+                    }
+                    uint32_t Q = q0;
+#ifdef DSUB_UNROLL_H
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+                    for (int h = 0; h < 2; h++) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int j = 0; j < 2; j++) DSUB_WINDOW(Q, acc)
+                            w[k] = acc;
+                        }
+                        if (aligned) {
+#ifdef DSUB_NT_STORES
+                            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                            v4u val = {w[0], w[1], w[2], w[3]};
+                            __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(dst) + h);
+#else
+                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                        }
+                    }
+#undef DSUB_WINDOW
+                    const uint32_t p = s + (Q - q0);
+#else
                     uint32_t p = s;
 #pragma unroll 1
                     for (int h = 0; h < 2; h++) {
@@ -518,6 +576,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                             for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
                         }
                     }
+#endif
                     rd.load(p);
                 }
 #else

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sched.h>
+#include <sys/mman.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -90,6 +92,22 @@ typedef struct {
     int readonly;
 } membuf_t;
 
+/* A stream buffer: zeroed like the reference's calloc (src/io.c:79-104, :181), free()d by the caller
+ * like the reference's.  From a few MiB on the kernel is asked to back it with huge pages: the
+ * first write into such a buffer is bound by page faults, and a 2 MiB page is one fault instead of
+ * 512 (transparent huge pages are in "madvise" mode on the GPU boxes). */
+#define HUF_BIG_BUFFER ((size_t)4 << 20)
+static void *stream_alloc(size_t bytes)
+{
+    void *p = calloc(bytes ? bytes : 1, 1);
+    if (p && bytes >= HUF_BIG_BUFFER) {
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)p + page - 1) & ~(page - 1), hi = ((uintptr_t)p + bytes) & ~(page - 1);
+        if (hi > lo) (void)madvise((void *)lo, (size_t)(hi - lo), MADV_HUGEPAGE);      /* advice only: failure is fine */
+    }
+    return p;
+}
+
 /* room for `count` more bytes behind the stream's contents */
 static huf_error_t mem_reserve(membuf_t *m, size_t count)
 {
@@ -100,7 +118,7 @@ static huf_error_t mem_reserve(membuf_t *m, size_t count)
         size_t want = m->cap * 2;
         if (count > want) want = count * 2;
         if (want < m->len + count) want = m->len + count;
-        void *grown = calloc(want ? want : 1, 1);
+        void *grown = stream_alloc(want);
         if (!grown) return HUF_ERROR_MEMORY_ALLOCATION;
         if (m->len) memcpy(grown, *m->buf, m->len);
         free(*m->buf);
@@ -138,7 +156,7 @@ huf_error_t huf_memopen(huf_read_writer_t **self, void **buf, size_t capacity)
     GUARD(buf);
     huf_read_writer_t *rw = (huf_read_writer_t *)calloc(1, sizeof(*rw));
     membuf_t *m = (membuf_t *)calloc(1, sizeof(*m));
-    void *mem = calloc(capacity ? capacity : 1, 1);
+    void *mem = stream_alloc(capacity);
     if (!rw || !m || !mem) {
         free(rw); free(m); free(mem);
         return HUF_ERROR_MEMORY_ALLOCATION;
@@ -799,6 +817,87 @@ static huf_error_t grow_dev(void **p, size_t *cap, size_t want)
     return HUF_ERROR_SUCCESS;
 }
 
+/* Device -> a memory stream's buffer.  The bytes behind a stream's contents are usually pages that
+ * were never touched (a fresh buffer, the caller's huf_memopen capacity): copied into as they are,
+ * the copy spends its time in page faults (240 MiB: 28-35 ms for a 4.5 ms copy).  So the pages are
+ * populated first - madvise(MADV_POPULATE_WRITE), contents untouched, a few threads on disjoint
+ * parts; with the huge pages stream_alloc asked for that is 2-3 ms - and copied into afterwards
+ * (not at the same time as ANY copy of this process, in either direction: the copies' page pinning
+ * and the populating threads then fight for the address-space lock - populating under the copy
+ * itself 56 ms, under the input's copy to the device still slower than one after the other). */
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+#define PREFAULT_MIN ((size_t)16 << 20)
+typedef struct { char *p; size_t n; } prefault_t;
+
+static void *prefault_main(void *arg)
+{
+    prefault_t *w = (prefault_t *)arg;
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = (uintptr_t)w->p & ~(page - 1), hi = ((uintptr_t)w->p + w->n + page - 1) & ~(page - 1);
+    if (madvise((void *)lo, (size_t)(hi - lo), MADV_POPULATE_WRITE) != 0)
+        for (volatile char *q = w->p; q < w->p + w->n; q += page) *q = *q;     /* older kernels: a write fault per page, contents kept */
+    return NULL;
+}
+
+static int prefault_threads(void)
+{
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("HUF_GPU_PREFAULT_THREADS");
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        n = e ? atoi(e) : (int)(cpus >= 4 ? 4 : cpus);
+        if (n < 0) n = 0;
+        if (n > 16) n = 16;
+    }
+    return n;
+}
+
+/* populate [p, p + n) on helper threads; prefault_end() waits for them */
+typedef struct {
+    prefault_t part[16];
+    pthread_t th[16];
+    int started;            /* bit i: th[i] runs */
+} prefault_job_t;
+
+static void prefault_begin(prefault_job_t *j, char *p, size_t n, int also_here)
+{
+    j->started = 0;
+    const int nthreads = prefault_threads();
+    if (n < PREFAULT_MIN || nthreads <= 0) return;
+    const size_t piece = ((n / (size_t)nthreads) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   /* whole huge pages */
+    for (int i = 0; i < nthreads; i++) {
+        const size_t off = (size_t)i * piece;
+        if (off >= n) break;
+        j->part[i].p = p + off;
+        j->part[i].n = (n - off < piece) ? n - off : piece;
+        if (i == 0 && also_here) continue;                          /* the first part is the calling thread's */
+        if (pthread_create(&j->th[i], NULL, prefault_main, &j->part[i]) == 0) j->started |= 1 << i;
+        else prefault_main(&j->part[i]);
+    }
+    if (also_here) prefault_main(&j->part[0]);
+}
+
+static void prefault_end(prefault_job_t *j)
+{
+    for (int i = 0; i < 16; i++)
+        if (j->started & (1 << i)) pthread_join(j->th[i], NULL);
+    j->started = 0;
+}
+
+static huf_error_t d2h_to_memstream(membuf_t *wmem, const void *d_src, size_t n)
+{
+    TRY(mem_reserve(wmem, n));
+    char *dst = (char *)*wmem->buf + wmem->len;
+    prefault_job_t job;
+    prefault_begin(&job, dst, n, 1);
+    prefault_end(&job);
+    TRY(hufgpu_memcpy_d2h(g_ctx, dst, d_src, n));
+    wmem->len += n;
+    return HUF_ERROR_SUCCESS;
+}
+
 static int relaxed_tree(void)
 {
     if (g_relaxed < 0) {
@@ -1055,28 +1154,29 @@ static huf_error_t encode_rounds(huf_encoder_t *enc, uint64_t batch, membuf_t *r
         const uint64_t take = (length - done < batch) ? length - done : batch;
         /* one large read per round; a short read is an error exactly like the reference's
          * block read (src/encoder.c:296, src/bufio.c:251-253) */
+        int rc = HUF_ERROR_SUCCESS;
         if (rmem) {
             if (rmem->len - rmem->off < take) {
                 rmem->off = rmem->len;                          /* what a failed read would have consumed */
-                return HUF_ERROR_READ_WRITE;
+                rc = HUF_ERROR_READ_WRITE;
+            } else {
+                rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, (const char *)*rmem->buf + rmem->off, take);
+                if (rc == HUF_ERROR_SUCCESS) rmem->off += take;
             }
-            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, (const char *)*rmem->buf + rmem->off, take));
-            rmem->off += take;
         } else if (rd->started) {
-            TRY(fd_reader_wait(rd, round, take));
-            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rd->buf[round], take));
-            fd_reader_release(rd, round);                       /* the next read starts under the encode */
+            rc = fd_reader_wait(rd, round, take);
+            if (rc == HUF_ERROR_SUCCESS) rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rd->buf[round], take);
+            if (rc == HUF_ERROR_SUCCESS) fd_reader_release(rd, round);   /* the next read starts under the encode */
         } else {
-            TRY(huf_bufio_read(enc->bufio_reader, g_stage.h_a, take));
-            TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take));
+            rc = huf_bufio_read(enc->bufio_reader, g_stage.h_a, take);
+            if (rc == HUF_ERROR_SUCCESS) rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, take);
         }
         uint64_t out_len = 0;
-        int rc = hufgpu_encode(g_ctx, g_stage.d_a, take, blocksize, g_stage.d_b, g_stage.d_b_cap, NULL, &out_len, NULL);
+        if (rc == HUF_ERROR_SUCCESS)
+            rc = hufgpu_encode(g_ctx, g_stage.d_a, take, blocksize, g_stage.d_b, g_stage.d_b_cap, NULL, &out_len, NULL);
         if (rc != HUF_ERROR_SUCCESS) return (huf_error_t)rc;
         if (wmem) {
-            TRY(mem_reserve(wmem, out_len));
-            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, out_len));
-            wmem->len += out_len;
+            TRY(d2h_to_memstream(wmem, g_stage.d_b, out_len));
         } else if (wr->started) {
             TRY(fd_writer_push(wr, g_stage.d_b, out_len));      /* waits for the write of two rounds ago */
         } else {
@@ -1273,9 +1373,7 @@ static huf_error_t decode_rounds_fd(huf_decoder_t *dec, fd_worker_t *rd, membuf_
         /* bytes of the blocks that decoded completely are delivered even when a later block
          * fails, as the reference's unbuffered writer would have done */
         if (raw && wmem) {
-            TRY(mem_reserve(wmem, raw));
-            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, raw));
-            wmem->len += raw;
+            TRY(d2h_to_memstream(wmem, g_stage.d_b, raw));
         } else if (raw && wr->started) {
             TRY(fd_writer_push(wr, g_stage.d_b, raw));
         } else if (raw) {
@@ -1360,9 +1458,11 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
     for (;;) {
         TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, avail + 16));
         TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, out_cap));
-        TRY(hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rmem ? (const void *)in_ptr : (const void *)g_stage.h_a, avail));
         uint64_t raw = 0, used = 0;
-        int rc = hufgpu_decode_stream(g_ctx, g_stage.d_a, avail, length, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
+        int rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rmem ? (const void *)in_ptr : (const void *)g_stage.h_a, avail);
+        if (rc == HUF_ERROR_SUCCESS)
+            rc = hufgpu_decode_stream(g_ctx, g_stage.d_a, avail, length, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
+        if (rc == HUF_ERROR_FATAL) return (huf_error_t)rc;
         if (rc == HUF_ERROR_MEMORY_ALLOCATION && out_cap < ((uint64_t)1 << 40)) {   /* output did not fit: enlarge */
             out_cap *= 4;
             continue;
@@ -1400,9 +1500,7 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
         /* bytes of the blocks that decoded completely are delivered even when a later block
          * fails, as the reference's unbuffered writer would have done */
         if (raw && wmem) {
-            TRY(mem_reserve(wmem, raw));
-            TRY(hufgpu_memcpy_d2h(g_ctx, (char *)*wmem->buf + wmem->len, g_stage.d_b, raw));
-            wmem->len += raw;
+            TRY(d2h_to_memstream(wmem, g_stage.d_b, raw));
         } else if (raw) {
             TRY(grow_host(&g_stage.h_b, &g_stage.h_b_cap, raw));
             TRY(hufgpu_memcpy_d2h(g_ctx, g_stage.h_b, g_stage.d_b, raw));

@@ -192,6 +192,11 @@ int huf_gpu_decode_blocks(const struct __huf_encoder_config *config, uint64_t *c
  * hold a context so far; *configured = the length of the list. */
 int huf_gpu_sessions(int *configured);
 
+/* huf_gpu_copy_out: memcpy for a binding that must hand a result over as an object of its own (the
+ * Python layer's `bytes`): `dst` is fresh memory, where a plain memcpy runs at page-fault speed.
+ * Huge-page advice for the destination, then a few threads make their parts present and copy them. */
+int huf_gpu_copy_out(void *dst, const void *src, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,15 @@ def _check(err: int, context: str) -> None:
         raise HuffmanError(f"{N.error_string(err)}. {context}")
 
 
+# a bytes object whose contents are filled in afterwards (the documented use of a NULL source)
+_PyBytes_New = C.pythonapi.PyBytes_FromStringAndSize
+_PyBytes_New.restype = C.py_object
+_PyBytes_New.argtypes = [C.c_void_p, C.c_ssize_t]
+_PyBytes_AsString = C.pythonapi.PyBytes_AsString
+_PyBytes_AsString.restype = C.c_void_p
+_PyBytes_AsString.argtypes = [C.py_object]
+
+
 class _MemStream:
     """A growable huf_memopen() stream; the buffer itself is owned here (huf_memclose only frees
     the stream objects, src/io.c:213-226)."""
@@ -78,7 +87,13 @@ class _MemStream:
 
     def getvalue(self) -> bytes:
         n = len(self)
-        return C.string_at(self._buf.value, n) if n else b""
+        if n < (16 << 20):
+            return C.string_at(self._buf.value, n) if n else b""
+        # a large result: the bytes object is fresh memory, and a plain copy into it runs at
+        # page-fault speed - the library's copy makes the pages present on a few threads first
+        out = _PyBytes_New(None, n)
+        _check(self._lib.huf_gpu_copy_out(_PyBytes_AsString(out), self._buf.value, n), "Failed to copy the result")
+        return out
 
     def rewind(self) -> None:
         _check(self._lib.huf_memrewind(self._rw), "Failed to rewind memory stream")

@@ -372,3 +372,17 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f == "datagen.py", os.path.join(dirpath, f)
+
+
+def test_copy_out_into_a_fresh_bytes_object(L):
+    """huf_gpu_copy_out (the Python layer's way to a `bytes` result without a page-fault-bound copy):
+    exact bytes for sizes below and above its threading threshold, odd alignments included."""
+    import numpy as np
+    from libhuffman_amd import huffmanfile as H
+    rng = np.random.default_rng(7)
+    for n in (0, 1, 4097, (16 << 20) - 1, (16 << 20) + 3, (37 << 20) + 12345):
+        src = rng.integers(0, 256, n + 5, dtype=np.uint8)
+        out = H._PyBytes_New(None, n)
+        assert L.huf_gpu_copy_out(H._PyBytes_AsString(out), src.ctypes.data + 5, n) == 0
+        assert type(out) is bytes and len(out) == n and out == src[5:].tobytes()
+    assert L.huf_gpu_copy_out(None, None, 10) == N.HUF_ERROR_INVALID_ARGUMENT

@@ -246,3 +246,19 @@ def test_decode_blocks_pieces_through_the_c_api():
     bad[8] = 0xff; bad[9] = 0x7f                           # tree_len 32767 in the first header
     with pytest.raises(huffmanfile.HuffmanError):
         d.decompress_blocks(bytes(bad))
+
+
+@gpu
+def test_large_results_take_the_threaded_copy():
+    """results of 16 MiB and more are copied out by huf_gpu_copy_out (a few threads, odd part sizes):
+    every byte, both directions"""
+    for n in ((16 << 20) + 3, (45 << 20) + 12345):
+        data = datagen.zipf255(n).tobytes()
+        comp = huffmanfile.compress(data, blocksize=65536)
+        assert len(comp) > (15 << 20)
+        back = huffmanfile.decompress(comp)
+        assert type(back) is bytes and len(back) == n and back == data
+        # the stream equals the one the small-copy path produces piece by piece
+        c = huffmanfile.HuffmanCompressor(blocksize=65536)
+        parts = [c.compress(data[i:i + (4 << 20)]) for i in range(0, n, 4 << 20)] + [c.flush()]
+        assert b"".join(parts) == comp

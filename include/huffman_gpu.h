@@ -45,9 +45,11 @@ typedef struct hufgpu_ctx hufgpu_ctx_t;
 #define HUFGPU_SEQUENTIAL   2u  /* hufgpu_decode_stream only: skip the parallel block discovery and take the
                                    blocks strictly in order (diagnostics; results are identical) */
 
-/* Largest block the kernels take (bytes): per-block byte counts are 32-bit.  Larger blocks ->
- * HUF_ERROR_INVALID_ARGUMENT. */
-#define HUFGPU_MAX_BLOCK (((uint64_t)1 << 32) - 1)
+/* Largest block the kernels take (bytes).  Larger blocks -> HUF_ERROR_INVALID_ARGUMENT.  (Codes are
+ * kept in 56 bits, which any block below F(57) = 3.6e11 bytes satisfies; the limit is what still
+ * fits a device together with its stream and its output.)  hufgpu_histogram() returns 32-bit counts
+ * and takes blocks below 2^32 bytes only. */
+#define HUFGPU_MAX_BLOCK ((uint64_t)1 << 38)
 
 /* Number of usable gfx950 devices; 0 when HIP is unusable (never an error by itself). */
 int hufgpu_device_count(void);

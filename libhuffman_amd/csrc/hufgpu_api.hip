@@ -294,7 +294,7 @@ static int ensure_encode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipStreamSynchronize(c->stream));
     free_encode_ws(c);
     const uint64_t cap = nblocks + nblocks / 8 + 16;
-    HIP_OK(c, hipMalloc((void **)&c->d_hist, cap * HUF_NSYM * sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_hist, cap * HUF_NSYM * sizeof(uint64_t)));   /* (64-bit counts for chunked blocks) */
     HIP_OK(c, hipMalloc((void **)&c->d_codetab, cap * HUF_NSYM * sizeof(hufcode_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_treebuf, cap * HUF_TREE_STRIDE * sizeof(int16_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_meta, cap * sizeof(HufBlockMeta)));
@@ -419,6 +419,10 @@ extern "C" int hufgpu_histogram(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n,
     if (n == 0) return HUFE_OK;
     int rc = check_block_args(ctx, n, &blocksize);
     if (rc) return rc;
+    if (blocksize > 0xffffffffull) {
+        set_err(ctx, "hufgpu_histogram returns 32-bit counts: blocks of 2^32 bytes and more are not taken");
+        return HUFE_ARGUMENT;
+    }
     HIP_OK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
     const uint64_t nb = hufgpu_block_count(n, blocksize);
@@ -517,9 +521,9 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
         geo.blocksize = blocksize;
         geo.cpb = (uint32_t)cpb;
         chunk_hist_kernel<HIST_THREADS><<<dim3((unsigned)nchunks), dim3(HIST_THREADS), 0, s>>>(in, geo, ctx->d_chunk_hist);
-        block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_hist);
+        block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, (uint64_t *)ctx->d_hist);
         STAGE_MARK(ctx, s);
-        tree_kernel<uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        tree_kernel<uint64_t, uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>((const uint64_t *)ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
         STAGE_MARK(ctx, s);
         scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
         chunk_total_kernel<<<dim3((unsigned)nchunks), dim3(64), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_codetab, ctx->d_chunk_tot);

@@ -41,8 +41,10 @@ struct HufDecodeMeta {
 
 /* A code table entry: (code << 8) | length, code right-aligned, root->leaf, first bit = MSB
  * of the `length`-bit field. length == 0 => symbol absent. Codes are <= 56 bits for any
- * block shorter than 2^32 bytes (Fibonacci depth bound 46 + the wrap-root bit). */
+ * block shorter than F(57) = 3.6e11 bytes (a leaf at depth d needs F(d + 2) symbols; + the
+ * wrap-root bit). */
 typedef uint64_t hufcode_t;
 #define HUF_CODE_MAXBITS 56
+#define HUF_MAX_BLOCK_LEN ((uint64_t)1 << 38)   /* = HUFGPU_MAX_BLOCK (include/huffman_gpu.h) */
 
 #endif

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
                  * reference's reader does at the end of its input (decoder.c:53-56). */
                 const uint64_t pay_bits = (o1 - o0 - HUF_HEADER_FIXED - 2ull * (uint64_t)tl) * 8ull;
                 if (bl > pay_bits) bl = pay_bits + 1;
-                if (bl > 0xffffffffull) m.status = HUFE_ARGUMENT;               /* beyond kernel limits */
+                if (bl > HUF_MAX_BLOCK_LEN) m.status = HUFE_ARGUMENT;            /* beyond kernel limits */
                 else {
                     m.block_len = bl;
                     m.tree_len = tl;
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(THREADS) void decode_chain_kernel(const uint8_t *__
          * stream's first error; only a block that decodes cleanly up to there needs more room */
         const bool capped = want > out_cap - wr;
         if (capped) want = out_cap - wr;
-        if (want > 0xffffffffull) { err = HUFE_ARGUMENT; break; }
+        if (want > HUF_MAX_BLOCK_LEN) { err = HUFE_ARGUMENT; break; }
         uint64_t end_bits = 0, produced = 0;
         if (want) err = decode_block<THREADS>(sh, tree, tl, want, avail - rd, out + wr, &end_bits, &produced);
         if (err != HUFE_OK) { wr += produced; break; }   /* symbols before the failure stay delivered */

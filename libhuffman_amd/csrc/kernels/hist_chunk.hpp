@@ -75,13 +75,12 @@ __global__ __launch_bounds__(THREADS) void chunk_hist_kernel(const uint8_t *__re
     }
 }
 
-/* byte counts of every block = the sums over its chunks (a block is shorter than 2^32 bytes:
- * HUFGPU_MAX_BLOCK, so 32-bit counts hold) */
+/* byte counts of every block = the sums over its chunks (64-bit: a block may be longer than 2^32 bytes) */
 __global__ __launch_bounds__(HUF_NSYM) void block_hist_kernel(const uint32_t *__restrict__ chunk_hist, uint32_t cpb,
-                                                              uint32_t *__restrict__ hist)
+                                                              uint64_t *__restrict__ hist)
 {
     const uint64_t blk = blockIdx.x;
-    uint32_t sum = 0;
+    uint64_t sum = 0;
     for (uint32_t c = 0; c < cpb; c++) sum += chunk_hist[(blk * cpb + c) * HUF_NSYM + threadIdx.x];
     hist[blk * HUF_NSYM + threadIdx.x] = sum;
 }

@@ -25,8 +25,8 @@ namespace hufgpu {
  * node (position of a right child = parent + 1 + entries of the left subtree, a subtree with
  * L leaves holding 4L-1 entries), which gives codes and the serialized tree without recursion.
  * ==================================================================================== */
-template <typename K>
-__global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ hist, uint64_t n,
+template <typename K, typename H = uint32_t>
+__global__ __launch_bounds__(64) void tree_kernel(const H *__restrict__ hist, uint64_t n,
                                                   uint64_t blocksize, hufcode_t *__restrict__ codetab,
                                                   int16_t *__restrict__ treebuf,
                                                   HufBlockMeta *__restrict__ meta)
@@ -42,10 +42,10 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint32_t *__restrict__ h
     const K KMAX = ~(K)0;
     const int lane = lane_id();
     const uint64_t blk = blockIdx.x;
-    const uint32_t *h = hist + blk * HUF_NSYM;
+    const H *h = hist + blk * HUF_NSYM;
 
     K key[8];
-    uint32_t rate[4];
+    H rate[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int slot = lane + 64 * j;

@@ -207,8 +207,7 @@ def test_concurrent_calls_take_different_sessions(torch_mod, devices, threads, w
 
 
 def test_one_block_of_3_5_gib(torch_mod, codec):
-    """A block just below the kernels' limit (2^32 - 1 bytes, include/huffman_gpu.h) - blocksize = 0 on a
-    multi-GiB input.  The oracle cannot encode that in test time; parity comes from two properties:
+    """A block just below 2^32 bytes (where 32-bit symbol counts end) - blocksize = 0 on a multi-GiB input.  The oracle cannot encode that in test time; parity comes from two properties:
     (1) counts scaled by a common factor give the same tree (every comparison of src/tree.c:292-427
     scales with them), so the tree of P repeated 8 m times is the tree of P repeated 8 times;
     (2) the payload of 8 copies of P is a whole number of bytes, so the payload of 8 m copies is
@@ -245,9 +244,6 @@ def test_one_block_of_3_5_gib(torch_mod, codec):
     assert res == (0, n, length) and torch.equal(out, data)
     print(f"\n  raw stream, one block of {n / 2**30:.2f} GiB: {ms:.1f} ms")
     assert ms < 200.0
-    # one byte more than the limit is an argument error, not a wrong stream
-    with pytest.raises(Exception):
-        codec.encode(torch.zeros(1 << 32, dtype=torch.uint8, device="cuda"), 0)
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -291,3 +287,56 @@ def test_fuzz_big_blocks_against_the_in_order_decoder(torch_mod, codec, seed):
             b = codec.decode_stream(bad, avail, avail, ref.zero_(), relaxed=True, sequential=True)
             assert a == b, (seed, case, trial, kind, k, skew, bs, a, b)
             assert torch.equal(out[:a[1]], ref[:a[1]]), (seed, case, trial, kind)
+
+
+def test_blocks_beyond_4_gib(torch_mod, codec):
+    """Blocks of 2^32 bytes and more (the reference's block_len is a uint64_t, src/encoder.c:338-341): a
+    4.5 GiB block of Zipf bytes - parity through the two properties of test_one_block_of_3_5_gib - and a
+    4.25 GiB block of one byte value, whose count does not fit 32 bits.  With the encoder's sub-index, as
+    a raw stream (sub-index built on the device), and cut short (the in-order decoder takes over)."""
+    torch = torch_mod
+    from oracle.oracle import Oracle
+    p_len, m = 16 << 20, 36                                   # 8 * 36 * 16 MiB = 4.5 GiB
+    P = datagen.zipf255(p_len)
+    want = Oracle().encode(np.tile(P, 8), 0)
+    tl = int.from_bytes(want[8:10].tobytes(), "little", signed=True)
+    hdr = 10 + 2 * tl
+    period = want.size - hdr
+    data = dev(torch, P).repeat(8 * m)
+    n = data.numel()
+    assert n == 8 * m * p_len and n > (1 << 32)
+    sub = codec.new_sub_index(n, 0)
+    stream, offs, length = codec.encode(data, 0, sub_index=sub)
+    assert offs.numel() == 2 and length == hdr + m * period
+    head = stream[:hdr].cpu().numpy()
+    assert int.from_bytes(head[:8].tobytes(), "little") == n
+    assert np.array_equal(head[8:], want[8:hdr]), "tree differs from the oracle's tree of the same proportions"
+    assert torch.equal(stream[hdr:hdr + period], dev(torch, want[hdr:])), "first period differs from the oracle's payload"
+    assert torch.equal(stream[hdr:length - period], stream[hdr + period:length]), "payload is not periodic"
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(stream, length, offs, 1, out, sub_index=sub, raw_size=n, blocksize=0) == n
+    assert torch.equal(out, data)
+    res = codec.decode_stream(stream, length, length, out.zero_())
+    assert res == (0, n, length) and torch.equal(out, data)
+    # cut short by a few bytes: no parallel path applies, the in-order decoder delivers what is there
+    t0 = time.perf_counter()
+    err, raw, used = codec.decode_stream(stream, length - 100, length - 100, out.zero_())
+    torch.cuda.synchronize()
+    print(f"\n  a 4.5 GiB block cut short, in-order decoder: {time.perf_counter() - t0:.1f} s, err {err}, {raw} bytes")
+    assert err == 3 and n - 200 <= raw < n and torch.equal(out[:raw], data[:raw])
+    del out, sub, stream, data
+    torch.cuda.empty_cache()
+
+    n1 = (1 << 32) + (1 << 28) + 5                            # 4.25 GiB of one byte value
+    ones = torch.full((n1,), 0x37, dtype=torch.uint8, device="cuda")
+    stream, offs, length = codec.encode(ones, 0)
+    assert length == 10 + 10 + (n1 + 7) // 8
+    hb = stream[:20].cpu().numpy()
+    assert int.from_bytes(hb[:8].tobytes(), "little") == n1 and int.from_bytes(hb[8:10].tobytes(), "little") == 5
+    assert int(stream[20:length].max().item()) == 0
+    back = torch.zeros(n1, dtype=torch.uint8, device="cuda")
+    res = codec.decode_stream(stream, length, length, back)
+    assert res == (0, n1, length) and torch.equal(back, ones)
+    # one byte more than the limit is an argument error, not a wrong stream
+    with pytest.raises(Exception):
+        codec.encode(torch.zeros(16, dtype=torch.uint8, device="cuda"), (1 << 38) + 1)

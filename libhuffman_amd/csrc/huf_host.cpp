@@ -27,6 +27,8 @@
 #include <string.h>
 #include <unistd.h>
 #include <sched.h>
+
+#include <atomic>
 #include <sys/mman.h>
 
 #include <hip/hip_runtime_api.h>
@@ -780,6 +782,28 @@ static void session_leave(void)
     pthread_mutex_unlock(&g_pool_lock);
 }
 
+/* a second, third ... session for the calling call, if one is free right now (never waits) */
+static session_t *session_try_extra(void)
+{
+    session_t *got = NULL;
+    pthread_mutex_lock(&g_pool_lock);
+    for (int i = 0; i < g_nsessions && !got; i++)
+        if (!g_sessions[i].busy) {
+            g_sessions[i].busy = 1;
+            got = &g_sessions[i];
+        }
+    pthread_mutex_unlock(&g_pool_lock);
+    return got;
+}
+
+static void session_release_extra(session_t *s)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    s->busy = 0;
+    pthread_cond_signal(&g_pool_cv);
+    pthread_mutex_unlock(&g_pool_lock);
+}
+
 static huf_error_t session_acquire(void)
 {
     if (g_ctx) return HUF_ERROR_SUCCESS;
@@ -1189,6 +1213,178 @@ static huf_error_t encode_rounds(huf_encoder_t *enc, uint64_t batch, membuf_t *r
     return HUF_ERROR_SUCCESS;
 }
 
+/* One huf_encode() over several sessions (HUF_GPU_DEVICES lists more than one and some are free):
+ * memory stream -> memory stream only.  The input is cut into rounds of whole blocks - blocks are
+ * independent (src/encoder.c:288-374, reset :360-373), so the stream is the rounds' streams one after
+ * the other, byte for byte what one session writes.  Every session runs on a thread of its own:
+ * input round to its device, encode, and - once the sizes of all earlier rounds are known - the
+ * result to its place in the output.  With sessions on different GPUs the rounds travel over
+ * different host links; with two sessions on ONE GPU a round's copy back runs beside the next
+ * round's copy in (full duplex).  The output's pages are made present before the first copy (a
+ * populate beside running copies fights them for the address-space lock, see d2h_to_memstream). */
+typedef struct {
+    const char *src;
+    char *dst;
+    uint64_t length, blocksize, round_bytes, nrounds;
+    std::atomic<uint64_t> next;
+    uint64_t *out_len;              /* per round, valid once known[k] */
+    unsigned char *known;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int err;
+} fanout_t;
+
+typedef struct { fanout_t *f; session_t *session; } fanout_worker_t;
+
+#define HUF_MAX_LINKS 64
+static pthread_mutex_t g_link_lock[HUF_MAX_LINKS][2];               /* per device: [0] host -> device, [1] device -> host */
+static pthread_once_t g_link_once = PTHREAD_ONCE_INIT;
+static void link_locks_init(void)
+{
+    for (int i = 0; i < HUF_MAX_LINKS; i++) {
+        pthread_mutex_init(&g_link_lock[i][0], NULL);
+        pthread_mutex_init(&g_link_lock[i][1], NULL);
+    }
+}
+
+static void fanout_fail(fanout_t *f, int err)
+{
+    pthread_mutex_lock(&f->mu);
+    if (f->err == HUF_ERROR_SUCCESS) f->err = err;
+    pthread_cond_broadcast(&f->cv);
+    pthread_mutex_unlock(&f->mu);
+}
+
+static void *fanout_main(void *arg)
+{
+    fanout_worker_t *w = (fanout_worker_t *)arg;
+    fanout_t *f = w->f;
+    t_session = w->session;                                          /* this thread's g_ctx / g_stage */
+    int rc = session_acquire();
+    const uint64_t bound = hufgpu_encode_bound(f->round_bytes, f->blocksize);
+    if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_a, &g_stage.d_a_cap, f->round_bytes);
+    if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound);
+    while (rc == HUF_ERROR_SUCCESS) {
+        if (*(volatile int *)&f->err != HUF_ERROR_SUCCESS) break;        /* another session failed */
+        const uint64_t k = f->next.fetch_add(1);
+        if (k >= f->nrounds) break;
+        const uint64_t off = k * f->round_bytes;
+        const uint64_t take = (f->length - off < f->round_bytes) ? f->length - off : f->round_bytes;
+        uint64_t out_len = 0;
+        /* sessions on one device take turns per direction: while one copies a result back the next
+         * copies its input in (both at once in the SAME direction only share the link, and all
+         * sessions would move through their phases in step) */
+        pthread_mutex_t *dir = g_link_lock[(unsigned)w->session->device % HUF_MAX_LINKS];
+        pthread_mutex_lock(&dir[0]);
+        rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, f->src + off, take);
+        pthread_mutex_unlock(&dir[0]);
+        if (rc == HUF_ERROR_SUCCESS)
+            rc = hufgpu_encode(g_ctx, g_stage.d_a, take, f->blocksize, g_stage.d_b, g_stage.d_b_cap, NULL, &out_len, NULL);
+        if (rc != HUF_ERROR_SUCCESS) break;
+        /* publish this round's size, then wait for the sizes of all rounds in front of it */
+        uint64_t before = 0;
+        pthread_mutex_lock(&f->mu);
+        f->out_len[k] = out_len;
+        f->known[k] = 1;
+        pthread_cond_broadcast(&f->cv);
+        for (;;) {
+            if (f->err != HUF_ERROR_SUCCESS) break;
+            uint64_t j = 0;
+            before = 0;
+            while (j < k && f->known[j]) before += f->out_len[j++];
+            if (j == k) break;
+            pthread_cond_wait(&f->cv, &f->mu);
+        }
+        const int stop = f->err != HUF_ERROR_SUCCESS;
+        pthread_mutex_unlock(&f->mu);
+        if (stop) break;
+        pthread_mutex_lock(&dir[1]);
+        rc = hufgpu_memcpy_d2h(g_ctx, f->dst + before, g_stage.d_b, out_len);
+        pthread_mutex_unlock(&dir[1]);
+    }
+    if (rc != HUF_ERROR_SUCCESS) fanout_fail(f, rc);
+    t_session = NULL;
+    return NULL;
+}
+
+/* returns 1 when the call was done here (*result = its outcome), 0 when the ordinary path should run */
+static int encode_fanout(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf_error_t *result)
+{
+    const uint64_t length = enc->config->length, blocksize = enc->config->blocksize;
+    if (!rmem || !wmem || wmem->readonly || g_nsessions < 2) return 0;
+    if (rmem->len - rmem->off < length) return 0;                     /* a short input: the ordinary path reports it */
+    const char *env = getenv("HUF_GPU_BATCH_MB");
+    uint64_t round_bytes = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : 32) << 20;
+    if (round_bytes < blocksize) round_bytes = blocksize;
+    round_bytes -= round_bytes % blocksize;
+    const uint64_t nrounds = (length + round_bytes - 1) / round_bytes;
+    if (nrounds < 2) return 0;
+
+    session_t *mine = t_session;
+    session_t *extra[HUF_MAX_SESSIONS];
+    int nextra = 0;
+    while ((uint64_t)nextra + 1 < nrounds && nextra < HUF_MAX_SESSIONS - 1) {
+        session_t *s = session_try_extra();
+        if (!s) break;
+        extra[nextra++] = s;
+    }
+    if (nextra == 0) return 0;                                        /* every other session is busy: one after the other */
+    pthread_once(&g_link_once, link_locks_init);
+
+    uint64_t bound = 0;
+    for (uint64_t k = 0; k < nrounds; k++) {
+        const uint64_t off = k * round_bytes;
+        bound += hufgpu_encode_bound(length - off < round_bytes ? length - off : round_bytes, blocksize);
+    }
+    fanout_t f;
+    f.src = (const char *)*rmem->buf + rmem->off;
+    f.length = length;
+    f.blocksize = blocksize;
+    f.round_bytes = round_bytes;
+    f.nrounds = nrounds;
+    f.next.store(0);
+    f.err = HUF_ERROR_SUCCESS;
+    f.out_len = (uint64_t *)calloc(nrounds, sizeof(uint64_t));
+    f.known = (unsigned char *)calloc(nrounds, 1);
+    huf_error_t err = (f.out_len && f.known) ? mem_reserve(wmem, bound) : HUF_ERROR_MEMORY_ALLOCATION;
+    if (err == HUF_ERROR_SUCCESS) {
+        f.dst = (char *)*wmem->buf + wmem->len;
+        prefault_job_t job;                                           /* about as many bytes as the stream will have */
+        prefault_begin(&job, f.dst, (size_t)(length < bound ? length : bound), 1);
+        prefault_end(&job);
+        pthread_mutex_init(&f.mu, NULL);
+        pthread_cond_init(&f.cv, NULL);
+        fanout_worker_t workers[HUF_MAX_SESSIONS];
+        pthread_t th[HUF_MAX_SESSIONS];
+        int started = 0;
+        for (int i = 0; i < nextra; i++) {
+            workers[i + 1].f = &f;
+            workers[i + 1].session = extra[i];
+            if (pthread_create(&th[i], NULL, fanout_main, &workers[i + 1]) != 0) break;
+            started++;
+        }
+        workers[0].f = &f;
+        workers[0].session = mine;
+        fanout_main(&workers[0]);                                     /* this thread works with the call's own session */
+        t_session = mine;
+        for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+        pthread_mutex_destroy(&f.mu);
+        pthread_cond_destroy(&f.cv);
+        err = (huf_error_t)f.err;
+        if (err == HUF_ERROR_SUCCESS) {
+            uint64_t total = 0;
+            for (uint64_t k = 0; k < nrounds; k++) total += f.out_len[k];
+            wmem->len += total;
+            rmem->off += length;
+        }
+    }
+    for (int i = 0; i < nextra; i++) session_release_extra(extra[i]);
+    free(f.out_len);
+    free(f.known);
+    *result = err;
+    return 1;
+}
+
 static huf_error_t encode_locked(huf_encoder_t *enc)
 {
     const uint64_t length = enc->config->length;
@@ -1204,6 +1400,11 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
     membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(enc->config->writer) : NULL;
     const int rfd = (rmem || !zero_copy_enabled()) ? -1 : own_fd_of(enc->config->reader, 0);
     const int wfd = (wmem || !zero_copy_enabled()) ? -1 : own_fd_of(enc->config->writer, 1);
+    {
+        huf_error_t fan = HUF_ERROR_SUCCESS;
+        if (encode_fanout(enc, rmem, wmem, &fan))
+            return fan != HUF_ERROR_SUCCESS ? fan : huf_bufio_read_writer_flush(enc->bufio_writer);
+    }
 
     /* bytes per round: whole blocks; smaller rounds when descriptor I/O runs next to the GPU
      * (the first read and the last write are not hidden) */

@@ -16,7 +16,8 @@ L = N.load()
 libc = C.CDLL(None)
 libc.free.argtypes = [C.c_void_p]
 NTHREADS = int(sys.argv[2])
-n, bs = (24 << 20) + 17, 65536
+n = ((int(sys.argv[3]) if len(sys.argv) > 3 else 24) << 20) + 17
+bs = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 inputs = [np.roll(datagen.zipf255(n), 1000 * i) for i in range(NTHREADS)]
 oracle = Oracle()
 want = [oracle.encode(x, bs) for x in inputs]

@@ -340,3 +340,22 @@ def test_blocks_beyond_4_gib(torch_mod, codec):
     # one byte more than the limit is an argument error, not a wrong stream
     with pytest.raises(Exception):
         codec.encode(torch.zeros(16, dtype=torch.uint8, device="cuda"), (1 << 38) + 1)
+
+
+@pytest.mark.parametrize("bs", [65536, (1 << 20) + 7])
+def test_one_call_fans_out_over_free_sessions(torch_mod, bs):
+    """With several sessions configured and free, ONE huf_encode() of a memory stream cuts its input
+    into rounds of whole blocks and gives them to the sessions (threads of their own); the stream is
+    byte for byte the oracle's.  Three sessions on the one GPU here; rounds of 16 MiB."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HUF_GPU_DEVICES"] = "0,0,0"
+    env["HUF_GPU_BATCH_MB"] = "16"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sessions_child.py"), root, "1", "150", str(bs)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    print("\n  " + r.stdout.strip().replace("\n", "\n  "))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sessions live=3 configured=3" in r.stdout, r.stdout

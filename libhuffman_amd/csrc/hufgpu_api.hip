@@ -720,9 +720,11 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
         const uint64_t pay_bytes = avail - pay_off;
 
         const uint64_t sub_bytes = hufgpu_sub_index_bytes(block_len, block_len);
+        /* (workspace that cannot be had - a block of many GiB needs a quarter of its size - is no
+         * error: the general path takes the block) */
         if (sub_bytes > ctx->big_sub_bytes) {
             free_big_ws(ctx, 4);
-            HIP_OK(ctx, hipMalloc(&ctx->d_big_sub, sub_bytes));
+            if (hipMalloc(&ctx->d_big_sub, sub_bytes) != hipSuccess) { (void)hipGetLastError(); ctx->d_big_sub = NULL; break; }
             ctx->big_sub_bytes = sub_bytes;
         }
         const HufSubIndex sub = sub_index_view(ctx->d_big_sub, block_len, block_len);
@@ -744,15 +746,23 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
             if (nlanes > ctx->big_lanes) {
                 free_big_ws(ctx, 1);
                 const uint64_t cap = nlanes + nlanes / 8 + 16;
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_entry, cap * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_exit, cap * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_pre, (cap + 1) * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_cnt, cap * sizeof(uint32_t)));
+                if (hipMalloc((void **)&ctx->d_big_entry, cap * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_exit, cap * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_pre, (cap + 1) * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_cnt, cap * sizeof(uint32_t)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    free_big_ws(ctx, 1);
+                    break;
+                }
                 ctx->big_lanes = cap;
             }
             if (ngroups > ctx->big_groups) {
                 free_big_ws(ctx, 2);
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_big_gstart, (ngroups + 1) * sizeof(uint64_t)));
+                if (hipMalloc((void **)&ctx->d_big_gstart, (ngroups + 1) * sizeof(uint64_t)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->d_big_gstart = NULL;
+                    break;
+                }
                 ctx->big_groups = ngroups;
             }
             SpecJob j;

@@ -386,3 +386,27 @@ def test_copy_out_into_a_fresh_bytes_object(L):
         assert L.huf_gpu_copy_out(H._PyBytes_AsString(out), src.ctypes.data + 5, n) == 0
         assert type(out) is bytes and len(out) == n and out == src[5:].tobytes()
     assert L.huf_gpu_copy_out(None, None, 10) == N.HUF_ERROR_INVALID_ARGUMENT
+
+
+def test_session_pool_follows_the_device_list():
+    """HUF_GPU_DEVICES is read once per process, without touching a GPU: one session per listed device
+    (a device may be listed twice); unset, empty or "all" on a box without devices = one session."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from libhuffman_amd import _native as N; L = N.load(); "
+            "c = C.c_int(0); live = L.huf_gpu_sessions(C.byref(c)); print(live, c.value)" % root)
+    for value, want in ((None, 1), ("", 1), ("3,1,1", 3), ("0, 2 ,5,7", 4), ("junk", 1), ("all", None)):
+        env = dict(os.environ)
+        env.pop("HUF_GPU_DEVICES", None)
+        if value is not None:
+            env["HUF_GPU_DEVICES"] = value
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        live, configured = (int(x) for x in r.stdout.split())
+        assert live == 0                                    # no call was made: no context exists
+        if want is None:                                    # "all": the visible devices, at least the fallback
+            assert configured >= 1
+        else:
+            assert configured == want, (value, configured)

@@ -17,7 +17,7 @@ mkdir -p $OUT
 cd /tmp
 COMMON="--secondary none --no-cpu-baseline --no-other-decode"
 for WL in $WLS; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -o run -- python3 $ROOT/bench.py --steps 5 --warmup 2 --workload $WL $COMMON > $OUT/${TAG}_${WL}_bench.json 2> $OUT/kt_$WL.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -o run -- python3 $ROOT/bench.py --steps 20 --warmup 5 --workload $WL $COMMON > $OUT/${TAG}_${WL}_bench.json 2> $OUT/kt_$WL.err
   cp $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${WL}_kernel_stats.csv
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rd_$WL -o rd -- python3 $ROOT/bench.py --steps 3 --warmup 1 --workload $WL $COMMON --no-verify > $OUT/rd_$WL.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wr_$WL -o wr -- python3 $ROOT/bench.py --steps 3 --warmup 1 --workload $WL $COMMON --no-verify > $OUT/wr_$WL.log 2>&1

@@ -70,8 +70,8 @@ struct hufgpu_ctx {
     uint64_t *d_spec_off;         /* speculative output offsets of the candidates (disc_cands + 1) */
 
     /* blocks of many MiB in a raw stream: the sub-index built for them (kernels/spec_index.hpp) */
-    uint64_t big_lanes, big_groups, big_sub_bytes;
-    uint64_t *d_big_entry, *d_big_exit, *d_big_pre, *d_big_gstart;
+    uint64_t big_lanes, big_sub_bytes;
+    uint64_t *d_big_entry, *d_big_exit, *d_big_pre, *d_big_wgpre, *d_big_wgscratch, *d_big_first_pos, *d_big_first_g, *d_big_last_pos;
     uint32_t *d_big_cnt;
     void *d_big_sub;
     uint64_t *d_big_offs;         /* SPEC_WORDS status words, then the two-entry block index */
@@ -222,9 +222,11 @@ static void free_big_ws(hufgpu_ctx *c, int which)
 {
     if (which & 1) {
         (void)hipFree(c->d_big_entry); (void)hipFree(c->d_big_exit); (void)hipFree(c->d_big_pre); (void)hipFree(c->d_big_cnt);
-        c->d_big_entry = c->d_big_exit = c->d_big_pre = NULL; c->d_big_cnt = NULL; c->big_lanes = 0;
+        (void)hipFree(c->d_big_wgpre); (void)hipFree(c->d_big_wgscratch);
+        (void)hipFree(c->d_big_first_pos); (void)hipFree(c->d_big_first_g); (void)hipFree(c->d_big_last_pos);
+        c->d_big_entry = c->d_big_exit = c->d_big_pre = c->d_big_wgpre = c->d_big_wgscratch = NULL; c->d_big_cnt = NULL; c->big_lanes = 0;
+        c->d_big_first_pos = c->d_big_first_g = c->d_big_last_pos = NULL;
     }
-    if (which & 2) { (void)hipFree(c->d_big_gstart); c->d_big_gstart = NULL; c->big_groups = 0; }
     if (which & 4) { (void)hipFree(c->d_big_sub); c->d_big_sub = NULL; c->big_sub_bytes = 0; }
     if (which & 8) { (void)hipFree(c->d_big_offs); c->d_big_offs = NULL; }
 }
@@ -741,7 +743,6 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
             uint64_t max_bits = pay_bytes * 8;
             if (max_bits > 9 * block_len + 64) max_bits = 9 * block_len + 64;
             const uint64_t nlanes = (max_bits + SPEC_LANE_BITS - 1) / SPEC_LANE_BITS;
-            const uint64_t ngroups = (block_len + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
             if (nlanes == 0) break;
             if (nlanes > ctx->big_lanes) {
                 free_big_ws(ctx, 1);
@@ -749,21 +750,17 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
                 if (hipMalloc((void **)&ctx->d_big_entry, cap * sizeof(uint64_t)) != hipSuccess ||
                     hipMalloc((void **)&ctx->d_big_exit, cap * sizeof(uint64_t)) != hipSuccess ||
                     hipMalloc((void **)&ctx->d_big_pre, (cap + 1) * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_wgpre, (cap / DEC_THREADS + 4) * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_wgscratch, (cap / DEC_THREADS + 4) * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_first_pos, cap * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_first_g, cap * sizeof(uint64_t)) != hipSuccess ||
+                    hipMalloc((void **)&ctx->d_big_last_pos, cap * sizeof(uint64_t)) != hipSuccess ||
                     hipMalloc((void **)&ctx->d_big_cnt, cap * sizeof(uint32_t)) != hipSuccess) {
                     (void)hipGetLastError();
                     free_big_ws(ctx, 1);
                     break;
                 }
                 ctx->big_lanes = cap;
-            }
-            if (ngroups > ctx->big_groups) {
-                free_big_ws(ctx, 2);
-                if (hipMalloc((void **)&ctx->d_big_gstart, (ngroups + 1) * sizeof(uint64_t)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    ctx->d_big_gstart = NULL;
-                    break;
-                }
-                ctx->big_groups = ngroups;
             }
             SpecJob j;
             j.tree = st + pos + HUF_HEADER_FIXED;
@@ -777,13 +774,16 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
             j.exitp = ctx->d_big_exit;
             j.cnt = ctx->d_big_cnt;
             j.pre = ctx->d_big_pre;
-            j.gstart = ctx->d_big_gstart;
+            j.wg_pre = ctx->d_big_wgpre;
+            j.first_pos = ctx->d_big_first_pos;
+            j.first_g = ctx->d_big_first_g;
+            j.last_pos = ctx->d_big_last_pos;
             j.status = d_status;
             const unsigned lane_wgs = (unsigned)((nlanes + DEC_THREADS - 1) / DEC_THREADS);
             spec_scan_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
-            spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j);
-            spec_mark_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
-            spec_groups_kernel<<<dim3((unsigned)((sub.gpb + 255) / 256)), dim3(256), 0, s>>>(j, sub, pos, pay_off, d_offs);
+            spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j, (uint64_t)lane_wgs, ctx->d_big_wgscratch);
+            spec_mark_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j, sub);
+            spec_groups_kernel<<<dim3((unsigned)((nlanes + 8 + 255) / 256)), dim3(256), 0, s>>>(j, sub, pos, pay_off, d_offs);
             HIP_OK(ctx, hipGetLastError());
             HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, d_status, SPEC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             HIP_OK(ctx, hipStreamSynchronize(s));

@@ -179,7 +179,7 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 8 * sizeof(uint64_t)));
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 8 * sizeof(uint64_t)));
-    HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 16 * sizeof(uint64_t), hipHostMallocDefault));
 
     /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
     uint64_t cum[255], acc = 0;
@@ -781,18 +781,55 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
             j.status = d_status;
             const unsigned lane_wgs = (unsigned)((nlanes + DEC_THREADS - 1) / DEC_THREADS);
             spec_scan_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
-            spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j, (uint64_t)lane_wgs, ctx->d_big_wgscratch);
-            spec_mark_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j, sub);
-            spec_groups_kernel<<<dim3((unsigned)((nlanes + 8 + 255) / 256)), dim3(256), 0, s>>>(j, sub, pos, pay_off, d_offs);
-            HIP_OK(ctx, hipGetLastError());
-            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, d_status, SPEC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIP_OK(ctx, hipStreamSynchronize(s));
+            bool chain_ok = false;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j, (uint64_t)lane_wgs, ctx->d_big_wgscratch);
+                spec_mark_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j, sub);
+                spec_groups_kernel<<<dim3((unsigned)((nlanes + 8 + 255) / 256)), dim3(256), 0, s>>>(j, sub, pos, pay_off, d_offs);
+                HIP_OK(ctx, hipGetLastError());
+                HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, d_status, SPEC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                HIP_OK(ctx, hipStreamSynchronize(s));
+                if (getenv("HUF_GPU_TRACE"))
+                    fprintf(stderr, "big block at %llu: attempt %d chain %llu fail %llu found %llu end_bits %llu lanes %llu\n", (unsigned long long)pos, attempt,
+                            (unsigned long long)ctx->h_result[SPEC_CHAIN], (unsigned long long)ctx->h_result[SPEC_FAIL],
+                            (unsigned long long)ctx->h_result[SPEC_FOUND], (unsigned long long)ctx->h_result[SPEC_END_BITS], (unsigned long long)nlanes);
+                if (!ctx->h_result[SPEC_CHAIN] || ctx->h_result[SPEC_FAIL] || attempt == 1) {
+                    chain_ok = !ctx->h_result[SPEC_CHAIN] && !ctx->h_result[SPEC_SHORT];
+                    break;
+                }
+                /* some share did not fall into step before its first bit (a run of one byte value is
+                 * a periodic bit string: a decoder can lock onto it one bit off): mend the chain, one
+                 * share further per round, then sum and mark again.  A run of more than
+                 * SPEC_REPAIR_ROUNDS shares (512 KiB of payload) is left to the general path. */
+                bool mended = false;
+                for (int round = 0; round < SPEC_REPAIR_ROUNDS && !mended; round += SPEC_REPAIR_BATCH) {
+                    HIP_OK(ctx, hipMemsetAsync(d_status + SPEC_REPAIRED, 0, sizeof(uint64_t), s));
+                    for (int k = 0; k < SPEC_REPAIR_BATCH; k++)      /* (a round that finds nothing to mend costs a few microseconds) */
+                        spec_repair_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
+                    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result + SPEC_REPAIRED, d_status + SPEC_REPAIRED, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                    HIP_OK(ctx, hipStreamSynchronize(s));
+                    mended = ctx->h_result[SPEC_REPAIRED] == 0;
+                    if (getenv("HUF_GPU_TRACE")) fprintf(stderr, "  repair rounds %d..: %llu shares\n", round, (unsigned long long)ctx->h_result[SPEC_REPAIRED]);
+                }
+                if (!mended) break;
+                HIP_OK(ctx, hipMemsetAsync(d_status + SPEC_CHAIN, 0, sizeof(uint64_t), s));
+                HIP_OK(ctx, hipMemsetAsync(d_status + SPEC_SHORT, 0, sizeof(uint64_t), s));
+                HIP_OK(ctx, hipMemsetAsync(d_status + SPEC_FOUND, 0, sizeof(uint64_t), s));
+                spec_sum_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
+            }
+            if (!chain_ok) break;
             if (ctx->h_result[SPEC_FAIL] || !ctx->h_result[SPEC_FOUND]) break;
             o1 = pay_off + ((ctx->h_result[SPEC_END_BITS] + 7) >> 3);
             if (o1 > avail) break;
         }
         uint64_t got = 0;
         const int err = decode_impl(ctx, st, o1, d_offs, 1, &sub, block_len, out + rawpos, out_cap - rawpos, flags, &got, stream);
+        if (getenv("HUF_GPU_TRACE")) {
+            uint32_t nfix = 0;
+            (void)hipMemcpy(&nfix, ctx->d_fix_count, sizeof(nfix), hipMemcpyDeviceToHost);
+            fprintf(stderr, "big block at %llu: decode err %d, %llu bytes, blocks decoded again without the sub-index: %u\n", (unsigned long long)pos, err,
+                    (unsigned long long)got, nfix);
+        }
         if (err != HUFE_OK || got != block_len) break;   /* the general path decodes it again and says what is wrong */
         pos = o1;
         rawpos += block_len;

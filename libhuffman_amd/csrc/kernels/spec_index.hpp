@@ -26,10 +26,12 @@ namespace hufgpu {
 
 #define SPEC_LANE_BITS 4096u
 #define SPEC_OVERLAP   512u
+#define SPEC_REPAIR_ROUNDS 1024    /* launches spent on mending a broken chain before the general path takes the block ... */
+#define SPEC_REPAIR_BATCH  16      /* ... checked by the host once per this many */
 
 /* status words of one attempt */
 enum { SPEC_FAIL = 0, SPEC_END_BITS = 1, SPEC_FOUND = 2, SPEC_BLOCK_LEN = 3, SPEC_TREE_LEN = 4, SPEC_LEAF = 5, SPEC_END_LANE = 6, SPEC_END_OPEN = 7,
-       SPEC_WORDS = 8 };
+       SPEC_CHAIN = 8, SPEC_REPAIRED = 9, SPEC_SHORT = 10, SPEC_WORDS = 11 };
 
 struct SpecJob {
     const uint8_t *tree;       /* the block's serialized tree */
@@ -212,6 +214,61 @@ __global__ __launch_bounds__(THREADS) void spec_scan_kernel(SpecJob j)
     if (threadIdx.x == 0) j.wg_pre[blockIdx.x] = total;
 }
 
+/* A share whose run-in did not reach a codeword boundary - it lies in a stretch where the payload
+ * looks the same one bit on (a long run of one short code: zeros in a sparse file) - begins where its
+ * left neighbour ended instead: one round mends every share whose neighbour was right, so a stretch
+ * of n such shares takes n rounds (each a launch that touches only the broken shares).  The host
+ * repeats it until nothing changes; then spec_sum_kernel redoes the sums. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spec_repair_kernel(SpecJob j)
+{
+    __shared__ DecShared<THREADS> sh;
+    __shared__ int s_any;
+    const uint64_t lane = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    uint64_t from = 0;
+    bool need = false;
+    if (lane > 0 && lane < j.nlanes) {
+        from = j.exitp[lane - 1];
+        need = j.entry[lane] != from;
+    }
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if (need) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;
+    int leaf;
+    const int rc = dec_build_tables<THREADS, false>(sh, j.tree, j.tree_len, &leaf);
+    if (rc != HUFE_OK || leaf >= 0) return;
+    __syncthreads();
+    if (!need) return;
+    const uint64_t hi = dmin<uint64_t>((lane + 1) * SPEC_LANE_BITS, j.max_bits);
+    ColStage st = spec_stage_of<THREADS>(sh, j);
+    uint64_t pos = from;
+    uint32_t c = 0;
+    while (pos < hi) {
+        st.stage(pos >> 5);
+        while (pos < hi && st.covers(pos))
+            if (spec_step<THREADS>(sh, st, pos)) c++;
+    }
+    j.entry[lane] = from;
+    j.exitp[lane] = pos;
+    j.cnt[lane] = c;
+    atomicAdd(&j.status[SPEC_REPAIRED], 1ull);
+}
+
+/* the sums of spec_scan_kernel's tail again, after a repair */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spec_sum_kernel(SpecJob j)
+{
+    __shared__ uint32_t s_part[THREADS / 64];
+    const uint64_t lane = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t c = lane < j.nlanes ? j.cnt[lane] : 0u;
+    uint32_t total;
+    const uint32_t before = block_excl_scan_u32<THREADS>(c, s_part, total);
+    if (lane < j.nlanes) j.pre[lane] = before;
+    if (threadIdx.x == 0) j.wg_pre[blockIdx.x] = total;
+}
+
 /* symbols before every workgroup's shares (in place: counts in, exclusive sums out, the total last) */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void spec_prefix_kernel(SpecJob j, uint64_t nwg, uint64_t *__restrict__ scratch)
@@ -239,11 +296,12 @@ __global__ __launch_bounds__(THREADS) void spec_mark_kernel(SpecJob j, HufSubInd
     uint64_t pos = j.entry[lane];
     /* the chain: this lane begins where the one before it ended (lane 0 begins at bit 0) */
     if (lane > 0 ? (j.exitp[lane - 1] != pos) : (pos != 0)) {
-        j.status[SPEC_FAIL] = 1;
+        j.status[SPEC_CHAIN] = 1;                         /* (spec_repair_kernel can mend this) */
         return;
     }
     if (lane + 1 == j.nlanes && s + j.cnt[lane] < j.block_len) {
-        j.status[SPEC_FAIL] = 1;                          /* the block does not end inside the covered bits */
+        j.status[SPEC_SHORT] = 1;                         /* the block does not end inside the covered bits (or the counts
+                                                             are those of a broken chain) */
         return;
     }
     const uint64_t stop = j.exitp[lane];
@@ -305,7 +363,7 @@ __global__ __launch_bounds__(256) void spec_groups_kernel(SpecJob j, HufSubIndex
     const uint64_t ngroups = (j.block_len + HUF_SUB_GROUP - 1) / HUF_SUB_GROUP;
     const uint64_t end_bits = j.status[SPEC_END_BITS], end_lane = j.status[SPEC_END_LANE];
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j.status[SPEC_FAIL] || !j.status[SPEC_FOUND]) return;
+    if (j.status[SPEC_FAIL] || j.status[SPEC_CHAIN] || j.status[SPEC_SHORT] || !j.status[SPEC_FOUND]) return;
     /* the last group start in front of share i */
     auto start_before = [&](uint64_t i) {
         while (i > 0) {

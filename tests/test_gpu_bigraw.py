@@ -359,3 +359,34 @@ def test_one_call_fans_out_over_free_sessions(torch_mod, bs):
     print("\n  " + r.stdout.strip().replace("\n", "\n  "))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "sessions live=3 configured=3" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("run_kib,limit_ms", [(2, 10.0), (24, 25.0), (300, 200.0), (2048, None)])
+def test_runs_of_one_byte_inside_a_big_block(torch_mod, codec, run_kib, limit_ms):
+    """A run of one byte value is a periodic bit string: a lane that starts inside it can lock onto the
+    pattern a bit off and never fall into step.  The broken chain is mended one share (512 payload
+    bytes) per round (spec_repair_kernel: 0.13 ms per round, stretches in parallel); a run of more
+    than 1 024 shares leaves the block to the in-order decoder.  Either way the output is exact."""
+    torch = torch_mod
+    n = 40 << 20
+    data = datagen.zipf255(n).copy()
+    rng = np.random.default_rng(run_kib)
+    run = run_kib << 10
+    for i, value in enumerate((0, 0, 1, 3, 17, 200)):
+        at = int(rng.integers(0, n - run - 1))
+        data[at:at + run] = value
+    d = dev(torch, data)
+    stream, offs, length = codec.encode(d, 0)
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode_stream(stream, length, length, out) == (0, n, length)
+    assert torch.equal(out, d)
+    out.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert codec.decode_stream(stream, length, length, out) == (0, n, length)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert torch.equal(out, d)
+    print(f"\n  40 MiB block with runs of {run_kib} KiB: {ms:.2f} ms")
+    if limit_ms is not None:
+        assert ms < limit_ms, ms

@@ -179,6 +179,7 @@ struct DecShared {
     uint32_t part[THREADS / 64];
     uint32_t wtile[32];                  /* decode_sub: payload bits of the chunk's wave tiles */
     uint32_t fastk;                      /* decode_sub: leaves of the tables dsub_fast_tables built (0: the tables are dec_build_tables') */
+    uint32_t l2n;                        /* decode_sub: entries of the second-level table in `ent` (0: none) */
     int efflen;
     uint32_t badsym;                     /* segment symbol index of the first walk that left the tree */
     uint32_t firstone;                   /* single-leaf trees: first set payload bit */

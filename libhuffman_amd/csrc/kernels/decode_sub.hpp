@@ -32,6 +32,8 @@ namespace hufgpu {
  * costs time, never correctness.
  * ==================================================================================== */
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
+#define DSUB_L2_BITS 6u                     /* a second-level table takes codes of up to 12 + 6 bits */
+#define DSUB_L2_ENTRIES 1024u               /* it lives in DecShared::ent */
 #define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: 31 table codewords + two refills of a lane that runs wild */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
@@ -145,7 +147,7 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
     static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256, "two entries per thread");
     const int tid = (int)threadIdx.x;
     const uint32_t K = (uint32_t)(tree_len - 1) >> 2;
-    if (tid == 0) sh.fastk = 0;
+    if (tid == 0) { sh.fastk = 0; sh.l2n = 0; }
     if (tree_len < 9 || tree_len > HUF_TREE_MAX || ((tree_len - 1) & 3) != 0) return false;     /* uniform */
     uint8_t *s_lens = reinterpret_cast<uint8_t *>(sh.pay);                      /* [256] the claimed lengths by byte value */
     uint16_t *s_pos = reinterpret_cast<uint16_t *>(sh.pay + 64);                /* [256] entry index of the k-th leaf */
@@ -240,10 +242,60 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
         }
         *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
+    /* ---- second level: the subtree below a 12-bit prefix whose codes are at most DSUB_L2_BITS longer
+     *      gets a table of its own in the LDS the tree entries occupied (they are not needed any more):
+     *      entry 0x8000 | (bits - 1) << 10 | offset in the first table, (length << 8) | byte in the second.
+     *      Codes beyond that keep their `long` entry. ---- */
+    __syncthreads();                                     /* the first table is written, the tree entries are done with */
+    {
+        uint16_t *l2 = reinterpret_cast<uint16_t *>(sh.ent);
+        const uint32_t *code = F::code(sh);
+        const uint8_t *len = F::len(sh);
+        uint32_t size = 0, nb = 0, run_end = 0;
+        const uint32_t k = (uint32_t)tid;
+        const uint32_t P = (k < K) ? (code[k] >> (32 - DEC_LUT_BITS)) : 0u;
+        if (k < K && d > (uint32_t)DEC_LUT_BITS &&
+            (k == 0 || len[k - 1] <= DEC_LUT_BITS || (code[k - 1] >> (32 - DEC_LUT_BITS)) != P)) {
+            /* first leaf below its prefix: the leaves below one prefix are neighbours (preorder = code order) */
+            uint32_t maxd = d, jn = k + 1u;
+            while (jn < K && jn - k <= (1u << DSUB_L2_BITS) && (code[jn] >> (32 - DEC_LUT_BITS)) == P) {
+                maxd = dmax<uint32_t>(maxd, len[jn]);
+                jn++;
+            }
+            const bool closed = !(jn < K && (code[jn] >> (32 - DEC_LUT_BITS)) == P);
+            if (closed && maxd <= (uint32_t)DEC_LUT_BITS + DSUB_L2_BITS) {
+                nb = maxd - DEC_LUT_BITS;
+                size = 1u << nb;
+                run_end = jn;
+            }
+        }
+        uint32_t total;
+        const uint32_t off = block_excl_scan_u32<THREADS>(size, sh.part, total);
+        if (size && off + size <= DSUB_L2_ENTRIES) {
+            for (uint32_t jn = k; jn < run_end; jn++) {
+                const uint32_t dj = len[jn];
+                const uint32_t first = (code[jn] >> (32 - DEC_LUT_BITS - nb)) & (size - 1u);
+                const uint32_t count = 1u << (DEC_LUT_BITS + nb - dj);
+                const uint16_t entry = (uint16_t)((dj << 8) | (uint32_t)F::sym(sh)[jn]);
+                for (uint32_t i = 0; i < count; i++) l2[off + first + i] = entry;
+            }
+            sh.lut[P] = (uint16_t)(0x8000u | ((nb - 1u) << 10) | off);
+        }
+        if (tid == 0) sh.l2n = dmin<uint32_t>(total, DSUB_L2_ENTRIES);
+    }
     if (tid == 0) sh.fastk = K;
     __syncthreads();
     return true;
 }
+
+/* a second-level entry of the first table resolved with the 32 bits at the codeword's start */
+template <int THREADS>
+__device__ __forceinline__ uint32_t dsub_l2(const DecShared<THREADS> &sh, uint32_t e, uint32_t bits32)
+{
+    const uint32_t nb = ((e >> 10) & 7u) + 1u;
+    return reinterpret_cast<const uint16_t *>(sh.ent)[(e & 0x3ffu) + ((bits32 << DEC_LUT_BITS) >> (32u - nb))];
+}
+#define DSUB_IS_L2(e) (((e) & 0xC000u) == 0x8000u)
 
 /* a codeword longer than the table's 12 bits with dsub_fast_tables' tables: the leaf whose code
  * interval holds the 32 bits at the position; result as dec_rare_packed */
@@ -266,6 +318,7 @@ template <int THREADS>
 __device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, LinReader &rd, uint32_t lim, bool &ok)
 {
     uint32_t e = sh.lut[rd.index()];
+    if (DSUB_IS_L2(e)) e = dsub_l2<THREADS>(sh, e, rd.hi);
     if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
         if (e >= DEC_E_LONG) {
             const uint64_t r = sh.fastk ? dec_rare_fast<THREADS>(sh, rd.st, rd.pos(), lim) : dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
@@ -389,6 +442,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     const uint32_t tstart_q = tincl - tbits_q;                       /* lane q: first bit of tile q relative to T0 */
     const uint32_t chunk_bits = wave_lane_u32(tincl, 63);
     if (T0 + chunk_bits > pay_bits) ok = false;                      /* (b): bits past the payload */
+    const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
     DPROF_ADD(8, pt);
 
 #pragma unroll 1
@@ -503,47 +557,52 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                     typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
                     const uint32_t q0 = s - 1u + 8u * (uint32_t)(uintptr_t)(lds_words)stage;
                     const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
-#define DSUB_WINDOW(Q, acc)                                                                                   \
+/* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
+ * wave by a ballot - goes on to the second table with the bits behind the 12-bit prefix.  Blocks
+ * without such codes (zipf255, uniform bytes) run the loop without the two ballots per window. */
+#define DSUB_WINDOW(Q, acc, L2)                                                                               \
                     {                                                                                         \
                         lds_words wp_ = (lds_words)(uintptr_t)(((Q) >> 3) & ~3u);                              \
                         const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[0], wp_[1], ~(Q));                 \
-                        const uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));    \
+                        uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));          \
+                        if (L2 && __ballot(DSUB_IS_L2(e1_))) {                                                \
+                            if (DSUB_IS_L2(e1_)) e1_ = dsub_l2<THREADS>(sh, e1_, d1_);                        \
+                        }                                                                                     \
                         const uint32_t l1_ = (e1_ >> 8) & 31u;                                                \
                         const uint32_t d2_ = d1_ << l1_;                                                      \
-                        const uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));    \
+                        uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));          \
+                        if (L2 && __ballot(DSUB_IS_L2(e2_))) {                                                \
+                            /* (the window has 32 - l1 bits left: a second code of the second level behind  \
+                             *  a long first one is left to the step-by-step path) */                        \
+                            if (DSUB_IS_L2(e2_))                                                              \
+                                e2_ = (l1_ + DEC_LUT_BITS + DSUB_L2_BITS <= 32u) ? dsub_l2<THREADS>(sh, e2_, d2_) : (uint32_t)DEC_E_LONG; \
+                        }                                                                                     \
                         special |= e1_ | e2_;                                                                 \
                         acc = __builtin_amdgcn_alignbit(e1_, acc, 8);                                         \
                         acc = __builtin_amdgcn_alignbit(e2_, acc, 8);                                         \
                         (Q) += l1_ + ((e2_ >> 8) & 31u);                                                      \
                     }
-                    uint32_t Q = q0;
-#ifdef DSUB_UNROLL_H
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-                    for (int h = 0; h < 2; h++) {
-                        uint32_t w[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t acc = 0;
-#pragma unroll
-                            for (int j = 0; j < 2; j++) DSUB_WINDOW(Q, acc)
-                            w[k] = acc;
-                        }
-                        if (aligned) {
-#ifdef DSUB_NT_STORES
-                            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                            v4u val = {w[0], w[1], w[2], w[3]};
-                            __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(dst) + h);
-#else
-                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
-#endif
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                        }
+#define DSUB_ROUNDS(L2)                                                                                        \
+                    _Pragma("unroll 1")                                                                       \
+                    for (int h = 0; h < 2; h++) {                                                             \
+                        uint32_t w[4];                                                                        \
+                        _Pragma("unroll")                                                                     \
+                        for (int k = 0; k < 4; k++) {                                                         \
+                            uint32_t acc = 0;                                                                 \
+                            _Pragma("unroll")                                                                 \
+                            for (int j = 0; j < 2; j++) DSUB_WINDOW(Q, acc, L2)                               \
+                            w[k] = acc;                                                                       \
+                        }                                                                                     \
+                        if (aligned) {                                                                        \
+                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);           \
+                        } else {                                                                              \
+                            _Pragma("unroll")                                                                 \
+                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
+                        }                                                                                     \
                     }
+                    uint32_t Q = q0;
+                    if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }
+#undef DSUB_ROUNDS
 #undef DSUB_WINDOW
                     const uint32_t p = s + (Q - q0);
 #else

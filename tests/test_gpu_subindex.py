@@ -334,3 +334,61 @@ def test_code_lengths_in_the_sub_index_are_checked_against_the_tree(torch_mod, c
                 bv[b] = lens[(b + 1) % nb].flip(0)
             raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, bad)
             assert raw == n and torch.equal(out[:n], dev(torch, data)), (kind, trial)
+
+
+def _long_code_data(kind, n, bs):
+    """inputs whose trees have codes beyond the decoder's 12-bit table: 13 to 18 bits (second-level
+    table), and beyond (the step-by-step path)"""
+    rng = np.random.default_rng(len(kind))
+    if kind == "zeros_then_zipf":                   # a quarter of every block is one byte value: the Zipf tail gets 13 bits
+        data = datagen.zipf255(n).copy()
+        view = data[: n - n % bs].reshape(-1, bs)
+        view[:, 1000:1000 + bs // 4] = 0
+        return data
+    if kind == "geometric":                         # p(i) ~ 2^-i: lengths 2, 3, 4, ... up to 24 bits
+        w = 0.5 ** np.arange(1, 25)
+        return rng.choice(24, size=n, p=w / w.sum()).astype(np.uint8)
+    if kind == "rare_bytes":                        # 40 common bytes and 200 bytes that occur a few times per block
+        w = np.concatenate([np.full(40, 1.0), np.full(200, 2e-4)])
+        return (rng.choice(240, size=n, p=w / w.sum()) + 7).astype(np.uint8)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["zeros_then_zipf", "geometric", "rare_bytes"])
+@pytest.mark.parametrize("bs", [65536, 1 << 20])
+def test_codes_beyond_the_first_table(torch_mod, codec, oracle, kind, bs):
+    """streams bit-exact with the oracle, sub-index decode exact, and damaged streams decode to the
+    same error and bytes with and without the sub-index"""
+    torch = torch_mod
+    from libhuffman_amd.codec import HuffmanGpuError
+    n = 6 * bs + 12345
+    data = _long_code_data(kind, n, bs)
+    want = oracle.encode(data, bs)
+    stream, offs, length, sub = encode_sub(torch, codec, data, bs)
+    got = stream[:length].cpu().numpy()
+    assert got.size == want.size and np.array_equal(got, want), kind
+    raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, sub)
+    assert raw == n and torch.equal(out[:n], dev(torch, data)), kind
+    nb = codec.block_count(n, bs)
+    offs_h = offs.cpu().numpy()
+    rng = np.random.default_rng(5)
+    for trial in range(8):
+        s = stream[:length].clone()
+        b = int(rng.integers(0, nb))
+        lo, hi = int(offs_h[b]), int(offs_h[b + 1])
+        pos = int(rng.integers(lo + (hi - lo) // 3, hi - 8))
+        if trial % 2:
+            s[pos] ^= 1 << int(rng.integers(0, 8))
+        else:
+            s[pos:pos + 4] = 0xff
+        res, outs = [], []
+        for kw in ({}, dict(sub_index=sub, raw_size=n, blocksize=bs)):
+            o = torch.zeros(n + bs, dtype=torch.uint8, device="cuda")
+            try:
+                res.append((0, codec.decode(s, length, offs, nb, o, **kw)))
+            except HuffmanGpuError as e:
+                res.append((e.err, None))
+            outs.append(o)
+        assert res[0] == res[1], (kind, trial, res)
+        if res[0][0] == 0:
+            assert torch.equal(outs[0], outs[1]), (kind, trial)

@@ -780,7 +780,7 @@ static int decode_big_blocks(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail,
             j.last_pos = ctx->d_big_last_pos;
             j.status = d_status;
             const unsigned lane_wgs = (unsigned)((nlanes + DEC_THREADS - 1) / DEC_THREADS);
-            spec_scan_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j);
+            spec_scan_kernel<DEC_THREADS><<<dim3(lane_wgs), dim3(DEC_THREADS), 0, s>>>(j, sub.lens);
             bool chain_ok = false;
             for (int attempt = 0; attempt < 2; attempt++) {
                 spec_prefix_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(j, (uint64_t)lane_wgs, ctx->d_big_wgscratch);

@@ -173,7 +173,7 @@ __device__ __forceinline__ ColStage spec_stage_of(DecShared<THREADS> &sh, const 
 
 /* pass 1: entry, exit and codeword count of every share */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void spec_scan_kernel(SpecJob j)
+__global__ __launch_bounds__(THREADS) void spec_scan_kernel(SpecJob j, uint8_t *__restrict__ lens_out)
 {
     __shared__ DecShared<THREADS> sh;
     int leaf;
@@ -183,6 +183,32 @@ __global__ __launch_bounds__(THREADS) void spec_scan_kernel(SpecJob j)
         return;
     }
     __syncthreads();                                      /* the table build used the stage area as scratch */
+    if (blockIdx.x == 0) {
+        /* the code length of every byte value = the depth of its leaf, level by level from the root:
+         * with them decode_sub_kernel builds its tables in a few parallel steps (and checks them
+         * against the tree, as it checks an encoder's) */
+        constexpr int ENT = DecShared<THREADS>::ENT;
+        uint16_t *depth = reinterpret_cast<uint16_t *>(sh.pay);
+        for (int i = threadIdx.x; i < ENT; i += THREADS) depth[i] = (i == 0) ? 0 : 0xffffu;
+        for (int i = threadIdx.x; i < HUF_NSYM; i += THREADS) lens_out[i] = 0;
+        __syncthreads();
+        for (uint32_t dlev = 0; dlev < (uint32_t)ENT; dlev++) {
+            bool any = false;
+            for (int i = threadIdx.x; i < j.tree_len; i += THREADS) {
+                if (depth[i] != dlev) continue;
+                const uint32_t lr = sh.lr[i];
+                if (lr == DEC_LEAF_LR) {
+                    if (dlev <= 255u) lens_out[(uint8_t)sh.ent[i]] = (uint8_t)dlev;
+                    continue;
+                }
+                const uint32_t l = lr & 0xffffu, r = lr >> 16;
+                if (l != DEC_NULL) { depth[l] = (uint16_t)(dlev + 1u); any = true; }
+                if (r != DEC_NULL) { depth[r] = (uint16_t)(dlev + 1u); any = true; }
+            }
+            if (!__syncthreads_or(any ? 1 : 0)) break;
+        }
+        __syncthreads();
+    }
     const uint64_t lane = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     uint32_t c = 0;
     if (lane < j.nlanes) {
@@ -384,8 +410,7 @@ __global__ __launch_bounds__(256) void spec_groups_kernel(SpecJob j, HufSubIndex
         sub.group_bits[ngroups - 1] = (uint16_t)(d > 0xffffull ? 0xffffull : d);
     }
     if (t < sub.gpb - ngroups) sub.group_bits[ngroups + t] = 0;
-    if (blockIdx.x == 0) {
-        sub.lens[threadIdx.x] = 0;                        /* no code lengths: the decoder builds its tables from the tree */
+    if (blockIdx.x == 0) {                                /* (the code lengths were written by spec_scan_kernel) */
         if (threadIdx.x == 0) {
             offs[0] = pos;
             offs[1] = pay_off + ((end_bits + 7) >> 3);

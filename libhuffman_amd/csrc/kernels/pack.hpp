@@ -304,7 +304,9 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
  * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
  * registers, more waves. */
 #ifndef PACK_WAVES_PER_SIMD
-#define PACK_WAVES_PER_SIMD 7          /* 72 VGPRs, no scratch: 7 workgroups per CU (6 at 80 VGPRs: zipf255 0.50 -> 0.47 ms; 8 at 64 spills: 0.59) */
+#define PACK_WAVES_PER_SIMD 6          /* 80 VGPRs.  NOT 7 (72 VGPRs, zipf255 0.50 -> 0.47 ms): with 7 the one-code-per-push form
+                                          (longest code 17..24 bits) wrote single wrong payload bytes in blocks 256 and up of a launch,
+                                          differently from run to run (tests/test_gpu_parity.py::test_many_blocks_of_deep_codes) */
 #endif
 template <int THREADS, bool SHORT>
 __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,

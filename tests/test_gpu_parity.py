@@ -824,3 +824,28 @@ def test_bench_runs_over_rccl_with_one_rank(torch_mod):
     rp = d["root_placement"]
     assert "error" not in rp, rp
     assert rp["bit_exact_roundtrip"] is True and rp["value"] > 0
+
+
+@pytest.mark.parametrize("top", [17, 24])
+def test_many_blocks_of_deep_codes(torch_mod, codec, oracle, top):
+    """600 blocks whose longest codes have 17..24 bits (the one-code-per-push form of pack_kernel), whole
+    stream against the oracle, several launches: a pack_kernel built for 7 waves per SIMD wrote single
+    wrong payload bytes here, in blocks 256 and up only and differently from run to run - nothing
+    with fewer blocks, shorter codes or one launch showed it."""
+    torch = torch_mod
+    bs, nb = 65536, 600
+    rng = np.random.default_rng(top)
+    w = 0.5 ** np.arange(1, top + 1)
+    data = rng.choice(top, size=nb * bs, p=w / w.sum()).astype(np.uint8)
+    want = oracle.encode(data, bs)
+    d = to_dev(torch, data)
+    for rep in range(6):
+        stream, offs, length = codec.encode(d, bs)
+        got = stream[:length].cpu().numpy()
+        assert got.size == want.size
+        if not np.array_equal(got, want):
+            oh = offs.cpu().numpy()
+            bad = [b for b in range(nb) if not np.array_equal(got[oh[b]:oh[b + 1]], want[oh[b]:oh[b + 1]])]
+            pytest.fail(f"launch {rep}: {len(bad)} blocks differ from the oracle, first {bad[:8]}")
+    out = torch.zeros(nb * bs, dtype=torch.uint8, device="cuda")
+    assert codec.decode(stream, length, offs, nb, out) == nb * bs and torch.equal(out, d)

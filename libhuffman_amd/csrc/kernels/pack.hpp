@@ -124,6 +124,9 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+#ifdef PACK_DBG_LDS_HANDOVER
+    __shared__ uint32_t s_hand[THREADS + 1];
+#endif
 
     uint8_t *g_a0 = out + (dst0 & ~3ull);
     const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
@@ -255,10 +258,17 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
 
         /* ---- tails hop one lane to the right ---- */
+#ifdef PACK_DBG_LDS_HANDOVER
+        uint32_t in_tail;
+        s_hand[tid + 1] = tail_val;
+        __syncthreads();
+        in_tail = (tid == 0) ? s_tail[WAVES] : s_hand[tid];
+#else
         uint32_t in_tail = wave_up1_u32(tail_val);
         if (lane == 63) s_tail[wave] = tail_val;
         __syncthreads();
         if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];
+#endif
         const uint32_t n_in = (uint32_t)(s & 31u);
         const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
         if (a.have_first) {
@@ -283,7 +293,11 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
         if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
         if (staged) {
+#ifdef PACK_DBG_GLOBAL_FLUSH
+            uint8_t *const g16 = reinterpret_cast<uint8_t *>(g_w0 + w_lo) - 4 * (size_t)i_lo;
+#else
             uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
+#endif
             for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
                 const uint32_t i0 = 4 * u;
                 if (i0 >= i_lo && i0 + 4 <= i_hi) {
@@ -294,6 +308,10 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                 }
             }
         }
+#ifdef PACK_DBG_POISON
+        __syncthreads();
+        for (uint32_t u = tid; u < PACK_STAGE_WORDS; u += THREADS) s_stage[u] = 0xEFBEADDEu;
+#endif
         bitpos += tile_bits;
         (void)rec_hi;
     }
@@ -308,8 +326,13 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                                           (longest code 17..24 bits) wrote single wrong payload bytes in blocks 256 and up of a launch,
                                           differently from run to run (tests/test_gpu_parity.py::test_many_blocks_of_deep_codes) */
 #endif
+#ifdef PACK_NUM_VGPR
+#define PACK_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PACK_NUM_VGPR)))
+#else
+#define PACK_NUM_VGPR_ATTR
+#endif
 template <int THREADS, bool SHORT>
-__global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
+__global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) PACK_NUM_VGPR_ATTR void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                        uint64_t blocksize,
                                                        const hufcode_t *__restrict__ codetab,
                                                        const int16_t *__restrict__ treebuf,
@@ -322,6 +345,9 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     __shared__ uint32_t s_tail[THREADS / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
 
+#ifdef PACK_DBG_CLOBBER72
+    asm volatile("; one VGPR more than the kernel uses" ::: "v72");
+#endif
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
     const uint64_t len = dmin<uint64_t>(blocksize, n - base);

@@ -87,8 +87,11 @@ int hufgpu_encode(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t bloc
 /*
  * Decode a block stream whose block index is known (d_block_offsets from hufgpu_encode).
  *   raw_len  : optional host pointer; when given the call synchronises, stores the number of
- *              bytes written to d_out and returns the first error in stream order
- *              (HUF_ERROR_BTREE_OVERFLOW / _CORRUPTED / _READ_WRITE like src/decoder.c).
+ *              bytes delivered in d_out and returns the first error in stream order
+ *              (HUF_ERROR_BTREE_OVERFLOW / _CORRUPTED / _READ_WRITE like src/decoder.c).  After an
+ *              error these are the blocks in front of the failing one AND the symbols of the failing
+ *              block that src/decoder.c:69-91 delivers before it stops (the block is decoded once
+ *              more, in order, with its record as the whole input).
  *              When NULL the call only enqueues; fetch the result with hufgpu_decode_result().
  */
 int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,

@@ -21,6 +21,7 @@ FILL_SEEDS = {"const41": 0, "uniform256": 1, "uniform255": 2, "zipf255": 3}
 class HuffmanGpuError(RuntimeError):
     def __init__(self, err: int, context: str, detail: str = ""):
         self.err = err
+        self.raw = None
         msg = f"{_native.error_string(err)}. {context}"
         if detail:
             msg += f" ({detail})"
@@ -52,9 +53,11 @@ class GpuCodec:
             pass
 
     # -- helpers ----------------------------------------------------------------------------
-    def _check(self, err: int, what: str):
+    def _check(self, err: int, what: str, raw: int | None = None):
         if err:
-            raise HuffmanGpuError(err, what, self.lib.hufgpu_last_error(self._ctx).decode())
+            e = HuffmanGpuError(err, what, self.lib.hufgpu_last_error(self._ctx).decode())
+            e.raw = raw                 # decode: bytes delivered before the failure (src/decoder.c:69-91)
+            raise e
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
@@ -124,12 +127,12 @@ class GpuCodec:
             err = self.lib.hufgpu_decode(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
                                          nblocks, out.data_ptr(), out.numel(), flags,
                                          C.byref(raw) if sync else None, self._stream())
-        self._check(err, "Failed to decode the data")
+        self._check(err, "Failed to decode the data", raw=int(raw.value) if sync else None)
         return int(raw.value) if sync else None
 
     def decode_result(self) -> int:
         raw = C.c_uint64(0)
-        self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data")
+        self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data", raw=int(raw.value))
         return int(raw.value)
 
     def decode_stream(self, stream: torch.Tensor, avail: int, length: int, out: torch.Tensor,

@@ -92,6 +92,12 @@ struct hufgpu_ctx {
     int slot_kind[PROF_SLOTS];
     int decode_pending;
     hipStream_t last_stream;
+    /* the last enqueued indexed decode: hufgpu_decode_result() decodes a failing block once more, in order */
+    const uint8_t *last_st;
+    const uint64_t *last_offsets;
+    uint8_t *last_out;
+    uint64_t last_stream_len, last_out_cap, last_nblocks;
+    int last_max_tree;
 };
 
 static char g_err[512] = "";
@@ -569,6 +575,10 @@ extern "C" int hufgpu_encode_sub(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n
     return encode_impl(ctx, d_in, n, blocksize, d_out, out_cap, d_block_offsets, d_sub_index, out_len, stream);
 }
 
+static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint8_t *out,
+                        uint64_t out_cap, int max_tree, hipStream_t s, uint64_t *raw, uint64_t *used,
+                        uint64_t *good_used, uint64_t *good_raw);
+
 extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
 {
     if (!ctx) return HUFE_ARGUMENT;
@@ -591,6 +601,21 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     HIP_OK(ctx, hipMemcpyAsync(&err, ctx->d_status + failing, sizeof(err), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipMemcpyAsync(&before, ctx->d_out_offsets + failing, sizeof(before), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
+    if ((err == HUFE_RW || err == HUFE_CORRUPTED) && ctx->last_st && failing < ctx->last_nblocks && before <= ctx->last_out_cap) {
+        /* src/decoder.c:69-91 delivers the symbols in front of the failure: the failing block once more by the
+         * exact in-order decoder, its record [o0, o1) as the whole input (a walk that needs more fails like the
+         * reference's reader at the end of its input) */
+        uint64_t o[2] = {0, 0};
+        HIP_OK(ctx, hipMemcpyAsync(o, ctx->last_offsets + failing, sizeof(o), hipMemcpyDeviceToHost, ctx->last_stream));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
+        if (o[1] > ctx->last_stream_len) o[1] = ctx->last_stream_len;
+        if (o[0] < o[1]) {
+            uint64_t raw = 0, used = 0, gu = 0, gr = 0;
+            const int rc = decode_chain(ctx, ctx->last_st + o[0], o[1] - o[0], 1, ctx->last_out + before, ctx->last_out_cap - before,
+                                        ctx->last_max_tree, ctx->last_stream, &raw, &used, &gu, &gr);
+            if (rc == err) before += raw;
+        }
+    }
     if (raw_len) *raw_len = before;
     if (err == HUFE_ARGUMENT) set_err(ctx, "block %llu is longer than the kernels support", (unsigned long long)failing);
     if (err == HUFE_MEMORY) set_err(ctx, "output buffer too small (block %llu)", (unsigned long long)failing);
@@ -644,6 +669,13 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
     HIP_OK(ctx, hipGetLastError());
     ctx->decode_pending = 1;
     ctx->last_stream = s;
+    ctx->last_st = st;
+    ctx->last_stream_len = stream_len;
+    ctx->last_offsets = d_block_offsets;
+    ctx->last_nblocks = nblocks;
+    ctx->last_out = (uint8_t *)d_out;
+    ctx->last_out_cap = out_cap;
+    ctx->last_max_tree = max_tree;
     if (raw_len) return hufgpu_decode_result(ctx, raw_len);
     return HUFE_OK;
 }

@@ -124,9 +124,6 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-#ifdef PACK_DBG_LDS_HANDOVER
-    __shared__ uint32_t s_hand[THREADS + 1];
-#endif
 
     uint8_t *g_a0 = out + (dst0 & ~3ull);
     const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
@@ -258,17 +255,10 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
 
         /* ---- tails hop one lane to the right ---- */
-#ifdef PACK_DBG_LDS_HANDOVER
-        uint32_t in_tail;
-        s_hand[tid + 1] = tail_val;
-        __syncthreads();
-        in_tail = (tid == 0) ? s_tail[WAVES] : s_hand[tid];
-#else
         uint32_t in_tail = wave_up1_u32(tail_val);
         if (lane == 63) s_tail[wave] = tail_val;
         __syncthreads();
         if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];
-#endif
         const uint32_t n_in = (uint32_t)(s & 31u);
         const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
         if (a.have_first) {
@@ -308,10 +298,6 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                 }
             }
         }
-#ifdef PACK_DBG_POISON
-        __syncthreads();
-        for (uint32_t u = tid; u < PACK_STAGE_WORDS; u += THREADS) s_stage[u] = 0xEFBEADDEu;
-#endif
         bitpos += tile_bits;
         (void)rec_hi;
     }
@@ -322,17 +308,15 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
  * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
  * registers, more waves. */
 #ifndef PACK_WAVES_PER_SIMD
-#define PACK_WAVES_PER_SIMD 6          /* 80 VGPRs.  NOT 7 (72 VGPRs, zipf255 0.50 -> 0.47 ms): with 7 the one-code-per-push form
-                                          (longest code 17..24 bits) wrote single wrong payload bytes in blocks 256 and up of a launch,
-                                          differently from run to run (tests/test_gpu_parity.py::test_many_blocks_of_deep_codes) */
-#endif
-#ifdef PACK_NUM_VGPR
-#define PACK_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PACK_NUM_VGPR)))
-#else
-#define PACK_NUM_VGPR_ATTR
+#define PACK_WAVES_PER_SIMD 6          /* 75 of 80 VGPRs.  With 7 (72 of 72 VGPRs; zipf255 0.50 -> 0.47 ms) hipcc 7.2 keeps code[5] of the
+                                          one-code-per-push form in v71, the LAST register of the allocation, and on gfx950 a 64-bit shift
+                                          whose shift amount is the last allocated VGPR shifts by something else (here: by the lane number) in
+                                          every wave that is not the first on its SIMD - wrong payload bits in blocks 256 and up.  Root cause,
+                                          reproducer and the build-time check: DESIGN.md 3.3, tools/calib/last_vgpr_probe.hip,
+                                          libhuffman_amd/isa_check.py (the build FAILS if any kernel shows the pattern). */
 #endif
 template <int THREADS, bool SHORT>
-__global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) PACK_NUM_VGPR_ATTR void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
+__global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                        uint64_t blocksize,
                                                        const hufcode_t *__restrict__ codetab,
                                                        const int16_t *__restrict__ treebuf,
@@ -345,8 +329,8 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) PACK_NUM_
     __shared__ uint32_t s_tail[THREADS / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
 
-#ifdef PACK_DBG_CLOBBER72
-    asm volatile("; one VGPR more than the kernel uses" ::: "v72");
+#ifdef PACK_VGPR_SLACK      /* test builds only: "v72" gives the 72-VGPR (7 waves per SIMD) build its register of slack */
+    asm volatile("; one VGPR more than the kernel uses" ::: PACK_VGPR_SLACK);
 #endif
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;

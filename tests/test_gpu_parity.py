@@ -760,8 +760,9 @@ def test_deepest_codes_at_the_short_pack_switch(torch_mod, codec, oracle, bs, le
 
 @pytest.mark.parametrize("kind,bs", [("zipf255", 65536), ("uniform256", 65536), ("const41", 65536), ("logtext", 1 << 20)])
 def test_full_size_stream_equals_oracle_stream(torch_mod, codec, oracle, kind, bs):
-    """BASELINE.md's bit-exactness gate at FULL size: every byte of the 1 GiB GPU stream against the
-    CPU oracle's stream of the same input.  Blocks are independent, so the host cores each encode a
+    """BASELINE.md's bit-exactness gate at FULL size: every byte of the 1 GiB GPU stream - as written by the
+    encode bench.py times, the one that also writes the sub-index - against the CPU oracle's stream of the
+    same input; the plain encode must give the same bytes, both timed decodes the input.  Blocks are independent, so the host cores each encode a
     block-aligned slice (ctypes releases the GIL) and the slices are compared where they lie; the
     sha256 of both whole streams is compared on top."""
     from concurrent.futures import ThreadPoolExecutor
@@ -773,7 +774,22 @@ def test_full_size_stream_equals_oracle_stream(torch_mod, codec, oracle, kind, b
     else:
         data = torch.empty(n, dtype=torch.uint8, device="cuda")
         codec.fill(data, kind)
-    out, offs, length = codec.encode(data, bs)
+    # the encode bench.py times: WITH the sub-index (pack_kernel's extra stores inside its tile loop) ...
+    sub = codec.new_sub_index(n, bs)
+    out, offs, length = codec.encode(data, bs, sub_index=sub)
+    # ... the plain encode must give the same bytes and the same block index
+    out2, offs2, length2 = codec.encode(data, bs)
+    assert length2 == length and torch.equal(out2[:length2], out[:length]) and torch.equal(offs2, offs)
+    del out2, offs2
+    # ... and the decodes bench.py times: with the sub-index, and with the block index alone
+    nblk = codec.block_count(n, bs)
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(out, length, offs, nblk, back, relaxed=True, sub_index=sub, raw_size=n, blocksize=bs) == n
+    assert torch.equal(back, data)
+    back.zero_()
+    assert codec.decode(out, length, offs, nblk, back, relaxed=True) == n
+    assert torch.equal(back, data)
+    del back, sub
     got = out[:length].cpu().numpy()
     offs_h = offs.cpu().numpy()
     host = data.cpu().numpy()

@@ -142,18 +142,24 @@ def test_wrong_sub_index_costs_time_not_correctness(torch_mod, codec, what):
     assert raw == n and torch.equal(out[:n], dev(torch, data))
 
 
-def test_damaged_stream_with_sub_index_matches_plain_decode(torch_mod, codec, oracle):
-    """A stream damaged after the encode: error code and delivered blocks are those of the decode
-    without the sub-index (which the other tests pin to the reference)."""
+def test_damaged_stream_matches_the_oracle_block_by_block(torch_mod, codec, oracle):
+    """A stream damaged after the encode, decoded with the block index alone and with the sub-index: against
+    the ORACLE.  The index fixes where every block starts, so the reference's behaviour is that of its decoder
+    run on each block's record [o0, o1) by itself (src/decoder.c:218-276 with that record as the whole input):
+    blocks in front of the damaged one are intact; the damaged one either still decodes - to whatever symbols
+    the oracle reads out of it - or fails with the oracle's error code after the oracle's number of delivered
+    symbols (src/decoder.c:69-91), which are in the output too."""
     torch = torch_mod
+    from libhuffman_amd.codec import HuffmanGpuError
     n, bs = 6 * 65536, 65536
     rng = np.random.default_rng(77)
+    seen = set()
     for kind in ("zipf255", "uniform255", "const41"):
         data = datagen.GENERATORS[kind](n)
         stream, offs, length, sub = encode_sub(torch, codec, data, bs)
         offs_h = offs.cpu().numpy()
         nb = codec.block_count(n, bs)
-        for trial in range(12):
+        for trial in range(16):
             s = stream[:length].clone()
             b = int(rng.integers(0, nb))
             lo, hi = int(offs_h[b]), int(offs_h[b + 1])
@@ -167,26 +173,36 @@ def test_damaged_stream_with_sub_index_matches_plain_decode(torch_mod, codec, or
             elif mode == 2:                           # a damaged tree entry
                 pos = lo + 10 + 2 * int(rng.integers(0, 5))
                 s[pos] ^= 0x55
-            else:                                     # a damaged block length
-                s[lo + 1] ^= 0x01
-            out_a = torch.zeros(n + 65536, dtype=torch.uint8, device="cuda")
-            out_b = torch.zeros(n + 65536, dtype=torch.uint8, device="cuda")
-            from libhuffman_amd.codec import HuffmanGpuError
-            res = []
-            for out, kw in ((out_a, {}), (out_b, dict(sub_index=sub, raw_size=n, blocksize=bs))):
-                try:
+            else:                                     # a block length that claims a few symbols more
+                s[lo] = (int(s[lo]) + 1 + int(rng.integers(0, 40))) & 0xff
+            record = s[lo:hi].cpu().numpy()
+            oerr, oout, _ = oracle.decode(record, bs + 4096, 1024, length=1)        # length 1: exactly one block
+            seen.add(oerr)
+            for kw in ({}, dict(sub_index=sub, raw_size=n, blocksize=bs)):
+                out = torch.zeros(n + 65536, dtype=torch.uint8, device="cuda")
+                tag = (kind, trial, mode, b, "sub" if kw else "index", oerr, oout.size)
+                if oerr == 0 and oout.size == bs:
                     raw = codec.decode(s, length, offs, nb, out, **kw)
-                    res.append((0, raw))
-                except HuffmanGpuError as e:
-                    res.append((e.err, codec.decode_result() if False else None))
-            assert res[0][0] == res[1][0], (kind, trial, res)
-            if res[0][0] == 0:
-                assert res[0][1] == res[1][1] and torch.equal(out_a, out_b), (kind, trial)
-            else:
-                # blocks before the failing one are delivered by both
-                first_bad = b * bs
-                assert torch.equal(out_a[:first_bad], out_b[:first_bad]), (kind, trial)
-                assert torch.equal(out_b[:first_bad], dev(torch, data[:first_bad])), (kind, trial)
+                    want = data.copy()
+                    want[b * bs:(b + 1) * bs] = oout
+                    assert raw == n and np.array_equal(out[:n].cpu().numpy(), want), tag
+                elif oerr == 0:
+                    # the block now claims another length: the blocks behind it land elsewhere in the output
+                    # (the index knows where they start in the STREAM); only the part in front is pinned here
+                    try:
+                        codec.decode(s, length, offs, nb, out, **kw)
+                    except HuffmanGpuError:
+                        pass
+                    assert np.array_equal(out[:b * bs + min(oout.size, bs)].cpu().numpy()[:b * bs], data[:b * bs]), tag
+                else:
+                    with pytest.raises(HuffmanGpuError) as ei:
+                        codec.decode(s, length, offs, nb, out, **kw)
+                    assert ei.value.err == oerr, tag + (ei.value.err,)
+                    assert ei.value.raw == b * bs + oout.size, tag + (ei.value.raw,)
+                    got = out[:ei.value.raw].cpu().numpy()
+                    assert np.array_equal(got[:b * bs], data[:b * bs]), tag
+                    assert np.array_equal(got[b * bs:], oout), tag
+    assert 6 in seen and 0 in seen, seen
 
 
 def test_sub_index_output_too_small(torch_mod, codec):

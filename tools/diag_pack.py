@@ -6,14 +6,16 @@ and maps each wrong 32-bit word of a bad launch back to the workgroup's tile, wa
 of the word among that lane's finished words - plus whether the wrong value is what the LDS stage held
 at the same stage index one tile earlier.  Test tooling: uses oracle/ as the checker.
 
-usage: diag_pack.py [seconds] [seed] [max_reports] [tops e.g. 17,24]
+usage: diag_pack.py [seconds | n<launches>] [seed] [max_reports] [tops e.g. 17,24]
+       (n2400 = stop after at least 2400 launches spread over 8 inputs instead of after a time)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle.oracle import Oracle
 
-seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+want_launches = int(sys.argv[1][1:]) if len(sys.argv) > 1 and sys.argv[1].startswith("n") else 0
+seconds = 1e9 if want_launches else (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 max_reports = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 tops = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [17, 24]
@@ -107,7 +109,7 @@ if __name__ == '__main__':
     t_end = time.time() + seconds
     cases = launches = bad = reports = 0
     print("lib", _native.so_path(), flush=True)
-    while time.time() < t_end:
+    while time.time() < t_end and (not want_launches or launches < want_launches):
         top = int(rng.integers(tops[0], tops[1] + 1))
         bs = int(rng.choice([65536, 65536, 32768, 100000]))
         nb = int(rng.integers(300, 900))
@@ -118,7 +120,8 @@ if __name__ == '__main__':
         d = torch.from_numpy(data).cuda()
         out = torch.empty(c.encode_bound(data.size, bs), dtype=torch.uint8, device="cuda")
         t_case = time.time() + 4.0
-        while time.time() < t_case:
+        case_first = launches
+        while (launches - case_first < want_launches // 8 + 1) if want_launches else (time.time() < t_case):
             for rep in range(50):
                 stream, _, length = c.encode(d, bs, out=out)
                 launches += 1

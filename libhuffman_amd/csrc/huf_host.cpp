@@ -51,7 +51,12 @@ extern "C" {
 /* ------------------------------------------------------------------ errors / alloc / config */
 const char *huf_error_string(huf_error_t error)   /* src/errors.c:5-33 */
 {
-    switch ((int)error) {
+    /* callers pass anything (the reference answers "Unknown error" for -1, 7, 8 ...): the bytes are read as
+     * an int, a C++ load of an out-of-range enum value would be undefined (UBSan: -fsanitize=enum) */
+    int code;
+    memcpy(&code, &error, sizeof(code));
+    static_assert(sizeof(code) == sizeof(error), "huf_error_t is a 4-byte enum");
+    switch (code) {
     case HUF_ERROR_SUCCESS: return "Success";
     case HUF_ERROR_MEMORY_ALLOCATION: return "Failed to allocate the requested memory block";
     case HUF_ERROR_INVALID_ARGUMENT: return "An invalid argument was specified to the function";

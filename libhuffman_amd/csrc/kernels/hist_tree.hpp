@@ -161,10 +161,16 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
         s_tot[b] = sum;
     }
     __syncthreads();                     /* copies are dead from here on; s_tot is complete */
+#ifdef HT_TREE_WAVE_ROT
+    /* the wave that builds the tree rotates with the block index: a workgroup's wave w sits on SIMD w of its
+     * CU, so "always wave 0" would put every tree of a CU on one SIMD */
+    if ((uint32_t)(tid >> 6) != ((uint32_t)blk & (uint32_t)(WAVES - 1))) return;
+#else
     if (tid >= 64) return;               /* ended waves do not take part in anything below */
+#endif
     uint32_t rate[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) rate[j] = s_tot[tid + 64 * j];
+    for (int j = 0; j < 4; j++) rate[j] = s_tot[(tid & 63) + 64 * j];
 #ifdef HT_ABLATE_TREE          /* (diagnostic builds: the counting alone) */
     const uint64_t bytes = rate[0] + rate[1] + rate[2] + rate[3] + 100;
 #else

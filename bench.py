@@ -53,6 +53,18 @@ WORKLOADS = {
 DEFAULT_SECONDARY = {"zipf255": ["uniform256", "const41"]}
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(workload: str, blocksize: int) -> dict:
     """Unmodified reference (oracle/_ref/libhuffman_ref.so) on ONE host core, bounded sample."""
     import numpy as np  # noqa: F401
@@ -109,7 +121,7 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
         except Exception as e:                                  # never fail the bench over the extra figure
             all_cores = {"error": repr(e)}
     return {"value": round(sample_bytes / GIB / (t_enc + t_dec), 5), "unit": "GiB/s", "cores": 1,
-            "kind": kind, "all_cores": all_cores,
+            "kind": kind, "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "all_cores": all_cores,
             "sample": f"{sample_bytes >> 20} MiB of {workload}, {blocksize >> 10} KiB blocks, "
                       f"encode {t_enc:.2f}s + decode {t_dec:.2f}s, memstreams, 1 thread",
             "encode_GiBps": round(sample_bytes / GIB / t_enc, 5),
@@ -181,18 +193,39 @@ class Bench:
         self.codec.fill(data, workload, first=first)
         return data
 
-    def run(self, workload: str, steps: int, warmup: int) -> dict:
+    def copy_ceiling(self, n: int) -> float:
+        """GB/s of a plain device copy of n bytes (read n + write n) on this GPU, HIP events on the
+        current stream: the measured ceiling SURVEY 8d asks to be reported beside the 8 TB/s spec."""
+        torch = self.torch
+        a = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        b = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        a.fill_(7)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 5
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        del a, b
+        torch.cuda.empty_cache()
+        return 2.0 * n * reps / 1e9 / (e0.elapsed_time(e1) / 1e3)
+
+    def run(self, workload: str, steps: int, warmup: int, decode: str = None, bytes_per_gpu: int = None,
+            other_decode: bool = True) -> dict:
         """K timed steps of one workload on every rank; returns rank 0's result record."""
         from libhuffman_amd.sharding import shard_range
         a, torch, dist, codec = self.a, self.torch, self.dist, self.codec
         world, rank, dev = self.world, self.rank, self.dev
         bs = a.blocksize or ((1 << 20) if workload == "logtext" else 65536)
-        n_total = a.bytes_per_gpu * world
+        n_total = (bytes_per_gpu or a.bytes_per_gpu) * world
         lo, hi = shard_range(n_total, bs, rank, world)          # contiguous block range of this rank
         n = hi - lo
         nb = codec.block_count(n, bs)
         relaxed = workload == "uniform256"
-        use_sub = a.decode == "sub"
+        use_sub = (decode or a.decode) == "sub"
 
         data = self.make_input(workload, n, lo)
         out = torch.empty(codec.encode_bound(n, bs), dtype=torch.uint8, device=dev)
@@ -275,7 +308,7 @@ class Bench:
         # the other decoder on the same stream, outside the timed region: what a stream without the
         # encoder's sub-index costs (and the other way round)
         other_ms = None
-        if rank == 0 and use_sub and not a.no_other_decode:
+        if rank == 0 and use_sub and other_decode and not a.no_other_decode:
             codec.set_profiling(True)
             for _ in range(3):
                 codec.decode(out, out.numel(), offs, nb, back, relaxed=relaxed, sync=False)
@@ -289,8 +322,12 @@ class Bench:
             K = steps
             value = n_total * K / GIB / elapsed
             # per-launch algorithmic bytes: encode reads N writes C, decode reads C writes N
-            alg = {"pack": n + comp_len, "decode": comp_len + n, "hist256": n, "tree": nb * (1024 + 2048 + 2064),
-                   "scan_sizes": nb * 24, "prepare_scan": nb * (16 + 10 + 28)}
+            # The sub-index is in-process side information, written by pack and read by decode_sub.  SURVEY 8d
+            # counts only N and C as algorithmic bytes (side tables are implementation traffic), so `achieved`
+            # does NOT include it; the line states its size so that nobody has to guess what else moves.
+            sub_bytes = codec.sub_index_bytes(n, bs) if (use_sub and workload != "const41") else 0
+            alg = {"pack": n + comp_len, "decode": comp_len + n, "hist256": n,
+                   "tree": nb * (1024 + 2048 + 2064), "scan_sizes": nb * 24, "prepare_scan": nb * (16 + 10 + 28)}
             if workload == "const41":
                 alg["pack"] = comp_len          # one-symbol blocks: the input is not read again, the payload is zeros
             # blocks below 4 MiB take the fused histogram+tree kernel: its time is reported once
@@ -315,7 +352,7 @@ class Bench:
             achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
             kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_kernel", "pack": "pack_kernel",
                             "hist_tree": "hist_tree_kernel", "hist256": "hist256_kernel", "tree": "tree_kernel"}
-            pipeline_bytes = 2 * (n + comp_len)
+            pipeline_bytes = 2 * (n + comp_len)     # the metric's bytes (side tables are implementation traffic)
             gpu_ms = ev0.elapsed_time(ev1) / K
             # encode-only / decode-only: this rank's bytes over the kernels of each half
             enc_ms = sum(v["avg_ms"] for k, v in kernels.items() if k in enc_prof)
@@ -333,6 +370,7 @@ class Bench:
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": measured_traffic(workload, dom, n, bs),
                              "alg_bytes_per_launch": alg[dom],
+                             "side_bytes_per_launch": sub_bytes if dom in ("pack", "decode") else 0,
                              "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},
                 "kernels": kernels,
                 "encode_only_GiBps_per_gpu": round(n / GIB / (enc_ms / 1e3), 1) if enc_ms > 0 else None,
@@ -380,6 +418,7 @@ class Bench:
             return {"error": "allocation failed on some rank: %s" % alloc_err} if rank == 0 else None
         in_sizes = [h - l for l, h in plan]
         gathered = None
+        leg_timeout = float(os.environ.get("BENCH_LEG_TIMEOUT", "120"))     # seconds a movement may take
         legs = {"scatter_in": 0.0, "encode": 0.0, "gather_stream": 0.0, "scatter_stream": 0.0, "decode": 0.0,
                 "gather_out": 0.0}
 
@@ -399,14 +438,14 @@ class Bench:
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            timed("scatter_in", lambda: sharding.scatter_from_root(full, in_sizes, shard, 0))
+            timed("scatter_in", lambda: sharding.scatter_from_root(full, in_sizes, shard, 0, timeout=leg_timeout))
             timed("encode", lambda: codec.encode(shard, bs, out=out, offsets=offs, sync=False, sub_index=sub))
             clen = int(offs[nb].item())
-            gathered, csizes = timed("gather_stream", lambda: sharding.gatherv_to_root(out, clen, 0))
-            timed("scatter_stream", lambda: sharding.scatter_from_root(gathered, csizes, out[:clen], 0))
+            gathered, csizes = timed("gather_stream", lambda: sharding.gatherv_to_root(out, clen, 0, timeout=leg_timeout))
+            timed("scatter_stream", lambda: sharding.scatter_from_root(gathered, csizes, out[:clen], 0, timeout=leg_timeout))
             timed("decode", lambda: codec.decode(out, clen, offs, nb, back, relaxed=relaxed, sync=True,
                                                  sub_index=sub, raw_size=n, blocksize=bs))
-            timed("gather_out", lambda: sharding.gather_to_root(back, in_sizes, result, 0))
+            timed("gather_out", lambda: sharding.gather_to_root(back, in_sizes, result, 0, timeout=leg_timeout))
             torch.cuda.synchronize()
             dist.barrier()
             total += time.perf_counter() - t0
@@ -422,6 +461,35 @@ class Bench:
                 "steps": steps, "bit_exact_roundtrip": ok, "stream_bytes": int(sum(csizes)),
                 "legs_ms_rank0": {key: round(v / steps * 1e3, 3) for key, v in legs.items()},
                 "note": "input and output live on rank 0; every leg is synchronised (no overlap between legs)"}
+
+
+def huffmanfile_layer(n: int, blocksize: int, reps: int = 2) -> dict:
+    """BASELINE.json configs[4]'s shape on this GPU: synthetic log text through the Python layer
+    (libhuffman_amd.huffmanfile.compress / decompress = huf_encode / huf_decode behind memstreams), host
+    bytes in, host bytes out.  PCIe-inclusive by construction: reported beside the resident-data figure,
+    never instead of it."""
+    import numpy as np
+    from libhuffman_amd import datagen, huffmanfile
+    tile = datagen.logtext(16 << 20)
+    data = np.tile(tile, (n + tile.size - 1) // tile.size)[:n].tobytes()
+    comp = huffmanfile.compress(data, blocksize)              # warm-up: sessions, pinned buffers, page faults
+    back = huffmanfile.decompress(comp)
+    ok = back == data
+    t_c = t_d = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        comp = huffmanfile.compress(data, blocksize)
+        t1 = time.perf_counter()
+        back = huffmanfile.decompress(comp)
+        t2 = time.perf_counter()
+        t_c += t1 - t0
+        t_d += t2 - t1
+        ok = ok and back == data
+    return {"value": round(n * reps / GIB / (t_c + t_d), 3), "unit": "GiB/s",
+            "workload": "configs[4] per-GPU share: %d MiB of synthetic log text, blocksize=%d KiB, through "
+                        "huffmanfile.compress/decompress (host bytes in and out)" % (n >> 20, blocksize >> 10),
+            "compress_GiBps": round(n * reps / GIB / t_c, 3), "decompress_GiBps": round(n * reps / GIB / t_d, 3),
+            "ratio": round(len(comp) / n, 5), "bit_exact_roundtrip": bool(ok), "reps": reps}
 
 
 def main() -> None:
@@ -442,6 +510,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-decode", action="store_true")
+    ap.add_argument("--no-index-free", action="store_true", help="skip the timed loop with the block index alone")
+    ap.add_argument("--no-python-layer", action="store_true", help="skip the huffmanfile (configs[4] shape) figure")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -479,29 +549,34 @@ def main() -> None:
 
     main_rec = bench.run(args.workload, args.steps, args.warmup)
     sec_recs = {w: bench.run(w, args.steps, args.warmup) for w in secondary}
-    # The scatter/gather form is an extra figure: it runs on a helper thread with a deadline, so that
-    # a collective that never returns (a rank that failed alone) cannot take the headline with it -
-    # the line is then printed without it and the ranks leave without the final barrier.
-    root_box = {"rec": None, "done": False}
+    # the same K steps with the BLOCK INDEX ALONE (no sub-index: what a stream that comes without the
+    # encoder's side information costs) - a timed region of its own, so that the driver's record holds both
+    if args.decode == "sub" and not args.no_index_free:
+        sec_recs[args.workload + "_index_free"] = bench.run(args.workload, args.steps, args.warmup, decode="selfsync",
+                                                           other_decode=False)
+    # BASELINE.json configs[3] is 16 GiB of uniform bytes over 8 GPUs: at world 8 that is 2 GiB per rank
+    if world == 8 and "uniform256" in secondary and args.bytes_per_gpu == (1 << 30):
+        sec_recs["uniform256_16GiB"] = bench.run("uniform256", max(2, args.steps // 2), min(args.warmup, 2),
+                                                 bytes_per_gpu=2 << 30, other_decode=False)
+        if rank == 0:
+            sec_recs["uniform256_16GiB"]["config"]["workload"] = \
+                "configs[3]: 16 GiB uniform-random bytes (uniform256 seed 1), blocksize=64KiB, sharded across 8 MI355X"
+    copy_gbs = bench.copy_ceiling(1 << 30) if rank == 0 else None
+    # The scatter/gather form is an extra figure.  Every movement in it is waited for with a deadline
+    # (BENCH_LEG_TIMEOUT), so a rank that fails alone shows as an exception here, not as a hang: the line is
+    # then printed without the figure and the ranks leave without the final barrier.
+    root_rec, root_ok = None, True
     if use_dist and args.placement in ("auto", "root"):
-        import threading
-
-        def extra():
-            try:
-                torch.cuda.set_device(local_rank)
-                root_box["rec"] = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
-            except Exception as e:                  # the extra figure never takes the headline down with it
-                root_box["rec"] = {"error": repr(e)}
-            root_box["done"] = True
-
-        th = threading.Thread(target=extra, daemon=True)
-        th.start()
-        th.join(float(os.environ.get("BENCH_EXTRA_TIMEOUT", "300")))
-        if not root_box["done"]:
-            root_box["rec"] = {"error": "timed out (BENCH_EXTRA_TIMEOUT)"}
-    else:
-        root_box["done"] = True
-    root_rec = root_box["rec"]
+        try:
+            root_rec = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
+        except Exception as e:                      # the extra figure never takes the headline down with it
+            root_rec, root_ok = {"error": repr(e)}, False
+    py_rec = None
+    if rank == 0 and not args.no_python_layer:
+        try:
+            py_rec = huffmanfile_layer(1 << 30, 1 << 20)
+        except Exception as e:
+            py_rec = {"error": repr(e)}
 
     result = None
     if rank == 0:
@@ -531,7 +606,14 @@ def main() -> None:
             for w, r in sec_recs.items()}
         if root_rec is not None:
             result["root_placement"] = root_rec
-        if world == 1 and not args.no_cpu_baseline:
+        if py_rec is not None:
+            result["secondary"]["logtext_huffmanfile"] = py_rec
+        result["roofline"]["copy_ceiling_GBps"] = round(copy_gbs, 1)
+        result["roofline"]["frac_of_copy_ceiling"] = round(result["roofline"]["achieved"] / copy_gbs, 4)
+        if world > 1:
+            result["multi_gpu_note"] = ("ranks are block-sharded; value = all ranks' bytes over the slowest rank's time; "
+                                        "cpu_baseline is rank 0's host")
+        if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, bs)
 
     # RCCL writes its version banner through C stdio, which a pipe only sees when a process exits:
@@ -540,8 +622,9 @@ def main() -> None:
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
-    if not root_box["done"]:
-        # a collective of the extra figure is stuck: no barrier, no teardown (both would wait for it)
+    if not root_ok:
+        # a movement of the extra figure failed or timed out on this rank: the ranks are out of step, so no
+        # barrier and no teardown (both would wait for the missing ones)
         if rank == 0:
             print(json.dumps(result), flush=True)
         os._exit(0)

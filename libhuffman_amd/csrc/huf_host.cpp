@@ -866,7 +866,7 @@ static void *prefault_main(void *arg)
     const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
     const uintptr_t lo = (uintptr_t)w->p & ~(page - 1), hi = ((uintptr_t)w->p + w->n + page - 1) & ~(page - 1);
     if (madvise((void *)lo, (size_t)(hi - lo), MADV_POPULATE_WRITE) != 0)
-        for (volatile char *q = w->p; q < w->p + w->n; q += page) *q = *q;     /* older kernels: a write fault per page, contents kept */
+        for (char *q = w->p; q < w->p + w->n; q += page) (void)__atomic_fetch_or(q, 0, __ATOMIC_RELAXED);   /* older kernels: a write fault per page, contents kept (one atomic read-modify-write) */
     return NULL;
 }
 
@@ -1234,12 +1234,13 @@ typedef struct {
     std::atomic<uint64_t> next;
     uint64_t *out_len;              /* per round, valid once known[k] */
     unsigned char *known;
+    unsigned char *done;            /* per round: its stream is in place in dst (written under mu, read after the joins) */
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    int err;
+    std::atomic<int> err;
 } fanout_t;
 
-typedef struct { fanout_t *f; session_t *session; } fanout_worker_t;
+typedef struct { fanout_t *f; session_t *session; int extra; } fanout_worker_t;   /* extra: not the call's own session */
 
 #define HUF_MAX_LINKS 64
 static pthread_mutex_t g_link_lock[HUF_MAX_LINKS][2];               /* per device: [0] host -> device, [1] device -> host */
@@ -1255,7 +1256,8 @@ static void link_locks_init(void)
 static void fanout_fail(fanout_t *f, int err)
 {
     pthread_mutex_lock(&f->mu);
-    if (f->err == HUF_ERROR_SUCCESS) f->err = err;
+    int none = HUF_ERROR_SUCCESS;
+    f->err.compare_exchange_strong(none, err);
     pthread_cond_broadcast(&f->cv);
     pthread_mutex_unlock(&f->mu);
 }
@@ -1269,8 +1271,14 @@ static void *fanout_main(void *arg)
     const uint64_t bound = hufgpu_encode_bound(f->round_bytes, f->blocksize);
     if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_a, &g_stage.d_a_cap, f->round_bytes);
     if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_b, &g_stage.d_b_cap, bound);
+    if (rc != HUF_ERROR_SUCCESS && w->extra) {
+        /* an EXTRA session that cannot be set up (a device of HUF_GPU_DEVICES without memory left, a context
+         * that cannot be created) has taken no round yet: the call goes on with the sessions that work */
+        t_session = NULL;
+        return NULL;
+    }
     while (rc == HUF_ERROR_SUCCESS) {
-        if (*(volatile int *)&f->err != HUF_ERROR_SUCCESS) break;        /* another session failed */
+        if (f->err.load() != HUF_ERROR_SUCCESS) break;                   /* another session failed */
         const uint64_t k = f->next.fetch_add(1);
         if (k >= f->nrounds) break;
         const uint64_t off = k * f->round_bytes;
@@ -1293,19 +1301,26 @@ static void *fanout_main(void *arg)
         f->known[k] = 1;
         pthread_cond_broadcast(&f->cv);
         for (;;) {
-            if (f->err != HUF_ERROR_SUCCESS) break;
             uint64_t j = 0;
             before = 0;
             while (j < k && f->known[j]) before += f->out_len[j++];
-            if (j == k) break;
+            if (j == k) break;                                       /* every earlier size is known: this round still lands, */
+            if (f->err.load() != HUF_ERROR_SUCCESS) break;           /* even after another session failed behind it */
             pthread_cond_wait(&f->cv, &f->mu);
         }
-        const int stop = f->err != HUF_ERROR_SUCCESS;
+        uint64_t j2 = 0;
+        while (j2 < k && f->known[j2]) j2++;
+        const int stop = j2 < k;                                         /* (only possible after a failure) */
         pthread_mutex_unlock(&f->mu);
         if (stop) break;
         pthread_mutex_lock(&dir[1]);
         rc = hufgpu_memcpy_d2h(g_ctx, f->dst + before, g_stage.d_b, out_len);
         pthread_mutex_unlock(&dir[1]);
+        if (rc == HUF_ERROR_SUCCESS) {
+            pthread_mutex_lock(&f->mu);
+            f->done[k] = 1;
+            pthread_mutex_unlock(&f->mu);
+        }
     }
     if (rc != HUF_ERROR_SUCCESS) fanout_fail(f, rc);
     t_session = NULL;
@@ -1348,10 +1363,11 @@ static int encode_fanout(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf
     f.round_bytes = round_bytes;
     f.nrounds = nrounds;
     f.next.store(0);
-    f.err = HUF_ERROR_SUCCESS;
+    f.err.store(HUF_ERROR_SUCCESS);
     f.out_len = (uint64_t *)calloc(nrounds, sizeof(uint64_t));
     f.known = (unsigned char *)calloc(nrounds, 1);
-    huf_error_t err = (f.out_len && f.known) ? mem_reserve(wmem, bound) : HUF_ERROR_MEMORY_ALLOCATION;
+    f.done = (unsigned char *)calloc(nrounds, 1);
+    huf_error_t err = (f.out_len && f.known && f.done) ? mem_reserve(wmem, bound) : HUF_ERROR_MEMORY_ALLOCATION;
     if (err == HUF_ERROR_SUCCESS) {
         f.dst = (char *)*wmem->buf + wmem->len;
         prefault_job_t job;                                           /* about as many bytes as the stream will have */
@@ -1365,27 +1381,31 @@ static int encode_fanout(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf
         for (int i = 0; i < nextra; i++) {
             workers[i + 1].f = &f;
             workers[i + 1].session = extra[i];
+            workers[i + 1].extra = 1;
             if (pthread_create(&th[i], NULL, fanout_main, &workers[i + 1]) != 0) break;
             started++;
         }
         workers[0].f = &f;
         workers[0].session = mine;
+        workers[0].extra = 0;
         fanout_main(&workers[0]);                                     /* this thread works with the call's own session */
         t_session = mine;
         for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
         pthread_mutex_destroy(&f.mu);
         pthread_cond_destroy(&f.cv);
-        err = (huf_error_t)f.err;
-        if (err == HUF_ERROR_SUCCESS) {
-            uint64_t total = 0;
-            for (uint64_t k = 0; k < nrounds; k++) total += f.out_len[k];
-            wmem->len += total;
-            rmem->off += length;
-        }
+        err = (huf_error_t)f.err.load();
+        /* what the reference's unbuffered writer has delivered when it fails stays delivered: the rounds in
+         * front of the first one that is not in place (all of them on success) */
+        uint64_t total = 0, p = 0;
+        while (p < nrounds && f.done[p]) total += f.out_len[p++];
+        if (err == HUF_ERROR_SUCCESS && p < nrounds) err = HUF_ERROR_FATAL;   /* (cannot happen: every round was taken) */
+        wmem->len += total;
+        rmem->off += (p == nrounds) ? length : p * round_bytes;
     }
     for (int i = 0; i < nextra; i++) session_release_extra(extra[i]);
     free(f.out_len);
     free(f.known);
+    free(f.done);
     *result = err;
     return 1;
 }

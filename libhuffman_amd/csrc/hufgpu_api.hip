@@ -901,8 +901,10 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
     uint64_t raw2 = 0, used2 = 0;
     const int err = decode_stream_general(ctx, (const uint8_t *)d_stream + pos, avail - pos, length - pos,
                                           (uint8_t *)d_out + rawpos, out_cap - rawpos, flags, &raw2, &used2, stream);
-    ctx->complete_used += pos;
-    ctx->complete_raw += rawpos;
+    /* the general path reports ITS complete blocks (0 / 0 when it returned before decoding anything): the
+     * totals are formed here, in one place */
+    ctx->complete_used = pos + ctx->complete_used;
+    ctx->complete_raw = rawpos + ctx->complete_raw;
     if (raw_len) *raw_len = rawpos + raw2;
     if (consumed) *consumed = pos + used2;
     return err;
@@ -918,6 +920,8 @@ static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64
     uint8_t *out = (uint8_t *)d_out;
     uint64_t raw = 0, used = 0;
     int err = HUFE_OK;
+    ctx->complete_used = 0;              /* also what an early return (a failed HIP call) leaves behind */
+    ctx->complete_raw = 0;
 
     /* ---- parallel path: discover the block chain, decode the validated prefix ---- */
     uint64_t prefix_raw = 0, resume = 0;

@@ -271,6 +271,7 @@ class HuffmanFile(io.BufferedIOBase):
         self._plain = bytearray()   # decoded, not yet returned (from self._cursor on)
         self._cursor = 0
         self._rest = b""            # compressed bytes behind the last whole block decoded so far
+        self._error = None          # the HuffmanError of a failed read: raised again by every later read
         self._eof = False
         self._cursor = 0
         if mode in ("", "r", "rb"):
@@ -336,25 +337,62 @@ class HuffmanFile(io.BufferedIOBase):
         """Decode rounds of READ_PIECE compressed bytes until `want` plain bytes are buffered (want <
         0: until the end of the file).  Block boundaries are only known by decoding (the format
         stores no payload length), so a round decodes the blocks that are complete in what has been
-        read and keeps the cut-off rest in front of the next piece: memory stays bounded by a round,
-        whatever the size of the file (the reference reads `size` COMPRESSED bytes per call and
-        fails when they do not end on a block boundary, huffmanfile.py:152-162)."""
+        read and keeps the cut-off rest in front of the next piece: memory stays bounded by a round
+        for blocks smaller than a round, whatever the size of the file (the reference reads `size`
+        COMPRESSED bytes per call and fails when they do not end on a block boundary,
+        huffmanfile.py:152-162).  A block LARGER than a round (blocksize = 0 makes the whole file one
+        block, src/encoder.c:163-165) is not decoded piece by piece over and over: when a round
+        completes no block, the next read is at least what the block's header says the block must
+        have (one bit per symbol) and at least as much again as is already held - geometric, so the
+        work stays linear in the size of the block."""
+        if self._error is not None:
+            raise self._error               # a failed read stays failed (the stream position is lost)
+        next_read = self.READ_PIECE
         while not self._eof and (want < 0 or len(self._plain) - self._cursor < want):
-            piece = self._fp.read(self.READ_PIECE)
+            piece = self._fp.read(next_read)
             if not piece:
                 self._eof = True
                 if self._rest:
                     # what is left is not a whole block: the error the reference's decoder gives
                     # when its input ends inside a block
-                    _check(N.HUF_ERROR_READ_WRITE, "Failed to decode the data")
+                    try:
+                        _check(N.HUF_ERROR_READ_WRITE, "Failed to decode the data")
+                    except HuffmanError as e:
+                        self._error = e
+                        raise
                 break
             buf = self._rest + piece if self._rest else piece
-            plain, used = self._decompressor.decompress_blocks(buf)
+            next_read = self.READ_PIECE
+            need = self._block_floor(buf)
+            if need > len(buf):
+                # the first block cannot be complete yet: no decode attempt, read on
+                self._rest = bytes(buf)
+                next_read = max(self.READ_PIECE, need - len(buf), len(buf))
+                continue
+            try:
+                plain, used = self._decompressor.decompress_blocks(buf)
+            except HuffmanError as e:
+                self._error = e
+                raise
             self._rest = bytes(memoryview(buf)[used:])
+            if used == 0:
+                next_read = max(self.READ_PIECE, len(buf))
             if self._cursor:
                 del self._plain[:self._cursor]
                 self._cursor = 0
             self._plain += plain
+
+    @staticmethod
+    def _block_floor(buf) -> int:
+        """Fewest bytes the block at the start of buf can occupy: header, tree, one bit per symbol
+        (src/encoder.c:325-348; every code has at least one bit).  0 when the header is not all there."""
+        if len(buf) < 10:
+            return 0
+        block_len = int.from_bytes(buf[0:8], "little")
+        tree_len = int.from_bytes(buf[8:10], "little", signed=True)
+        if tree_len < 0 or tree_len > 1025 or block_len > (1 << 40):
+            return 0                        # the decoder reports what is wrong with it
+        return 10 + 2 * tree_len + (block_len + 7) // 8
 
     def read(self, size: int = -1) -> bytes:
         """Up to `size` uncompressed bytes; everything that is left when size < 0."""

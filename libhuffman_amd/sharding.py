@@ -13,10 +13,23 @@ GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
 
+from datetime import timedelta
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def _all_to_all(out, inp, out_split, in_split, group, timeout: Optional[float]):
+    """all_to_all_single; with `timeout` (seconds) the call is asynchronous and waited for that long -
+    a peer that never arrives raises here instead of holding the caller for ever."""
+    if timeout is None:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        return
+    work = dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=group,
+                                  async_op=True)
+    if work.wait(timeout=timedelta(seconds=timeout)) is False:
+        raise TimeoutError("variable-size all-to-all did not complete in %.0f s" % timeout)
 
 
 def shard_range(n_total: int, blocksize: int, rank: int, world: int) -> Tuple[int, int]:
@@ -96,7 +109,7 @@ def shard_plan(n_total: int, blocksize: int, world: int) -> List[Tuple[int, int]
 # (the sizes of compressed shards come from the size all-gather).
 
 def scatter_from_root(full: Optional[torch.Tensor], sizes: List[int], mine: torch.Tensor, src: int = 0,
-                      group=None) -> torch.Tensor:
+                      group=None, timeout: Optional[float] = None) -> torch.Tensor:
     """Rank `src` holds the concatenation of all shards (`sizes` bytes each, rank order); every
     rank receives its shard into `mine` (sizes[rank] bytes)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -106,12 +119,12 @@ def scatter_from_root(full: Optional[torch.Tensor], sizes: List[int], mine: torc
     else:
         send, in_split = mine.new_empty(0), [0] * world
     out_split = [sizes[rank] if r == src else 0 for r in range(world)]
-    dist.all_to_all_single(mine, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    _all_to_all(mine, send, out_split, in_split, group, timeout)
     return mine
 
 
 def gather_to_root(local: torch.Tensor, sizes: List[int], out: Optional[torch.Tensor], dst: int = 0,
-                   group=None) -> Optional[torch.Tensor]:
+                   group=None, timeout: Optional[float] = None) -> Optional[torch.Tensor]:
     """Inverse of scatter_from_root with sizes known everywhere: rank r's `local` (sizes[r] bytes)
     lands at offset sum(sizes[:r]) of `out` on rank `dst`."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -121,18 +134,18 @@ def gather_to_root(local: torch.Tensor, sizes: List[int], out: Optional[torch.Te
         recv, out_split = out[: sum(sizes)], list(sizes)
     else:
         recv, out_split = local.new_empty(0), [0] * world
-    dist.all_to_all_single(recv, local, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    _all_to_all(recv, local, out_split, in_split, group, timeout)
     return out if rank == dst else None
 
 
-def gatherv_to_root(local: torch.Tensor, local_len: int, dst: int = 0, group=None):
+def gatherv_to_root(local: torch.Tensor, local_len: int, dst: int = 0, group=None, timeout: Optional[float] = None):
     """Variable-size gather of the compressed shards: sizes are exchanged first (all-gather of one
     int64 per rank), then the shards travel.  Returns (stream on `dst` or None, sizes list)."""
     sizes, _ = exchange_stream_offsets(torch.tensor([local_len], dtype=torch.int64, device=local.device), group)
     sizes_h = [int(x) for x in sizes.tolist()]
     rank = dist.get_rank(group)
     out = torch.empty(sum(sizes_h), dtype=torch.uint8, device=local.device) if rank == dst else None
-    gather_to_root(local[:local_len], sizes_h, out, dst, group)
+    gather_to_root(local[:local_len], sizes_h, out, dst, group, timeout)
     return out, sizes_h
 
 

@@ -227,6 +227,36 @@ def test_read_is_streaming_in_bounded_rounds(tmp_path, monkeypatch):
 
 
 @gpu
+def test_one_block_file_is_not_decoded_piece_by_piece(tmp_path, monkeypatch):
+    """blocksize = 0 (the reference's default: the whole file is ONE block, src/encoder.c:163-165) with a block
+    far larger than a read round: the header says how many bytes the block must at least have, so no decode is
+    attempted on a prefix that cannot hold it, and later reads grow geometrically - a handful of decode calls,
+    not one per piece.  A failed read stays failed."""
+    import io as _io
+    data = datagen.zipf255(3 << 20).tobytes()
+    name = tmp_path / "one.hm"
+    with huffmanfile.HuffmanFile(name, "w", blocksize=0) as f:
+        f.write(data)
+    monkeypatch.setattr(huffmanfile.HuffmanFile, "READ_PIECE", 64 << 10)
+    calls = []
+    real = huffmanfile.HuffmanDecompressor.decompress_blocks
+
+    def counting(self, buf):
+        calls.append(len(buf))
+        return real(self, buf)
+    monkeypatch.setattr(huffmanfile.HuffmanDecompressor, "decompress_blocks", counting)
+    with huffmanfile.HuffmanFile(name, "r") as f:
+        assert f.read() == data
+    assert 1 <= len(calls) <= 6, calls                       # (48 pieces of 64 KiB would be 48 growing decodes)
+    raw = name.read_bytes()
+    with huffmanfile.HuffmanFile(_io.BytesIO(raw[:len(raw) // 2]), "r") as f:
+        for _ in range(2):                                    # the second read raises again instead of returning b""
+            with pytest.raises(huffmanfile.HuffmanError) as ei:
+                f.read(100)
+            assert "read/write" in str(ei.value)
+
+
+@gpu
 def test_decode_blocks_pieces_through_the_c_api():
     """huf_gpu_decode_blocks: whole blocks inside the piece are decoded, *consumed stops in front of a
     cut-off block (no error), a damaged block is still huf_decode's error."""

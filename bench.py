@@ -330,8 +330,9 @@ class Bench:
                    "tree": nb * (1024 + 2048 + 2064), "scan_sizes": nb * 24, "prepare_scan": nb * (16 + 10 + 28)}
             if workload == "const41":
                 alg["pack"] = comp_len          # one-symbol blocks: the input is not read again, the payload is zeros
-            # blocks below 4 MiB take the fused histogram+tree kernel: its time is reported once
-            fused = bs < (1 << 22)
+            # blocks below 32 KiB take the fused histogram+tree kernel: its time is reported once; from 32 KiB
+            # (and below 4 MiB) on the counts and the trees are two launches, hist_lanes_kernel and tree_wave_kernel
+            fused = bs < 32768
             if fused:
                 enc_prof = dict(enc_prof)
                 # (the "tree" and "scan_sizes" stages are empty event gaps: that work runs inside the fused kernel)
@@ -351,7 +352,8 @@ class Bench:
                       key=lambda k: kernels[k]["avg_ms"])
             achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
             kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_kernel", "pack": "pack_kernel",
-                            "hist_tree": "hist_tree_kernel", "hist256": "hist256_kernel", "tree": "tree_kernel"}
+                            "hist_tree": "hist_tree_kernel", "hist256": "hist_lanes_kernel" if bs < (1 << 22) else "chunk_hist_kernel",
+                            "tree": "tree_wave_kernel" if bs < (1 << 22) else "tree_kernel"}
             pipeline_bytes = 2 * (n + comp_len)     # the metric's bytes (side tables are implementation traffic)
             gpu_ms = ev0.elapsed_time(ev1) / K
             # encode-only / decode-only: this rank's bytes over the kernels of each half

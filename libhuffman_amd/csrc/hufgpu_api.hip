@@ -505,17 +505,29 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
 
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
     TwoLevel sizes = ctx->enc_sizes;
+    static const bool fused_only = getenv("HUF_GPU_FUSED_HIST") && atoi(getenv("HUF_GPU_FUSED_HIST")) != 0;   /* (measurements: the one-launch form) */
     if (blocksize < HUF_BIG_BLOCK) {
         /* counts, tree and the sums of the encoded sizes in one launch (the profile's "tree" and
          * "scan_sizes" stages are then empty) */
         sizes.total = offs + nb;
+        if (blocksize >= HL_MIN_BLOCK && !fused_only) {
+            /* counts with lane-private counters at the rate HBM delivers, then the trees as a launch of their
+             * own (kernels/hist_lanes.hpp): 0.19 + 0.13 ms per GiB on zipf255 where the fused kernel takes 0.44 */
+            hist_lanes_kernel<HL_THREADS><<<dim3((unsigned)nb), dim3(HL_THREADS), 0, s>>>(in, n, blocksize, ctx->d_hist);
+            STAGE_MARK(ctx, s);
+            tree_wave_kernel<<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
+            STAGE_MARK(ctx, s);
+            STAGE_MARK(ctx, s);
+        } else
         if (blocksize <= HT_PACKED_MAX_BLOCK)
             hist_tree_kernel<HIST_THREADS, true><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
         else
             hist_tree_kernel<HIST_THREADS, false><<<dim3((unsigned)nb), dim3(HIST_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
-        STAGE_MARK(ctx, s);
-        STAGE_MARK(ctx, s);
-        STAGE_MARK(ctx, s);
+        if (!(blocksize >= HL_MIN_BLOCK && !fused_only)) {
+            STAGE_MARK(ctx, s);
+            STAGE_MARK(ctx, s);
+            STAGE_MARK(ctx, s);
+        }
     } else {
         /* blocks of HUF_BIG_BLOCK bytes and more are cut into chunks, one workgroup each (blocksize = 0:
          * the whole input is ONE block, src/encoder.c:163-165 - the reference's default) */

@@ -24,6 +24,7 @@
 #include "kernels/tree.hpp"
 #include "kernels/offsets.hpp"
 #include "kernels/hist_tree.hpp"
+#include "kernels/hist_lanes.hpp"
 #include "kernels/pack.hpp"
 #include "kernels/hist_chunk.hpp"
 #include "kernels/pack_chunk.hpp"

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64) void tree_kernel(const H *__restrict__ hist, ui
  *     item's logical index (rate<<9 | 511-index), so the selection order is unchanged.
  *   - The wave minimum is a DPP reduction (quad_perm, row_half_mirror, row_mirror, row_bcast15,
  *     row_bcast31) ending in lane 63 and read back as a scalar: no LDS round trips in the loop.
- *   - Children are written to LDS fire-and-forget; leaf counts are derived after the loop.
+ *   - Children are written to LDS fire-and-forget; a node's leaf count is the sum of its children's, read when
+ *     the node is made (children are always made in an earlier round).
  * ==================================================================================== */
 /* Wave minimum: six v_min_u32 with a DPP source operand (the compiler turns update_dpp + min into
  * mov, mov_dpp, min - three instructions per step; the merge loop runs two of these reductions
@@ -223,33 +224,35 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-/* Bitonic sort of the wave's 256 keys, ascending by sorted position lane * 4 + r (blocked: the
- * keys at positions 2p and 2p + 1 end up in one lane).  Partners 1 or 2 positions apart are
- * registers of the same lane, all others the same register of lane ^ (distance / 4). */
-__device__ __forceinline__ void wave_sort256(uint32_t (&k)[4])
+/* Bitonic sort of the wave's 64 R keys k[0..R-1] (R = 1, 2, 4), ascending by sorted position lane * R + r
+ * (blocked: for R >= 2 the keys at positions 2p and 2p + 1 end up in one lane).  Partners less than R
+ * positions apart are registers of the same lane, all others the same register of lane ^ (distance / R):
+ * DPP / ds_swizzle exchanges (util.hpp), no LDS round trip but for distance 32.  A tree round sorts only as
+ * many registers as its live keys need: 36 compare-exchange stages on four registers for 256 keys, 28 on two
+ * for 128, 21 on one for 64 - the later rounds of a block have a few dozen keys left. */
+template <int R>
+__device__ __forceinline__ void wave_sort_r(uint32_t (&k)[4])
 {
     const uint32_t lane = (uint32_t)lane_id();
 #pragma unroll
-    for (uint32_t kk = 2; kk <= 256; kk <<= 1) {
+    for (uint32_t kk = 2; kk <= 64u * R; kk <<= 1) {
 #pragma unroll
         for (uint32_t jj = kk >> 1; jj >= 1; jj >>= 1) {
-            if (jj >= 4) {
-                const bool up = ((lane * 4u) & kk) == 0u;                 /* this block sorts ascending */
-                const bool lower = (lane & (jj >> 2)) == 0u;              /* I hold the pair's lower position */
+            if (jj >= (uint32_t)R) {
+                const bool up = ((lane * (uint32_t)R) & kk) == 0u;        /* this block sorts ascending */
+                const bool lower = (lane & (jj / R)) == 0u;               /* I hold the pair's lower position */
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    /* the partner lane's key by DPP / ds_swizzle (util.hpp): 72 of a sort's 84 exchanges
-                     * need no LDS round trip any more (the loops are unrolled: d is a constant) */
-                    const uint32_t d = jj >> 2;
+                for (int r = 0; r < R; r++) {
+                    const uint32_t d = jj / R;
                     const uint32_t o = d == 1 ? wave_xor_u32<1>(k[r]) : d == 2 ? wave_xor_u32<2>(k[r]) : d == 4 ? wave_xor_u32<4>(k[r])
                                      : d == 8 ? wave_xor_u32<8>(k[r]) : d == 16 ? wave_xor_u32<16>(k[r]) : wave_xor_u32<32>(k[r]);
                     k[r] = (lower == up) ? dmin(k[r], o) : dmax(k[r], o);
                 }
             } else {
 #pragma unroll
-                for (uint32_t r = 0; r < 4; r++) {
+                for (uint32_t r = 0; r < (uint32_t)R; r++) {
                     if (r & jj) continue;
-                    const bool up = ((lane * 4u + r) & kk) == 0u;
+                    const bool up = ((lane * (uint32_t)R + r) & kk) == 0u;
                     const uint32_t lo = dmin(k[r], k[r | jj]), hi = dmax(k[r], k[r | jj]);
                     k[r] = up ? lo : hi;
                     k[r | jj] = up ? hi : lo;
@@ -258,6 +261,7 @@ __device__ __forceinline__ void wave_sort256(uint32_t (&k)[4])
         }
     }
 }
+__device__ __forceinline__ void wave_sort256(uint32_t (&k)[4]) { wave_sort_r<4>(k); }
 
 struct TreeLds {                  /* 7 KiB: what bounds the tree waves a CU holds (they are latency bound) */
     uint32_t code[HUF_NSLOT];     /* blocks shorter than 2^22 bytes: depth <= 32 */
@@ -333,6 +337,34 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         s_right[256 + slot] = -1;
     }
 
+    /* The live keys sit in the first R registers of every lane (R = 4, 2, 1 for up to 256, 128, 64 keys; the
+     * other registers hold KMAX), because a round's sort costs what its register count costs.  Keys are moved
+     * together through 1 KiB of LDS (the code table's area, not needed before the level sweep): a key's compact
+     * index is its rank among the live ones. */
+    uint32_t *s_scratch = s_code;
+    uint32_t live, R = 4;
+    {
+        const unsigned long long nz0 = __ballot(rate[0] != 0), nz1 = __ballot(rate[1] != 0);
+        const unsigned long long nz2 = __ballot(rate[2] != 0), nz3 = __ballot(rate[3] != 0);
+        const uint32_t c0 = (uint32_t)__popcll(nz0), c1 = (uint32_t)__popcll(nz1), c2 = (uint32_t)__popcll(nz2), c3 = (uint32_t)__popcll(nz3);
+        live = c0 + c1 + c2 + c3;
+        if (live <= 128u) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (rate[0]) s_scratch[(uint32_t)__popcll(nz0 & below)] = k[0];
+            if (rate[1]) s_scratch[c0 + (uint32_t)__popcll(nz1 & below)] = k[1];
+            if (rate[2]) s_scratch[c0 + c1 + (uint32_t)__popcll(nz2 & below)] = k[2];
+            if (rate[3]) s_scratch[c0 + c1 + c2 + (uint32_t)__popcll(nz3 & below)] = k[3];
+            TREE_WAVE_SYNC();
+            R = live <= 64u ? 1u : 2u;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                const uint32_t c = (uint32_t)lane * R + r;
+                k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
+            }
+            TREE_WAVE_SYNC();
+        }
+    }
+
     int node = HUF_NSYM;
     int root = -1;
     for (;;) {
@@ -344,7 +376,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         const uint32_t b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
         const int i1 = 511 - (int)(a & 511u);
         if (b == KMAX) {                                           /* tree.c:410-413: left-only wrap root */
-            if (lane == 0) s_left[node] = (int16_t)i1;
+            if (lane == 0) { s_left[node] = (int16_t)i1; s_lcnt[node] = s_lcnt[i1]; }
             root = node;
             node++;
             break;
@@ -353,30 +385,85 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
          * is at least that), so all of them pair up in key order no matter what is merged first:
          * when there are enough, sort the wave's keys once and merge all those pairs in one step
          * (pair p = sorted positions 2p, 2p + 1 -> node + p: the sequential order of tree.c:355-407).
-         * Typical blocks take ~10 such rounds instead of 255 merges with two wave minima each
-         * (4x less latency for the block's tree); a block that never offers TREE_ROUND_MIN items
-         * at once (Fibonacci-like counts) falls through to the single merge below. */
+         * Typical blocks take 5-7 such rounds instead of 255 merges with two wave minima each; a block
+         * that never offers enough items at once (Fibonacci-like counts) falls through to the single
+         * merge below.  "Enough" is what makes the sort cheaper than the single merges it replaces. */
         {
             const uint32_t thr = (a >> 9) + (b >> 9);
             uint32_t sel = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) sel += (uint32_t)__popcll(__ballot((k[j] >> 9) < thr));
-            if (sel >= TREE_ROUND_MIN) {
-                wave_sort256(k);
+            const uint32_t round_min = R == 4u ? TREE_ROUND_MIN : (R == 2u ? TREE_ROUND_MIN / 2u : TREE_ROUND_MIN / 4u);
+            if (sel >= round_min) {
                 const uint32_t pairs = sel >> 1;
+                if (R == 4u) {
+                    wave_sort_r<4>(k);
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t p = 2u * (uint32_t)lane + (uint32_t)h;
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t p = 2u * (uint32_t)lane + (uint32_t)h;
+                        if (p < pairs) {
+                            const uint32_t x = k[2 * h], y = k[2 * h + 1];
+                            const int n = node + (int)p;
+                            const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
+                            s_left[n] = (int16_t)xi;
+                            s_right[n] = (int16_t)yi;
+                            s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);   /* children were made in earlier rounds */
+                            k[2 * h] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
+                            k[2 * h + 1] = KMAX;
+                        }
+                    }
+                } else if (R == 2u) {
+                    wave_sort_r<2>(k);
+                    const uint32_t p = (uint32_t)lane;
                     if (p < pairs) {
-                        const uint32_t x = k[2 * h], y = k[2 * h + 1];
+                        const uint32_t x = k[0], y = k[1];
                         const int n = node + (int)p;
-                        s_left[n] = (int16_t)(511 - (int)(x & 511u));
-                        s_right[n] = (int16_t)(511 - (int)(y & 511u));
-                        k[2 * h] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
-                        k[2 * h + 1] = KMAX;
+                        const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
+                        s_left[n] = (int16_t)xi;
+                        s_right[n] = (int16_t)yi;
+                        s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);
+                        k[0] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
+                        k[1] = KMAX;
+                    }
+                } else {
+                    wave_sort_r<1>(k);
+                    const uint32_t p = (uint32_t)lane >> 1;
+                    const uint32_t o = wave_xor_u32<1>(k[0]);              /* the pair's other key */
+                    if (p < pairs) {
+                        if ((lane & 1) == 0) {
+                            const uint32_t x = k[0], y = o;
+                            const int n = node + (int)p;
+                            const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
+                            s_left[n] = (int16_t)xi;
+                            s_right[n] = (int16_t)yi;
+                            s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);
+                            k[0] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
+                        } else {
+                            k[0] = KMAX;
+                        }
                     }
                 }
                 node += (int)pairs;
+                const uint32_t was = live;                           /* keys at positions < was are live or just paired */
+                live -= pairs;
+                const uint32_t nr = live <= 64u ? 1u : (live <= 128u ? 2u : 4u);
+                if (nr < R) {
+                    /* fewer registers from here on: new node p (at position 2p) becomes key p, a key that was
+                     * not paired (position q >= 2 pairs) key q - pairs */
+#pragma unroll
+                    for (uint32_t r = 0; r < 4; r++) {
+                        const uint32_t q = (uint32_t)lane * R + r;
+                        if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? (q >> 1) : (q - pairs)] = k[r];
+                    }
+                    TREE_WAVE_SYNC();
+                    R = nr;
+#pragma unroll
+                    for (uint32_t r = 0; r < 4; r++) {
+                        const uint32_t c = (uint32_t)lane * R + r;
+                        k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
+                    }
+                    TREE_WAVE_SYNC();
+                }
                 continue;
             }
         }
@@ -387,30 +474,15 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         if (lane == 0) {
             s_left[node] = (int16_t)i1;                            /* tree.c:390-404 */
             s_right[node] = (int16_t)i2;
+            s_lcnt[node] = (uint16_t)(s_lcnt[i1] + s_lcnt[i2]);
         }
         node++;
+        live--;
     }
     TREE_WAVE_SYNC();
     const int nodes = node;
 
-    /* leaves below every internal node: children always have smaller indices, so a few rounds of
-     * "both children known -> sum" settle it (one tree level per round) */
-    for (int round = 0; round < HUF_NSLOT; round++) {
-        bool pending = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int slot = 256 + lane + 64 * j;
-            if (slot < nodes && s_lcnt[slot] == 0xffffu) {
-                const int l = s_left[slot], r = s_right[slot];
-                const uint32_t cl = s_lcnt[l];
-                const uint32_t cr = (r >= 0) ? (uint32_t)s_lcnt[r] : 0u;
-                if (cl != 0xffffu && cr != 0xffffu) s_lcnt[slot] = (uint16_t)(cl + cr);
-                else pending = true;
-            }
-        }
-        TREE_WAVE_SYNC();
-        if (!__any(pending)) break;
-    }
+    /* (leaves below every internal node: summed when the node was made - its children are older) */
     const int nleaves = (root >= 0) ? (int)s_lcnt[root] : 0;
     const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
 

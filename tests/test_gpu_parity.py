@@ -225,7 +225,7 @@ def test_one_symbol_payload_stray_bits(torch_mod, codec, oracle):
                 d_bad, d_offs = to_dev(torch, bad), torch.from_numpy(offs.astype(np.int64)).cuda()
                 err = codec.lib.hufgpu_decode(codec._ctx, d_bad.data_ptr(), bad.size, d_offs.data_ptr(), offs.size - 1,
                                               out.data_ptr(), cap, 0, C.byref(raw), None)
-                want_raw = oout.size if oerr == 0 else b * bs        # indexed: the bytes in front of the failing block
+                want_raw = oout.size            # indexed too: the blocks in front AND the failing block's symbols before the failure (decoder.c:69-91)
                 assert (err, raw.value) == (oerr, want_raw), (bs, lead, bit, err, oerr, raw.value, want_raw)
                 assert np.array_equal(out[:oout.size].cpu().numpy(), oout), (bs, lead, bit)
                 for sequential in (False, True):

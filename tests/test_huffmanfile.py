@@ -235,7 +235,7 @@ def test_one_block_file_is_not_decoded_piece_by_piece(tmp_path, monkeypatch):
     import io as _io
     data = datagen.zipf255(3 << 20).tobytes()
     name = tmp_path / "one.hm"
-    with huffmanfile.HuffmanFile(name, "w", blocksize=0) as f:
+    with huffmanfile.HuffmanFile(name, "w", blocksize=len(data)) as f:    # one block, as the C API's blocksize = 0 writes it
         f.write(data)
     monkeypatch.setattr(huffmanfile.HuffmanFile, "READ_PIECE", 64 << 10)
     calls = []

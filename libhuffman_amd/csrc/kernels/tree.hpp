@@ -263,14 +263,27 @@ __device__ __forceinline__ void wave_sort_r(uint32_t (&k)[4])
 }
 __device__ __forceinline__ void wave_sort256(uint32_t (&k)[4]) { wave_sort_r<4>(k); }
 
-struct TreeLds {                  /* 7 KiB: what bounds the tree waves a CU holds (they are latency bound) */
-    uint32_t code[HUF_NSLOT];     /* blocks shorter than 2^22 bytes: depth <= 32 */
-    int16_t left[HUF_NSLOT];
-    int16_t right[HUF_NSLOT];
-    uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot, 0xffff = not known yet */
-    uint16_t depth[HUF_NSLOT];    /* 0xffff = not reached */
-    uint16_t pos[HUF_NSLOT];      /* preorder position */
+struct TreeLds {                  /* 6 KiB: what bounds the tree waves a CU holds (they are latency bound) */
+    uint64_t state[HUF_NSLOT];    /* per node: its path to an ancestor, see TREE_STATE below */
+    uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot */
+    uint32_t scratch[HUF_NSYM];   /* keys on their way into fewer registers */
 };
+
+/* A node's state while codes, depths and preorder positions are worked out: the path from the node up to
+ * an ancestor `anc` - how many edges (depth), the turns taken on them (code, first turn in the highest bit
+ * used), and how many entries the serialized tree has between the ancestor's and the node's (pos).  When a
+ * node is made its two children get (anc = the node, depth 1, code 0 / 1, pos 1 / 4 * leaves of the left
+ * child - a subtree with L leaves holds 4L - 1 entries and the right child follows the left subtree).
+ * Paths are then doubled - state(n) := state(n) + state(anc(n)) - until every anc is the root: at most five
+ * rounds for depth <= 32, whatever the order the lanes' updates land in (a node's state is ONE 64-bit LDS
+ * word, read and written whole, and every state it can have IS a valid path).  The level-by-level sweep this
+ * replaces cost one pass over all slots per tree level: ~2 400 instructions where this has ~600.
+ * low word: anc (10 bits, TREE_ANC_ROOT = reached) | depth << 10 (6 bits) | pos << 16 (11 bits); high: code. */
+#define TREE_ANC_ROOT 0x3ffu
+__device__ __forceinline__ uint64_t tree_state(uint32_t anc, uint32_t depth, uint32_t pos, uint32_t code)
+{
+    return ((uint64_t)code << 32) | (uint64_t)(anc | (depth << 10) | (pos << 16));
+}
 
 /* Single-wave synchronisation: LDS operations of one wave are in order, so only the compiler and
  * the LDS counter have to be fenced.  (The fused kernel calls this after its other waves have
@@ -291,9 +304,8 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                                                hufcode_t *__restrict__ codetab, int16_t *__restrict__ treebuf,
                                                HufBlockMeta *__restrict__ meta)
 {
-    int16_t *s_left = L.left, *s_right = L.right;
-    uint16_t *s_lcnt = L.lcnt, *s_depth = L.depth, *s_pos = L.pos;
-    uint32_t *s_code = L.code;
+    uint64_t *s_state = L.state;
+    uint16_t *s_lcnt = L.lcnt;
     const uint32_t KMAX = 0xffffffffu;
     const int lane = lane_id();
 
@@ -330,18 +342,13 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         const int slot = lane + 64 * j;
         k[j] = rate[j] ? ((rate[j] << 9) | (uint32_t)(511 - slot)) : KMAX;
         s_lcnt[slot] = rate[j] ? 1 : 0;
-        s_lcnt[256 + slot] = 0xffffu;
-        s_depth[slot] = 0xffffu;
-        s_depth[256 + slot] = 0xffffu;
-        s_left[256 + slot] = -1;
-        s_right[256 + slot] = -1;
     }
 
     /* The live keys sit in the first R registers of every lane (R = 4, 2, 1 for up to 256, 128, 64 keys; the
      * other registers hold KMAX), because a round's sort costs what its register count costs.  Keys are moved
-     * together through 1 KiB of LDS (the code table's area, not needed before the level sweep): a key's compact
+     * together through 1 KiB of LDS: a key's compact
      * index is its rank among the live ones. */
-    uint32_t *s_scratch = s_code;
+    uint32_t *s_scratch = L.scratch;
     uint32_t live, R = 4;
     {
         const unsigned long long nz0 = __ballot(rate[0] != 0), nz1 = __ballot(rate[1] != 0);
@@ -376,7 +383,10 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         const uint32_t b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
         const int i1 = 511 - (int)(a & 511u);
         if (b == KMAX) {                                           /* tree.c:410-413: left-only wrap root */
-            if (lane == 0) { s_left[node] = (int16_t)i1; s_lcnt[node] = s_lcnt[i1]; }
+            if (lane == 0) {
+                s_state[i1] = tree_state((uint32_t)node, 1u, 1u, 0u);
+                s_lcnt[node] = s_lcnt[i1];
+            }
             root = node;
             node++;
             break;
@@ -405,9 +415,10 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                             const uint32_t x = k[2 * h], y = k[2 * h + 1];
                             const int n = node + (int)p;
                             const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
-                            s_left[n] = (int16_t)xi;
-                            s_right[n] = (int16_t)yi;
-                            s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);   /* children were made in earlier rounds */
+                            const uint32_t lx = s_lcnt[xi];                          /* children were made in earlier rounds */
+                            s_state[xi] = tree_state((uint32_t)n, 1u, 1u, 0u);
+                            s_state[yi] = tree_state((uint32_t)n, 1u, 4u * lx, 1u);
+                            s_lcnt[n] = (uint16_t)(lx + s_lcnt[yi]);
                             k[2 * h] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
                             k[2 * h + 1] = KMAX;
                         }
@@ -419,9 +430,10 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                         const uint32_t x = k[0], y = k[1];
                         const int n = node + (int)p;
                         const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
-                        s_left[n] = (int16_t)xi;
-                        s_right[n] = (int16_t)yi;
-                        s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);
+                        const uint32_t lx = s_lcnt[xi];
+                        s_state[xi] = tree_state((uint32_t)n, 1u, 1u, 0u);
+                        s_state[yi] = tree_state((uint32_t)n, 1u, 4u * lx, 1u);
+                        s_lcnt[n] = (uint16_t)(lx + s_lcnt[yi]);
                         k[0] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
                         k[1] = KMAX;
                     }
@@ -434,9 +446,10 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                             const uint32_t x = k[0], y = o;
                             const int n = node + (int)p;
                             const int xi = 511 - (int)(x & 511u), yi = 511 - (int)(y & 511u);
-                            s_left[n] = (int16_t)xi;
-                            s_right[n] = (int16_t)yi;
-                            s_lcnt[n] = (uint16_t)(s_lcnt[xi] + s_lcnt[yi]);
+                            const uint32_t lx = s_lcnt[xi];
+                            s_state[xi] = tree_state((uint32_t)n, 1u, 1u, 0u);
+                            s_state[yi] = tree_state((uint32_t)n, 1u, 4u * lx, 1u);
+                            s_lcnt[n] = (uint16_t)(lx + s_lcnt[yi]);
                             k[0] = (((x >> 9) + (y >> 9)) << 9) | (uint32_t)(511 - n);
                         } else {
                             k[0] = KMAX;
@@ -472,61 +485,64 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
 #pragma unroll
         for (int j = 0; j < 4; j++) k[j] = (k[j] == a) ? nk : ((t[j] == b) ? KMAX : t[j]);
         if (lane == 0) {
-            s_left[node] = (int16_t)i1;                            /* tree.c:390-404 */
-            s_right[node] = (int16_t)i2;
-            s_lcnt[node] = (uint16_t)(s_lcnt[i1] + s_lcnt[i2]);
+            const uint32_t lx = s_lcnt[i1];                        /* tree.c:390-404 */
+            s_state[i1] = tree_state((uint32_t)node, 1u, 1u, 0u);
+            s_state[i2] = tree_state((uint32_t)node, 1u, 4u * lx, 1u);
+            s_lcnt[node] = (uint16_t)(lx + s_lcnt[i2]);
         }
         node++;
         live--;
     }
+    if (lane == 0 && root >= 0) s_state[root] = tree_state(TREE_ANC_ROOT, 0u, 0u, 0u);
     TREE_WAVE_SYNC();
     const int nodes = node;
-
-    /* (leaves below every internal node: summed when the node was made - its children are older) */
     const int nleaves = (root >= 0) ? (int)s_lcnt[root] : 0;
     const int tree_len = (root >= 0) ? 4 * nleaves + 1 : 1;
 
-    if (lane == 0 && root >= 0) {
-        s_depth[root] = 0;
-        s_code[root] = 0;
-        s_pos[root] = 0;
-    }
-    TREE_WAVE_SYNC();
-
-    /* level sweep: codes, depths, preorder positions (see tree_kernel).  The serialized tree goes
-     * straight to HBM: a node at position p writes its index there, a leaf also the two -1 of its
-     * absent children behind it, and a node without a right child (the wrap root) the -1 where
-     * that child would start - together exactly the 4k+1 entries, each written once. */
-    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
-    for (int d = 0; d < HUF_NSLOT; d++) {
-        bool any = false;
+    /* paths doubled until every node has reached the root (TREE_STATE above); a lane keeps the states of its
+     * eight slots (leaves lane + 64 j, nodes 256 + lane + 64 j) in registers and publishes every update */
+    uint32_t w0[8], w1[8];
+    bool have[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int slot = 256 + lane + 64 * j;
-            if (slot < nodes && s_depth[slot] == (uint16_t)d) {
-                any = true;
-                const int l = s_left[slot], r = s_right[slot];
-                const uint32_t c = s_code[slot];
-                const int p = s_pos[slot];
-                tb[p] = (int16_t)slot;
-                s_depth[l] = (uint16_t)(d + 1);
-                s_code[l] = c << 1;
-                s_pos[l] = (uint16_t)(p + 1);
-                if (l < HUF_NSYM) { tb[p + 1] = (int16_t)l; tb[p + 2] = -1; tb[p + 3] = -1; }
-                const int pr = p + 4 * (int)s_lcnt[l];
-                if (r >= 0) {
-                    s_depth[r] = (uint16_t)(d + 1);
-                    s_code[r] = (c << 1) | 1u;
-                    s_pos[r] = (uint16_t)pr;
-                    if (r < HUF_NSYM) { tb[pr] = (int16_t)r; tb[pr + 1] = -1; tb[pr + 2] = -1; }
-                } else {
-                    tb[pr] = -1;
-                }
+    for (int j = 0; j < 8; j++) {
+        const int slot = lane + 64 * j;
+        have[j] = (j < 4) ? (rate[j & 3] != 0) : (slot < nodes);
+        const uint64_t st = have[j] ? s_state[slot] : tree_state(TREE_ANC_ROOT, 0u, 0u, 0u);
+        w0[j] = (uint32_t)st;
+        w1[j] = (uint32_t)(st >> 32);
+    }
+#pragma unroll 1
+    for (int round = 0; round < 6; round++) {
+        bool pending = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t anc = w0[j] & 0x3ffu;
+            if (anc != TREE_ANC_ROOT) {
+                const uint64_t up = s_state[anc];
+                const uint32_t u0 = (uint32_t)up, u1 = (uint32_t)(up >> 32);
+                w1[j] |= u1 << ((w0[j] >> 10) & 63u);               /* my turns follow the ancestor's (own depth <= 31 here) */
+                w0[j] = ((w0[j] & ~0x3ffu) + (u0 & ~0x3ffu)) | (u0 & 0x3ffu);
+                s_state[lane + 64 * j] = ((uint64_t)w1[j] << 32) | w0[j];
+                pending = pending || (u0 & 0x3ffu) != TREE_ANC_ROOT;
             }
         }
-        TREE_WAVE_SYNC();
-        if (!__any(any)) break;
+        if (!__any(pending)) break;
     }
+
+    /* The serialized tree goes straight to HBM: a node at preorder position p writes its index there, a leaf
+     * also the two -1 of its absent children behind it, and the wrap root (the only node without a right
+     * child) the -1 where that child would start, the last entry - together exactly the 4k+1 entries, each
+     * written once. */
+    int16_t *tb = treebuf + blk * HUF_TREE_STRIDE;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (have[j]) {
+            const uint32_t p = w0[j] >> 16;
+            tb[p] = (int16_t)(lane + 64 * j);
+            if (j < 4) { tb[p + 1] = -1; tb[p + 2] = -1; }
+        }
+    }
+    if (lane == 0 && root >= 0) tb[tree_len - 1] = -1;
 
     uint64_t bits = 0;
     uint32_t maxlen = 0;
@@ -535,8 +551,9 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         const int slot = lane + 64 * j;
         hufcode_t e = 0;
         if (rate[j]) {
-            const uint32_t len = s_depth[slot];
-            e = ((hufcode_t)s_code[slot] << 8) | (hufcode_t)len;
+            const uint32_t len = (w0[j] >> 10) & 63u;
+            /* the path's turns, root first: `len` bits, the first turn in bit len - 1 */
+            e = ((hufcode_t)w1[j] << 8) | (hufcode_t)len;
             bits += (uint64_t)rate[j] * len;
             maxlen = dmax(maxlen, len);
         }

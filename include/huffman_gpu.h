@@ -139,6 +139,18 @@ int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail
                          void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                          uint64_t *consumed, void *stream);
 
+/*
+ * The block index of a raw stream (what hufgpu_decode() wants) without decoding the stream into an output
+ * buffer: every candidate header is probed count-only and the chain from offset 0 is walked
+ * (kernels/discover.hpp).  *d_index = device array of *nblocks + 1 header offsets owned by the context (valid
+ * until its next decode call), the last one = *consumed, the stream offset behind the validated blocks.
+ * *nblocks = 0: nothing could be validated (a damaged or tiny stream - hufgpu_decode_stream() reports what is
+ * wrong with it).  d_stream must be 16-byte aligned.  For callers that spread the decode of ONE stream over
+ * several devices (huf_decode() with HUF_GPU_DEVICES, src/decoder.c:218-276: blocks are independent once found).
+ */
+int hufgpu_block_index(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length, uint32_t flags,
+                       const uint64_t **d_index, uint64_t *nblocks, uint64_t *consumed, void *stream);
+
 /* Of the last hufgpu_decode_stream() call: the stream bytes and output bytes of the blocks that
  * decoded COMPLETELY (on success all of them; after an error the position in front of the failing
  * block - what a caller that feeds a stream piecewise keeps for its next piece). */
@@ -196,6 +208,12 @@ int huf_gpu_decode_blocks(const struct __huf_encoder_config *config, uint64_t *c
  * on different sessions, so a multi-threaded caller uses every listed GPU.  Returns the sessions that
  * hold a context so far; *configured = the length of the list. */
 int huf_gpu_sessions(int *configured);
+
+/* With several sessions configured and free, ONE huf_encode() / huf_decode() between memory streams is spread
+ * over them: the encoder deals out rounds of whole blocks, the decoder finds the stream's blocks on one device
+ * (hufgpu_block_index) and deals out block ranges balanced by compressed bytes (src/decoder.c:218-276: blocks
+ * are independent once found).  Counts of the calls of this process that went that way; returns their sum. */
+int huf_gpu_fanouts(int *encodes, int *decodes);
 
 /* huf_gpu_copy_out: memcpy for a binding that must hand a result over as an object of its own (the
  * Python layer's `bytes`): `dst` is fresh memory, where a plain memcpy runs at page-fault speed.

@@ -1240,6 +1240,8 @@ typedef struct {
     std::atomic<int> err;
 } fanout_t;
 
+static std::atomic<int> g_fanout_decodes(0), g_fanout_encodes(0);     /* huf_gpu_fanouts() */
+
 typedef struct { fanout_t *f; session_t *session; int extra; } fanout_worker_t;   /* extra: not the call's own session */
 
 #define HUF_MAX_LINKS 64
@@ -1401,6 +1403,7 @@ static int encode_fanout(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf
         if (err == HUF_ERROR_SUCCESS && p < nrounds) err = HUF_ERROR_FATAL;   /* (cannot happen: every round was taken) */
         wmem->len += total;
         rmem->off += (p == nrounds) ? length : p * round_bytes;
+        if (err == HUF_ERROR_SUCCESS) g_fanout_encodes.fetch_add(1);
     }
     for (int i = 0; i < nextra; i++) session_release_extra(extra[i]);
     free(f.out_len);
@@ -1651,6 +1654,167 @@ static huf_error_t decode_from_fd(huf_decoder_t *dec, int rfd, membuf_t *wmem, i
 
 /* pieces = NULL: huf_decode().  pieces != NULL: huf_gpu_decode_blocks() - only the blocks that lie
  * completely inside `length` bytes, *pieces = their stream bytes, a cut-off last block is no error. */
+/* One huf_decode() over several sessions (the twin of encode_fanout): memory stream -> memory stream, sessions
+ * free.  Blocks are independent once they are found (src/decoder.c:218-276), and finding them is a device job
+ * of a few milliseconds per GiB (hufgpu_block_index: every candidate header probed count-only, the chain
+ * walked).  So: the stream goes to the call's own device, its block index comes back, the blocks are dealt out
+ * in contiguous ranges balanced by COMPRESSED bytes, and every session - a thread of its own -
+ * takes its range of the stream from host memory, decodes it with the indexed kernels and writes its output
+ * where it belongs (the sum of the block_len fields in front of it).  Anything unusual - a stream the walk
+ * cannot validate to its end, an error in any range - leaves the whole call to the ordinary path, which
+ * reports what the reference reports; nothing has been committed by then. */
+
+typedef struct {
+    const char *src;                /* the stream in host memory */
+    char *dst;                      /* the output's place in the writer's buffer */
+    const uint64_t *offs;           /* nblocks + 1 header offsets (host) */
+    const uint64_t *outoff;         /* nblocks + 1 output offsets (host) */
+    uint64_t b0, b1;                /* this worker's blocks */
+    uint32_t flags;
+    session_t *session;
+    int own;                        /* the call's own session: the stream is already on its device (at d_a) */
+    const uint64_t *d_index;        /* own: the device index */
+    int rc;
+} dfan_worker_t;
+
+static void *dfan_main(void *arg)
+{
+    dfan_worker_t *w = (dfan_worker_t *)arg;
+    w->rc = HUF_ERROR_SUCCESS;
+    if (w->b1 <= w->b0) return NULL;
+    session_t *const before = t_session;
+    t_session = w->session;
+    int rc = session_acquire();
+    const uint64_t nb = w->b1 - w->b0;
+    const uint64_t s0 = w->offs[w->b0], s1 = w->offs[w->b1];
+    const uint64_t raw = w->outoff[w->b1] - w->outoff[w->b0];
+    pthread_mutex_t *dir = g_link_lock[(unsigned)w->session->device % HUF_MAX_LINKS];
+    uint64_t got = 0;
+    if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_b, &g_stage.d_b_cap, raw + 16);
+    if (rc == HUF_ERROR_SUCCESS && w->own) {
+        rc = hufgpu_decode(g_ctx, g_stage.d_a, s1, w->d_index + w->b0, nb, g_stage.d_b, g_stage.d_b_cap, w->flags, &got, NULL);
+    } else if (rc == HUF_ERROR_SUCCESS) {
+        uint64_t *rel = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
+        if (!rel) rc = HUF_ERROR_MEMORY_ALLOCATION;
+        if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_a, &g_stage.d_a_cap, s1 - s0 + 16);
+        if (rc == HUF_ERROR_SUCCESS) rc = grow_dev(&g_stage.d_c, &g_stage.d_c_cap, (nb + 1) * sizeof(uint64_t));
+        if (rc == HUF_ERROR_SUCCESS) {
+            for (uint64_t i = 0; i <= nb; i++) rel[i] = w->offs[w->b0 + i] - s0;
+            pthread_mutex_lock(&dir[0]);
+            rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, w->src + s0, s1 - s0);
+            if (rc == HUF_ERROR_SUCCESS) rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_c, rel, (nb + 1) * sizeof(uint64_t));
+            pthread_mutex_unlock(&dir[0]);
+        }
+        if (rc == HUF_ERROR_SUCCESS)
+            rc = hufgpu_decode(g_ctx, g_stage.d_a, s1 - s0, (const uint64_t *)g_stage.d_c, nb, g_stage.d_b, g_stage.d_b_cap, w->flags,
+                               &got, NULL);
+        free(rel);
+    }
+    if (rc == HUF_ERROR_SUCCESS && got != raw) rc = HUF_ERROR_FATAL;       /* (the block_len fields said otherwise) */
+    if (rc == HUF_ERROR_SUCCESS) {
+        pthread_mutex_lock(&dir[1]);
+        rc = hufgpu_memcpy_d2h(g_ctx, w->dst + w->outoff[w->b0], g_stage.d_b, raw);
+        pthread_mutex_unlock(&dir[1]);
+    }
+    w->rc = rc;
+    t_session = before;
+    return NULL;
+}
+
+/* returns 1 when the call was done here (*result = its outcome), 0 when the ordinary path should run */
+static int decode_fanout(huf_decoder_t *dec, membuf_t *rmem, membuf_t *wmem, uint32_t flags, huf_error_t *result)
+{
+    const uint64_t length = dec->config->length;
+    if (!rmem || !wmem || wmem->readonly || g_nsessions < 2) return 0;
+    if (rmem->len - rmem->off < length) return 0;
+    const char *env = getenv("HUF_GPU_FANOUT_MIN_MB");
+    const uint64_t min_bytes = (uint64_t)(env && atoi(env) > 0 ? atoi(env) : 64) << 20;
+    if (length < min_bytes) return 0;
+    session_t *mine = t_session;
+    session_t *extra[HUF_MAX_SESSIONS];
+    int nextra = 0;
+    while (nextra < HUF_MAX_SESSIONS - 1) {
+        session_t *s = session_try_extra();
+        if (!s) break;
+        extra[nextra++] = s;
+    }
+    if (nextra == 0) return 0;
+    pthread_once(&g_link_once, link_locks_init);
+    const char *src = (const char *)*rmem->buf + rmem->off;
+    uint64_t *offs = NULL, *outoff = NULL;
+    int done = 0;
+    do {
+        /* the stream on the call's own device, and its block index */
+        if (grow_dev(&g_stage.d_a, &g_stage.d_a_cap, length + 16) != HUF_ERROR_SUCCESS) break;
+        if (hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, src, length) != HUF_ERROR_SUCCESS) break;
+        const uint64_t *d_index = NULL;
+        uint64_t nb = 0, used = 0;
+        if (hufgpu_block_index(g_ctx, g_stage.d_a, length, length, flags, &d_index, &nb, &used, NULL) != HUF_ERROR_SUCCESS) break;
+        if (nb < 2 || used != length) break;                          /* not validated to its end: the ordinary path */
+        offs = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
+        outoff = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
+        if (!offs || !outoff) break;
+        if (hufgpu_memcpy_d2h(g_ctx, offs, d_index, (nb + 1) * sizeof(uint64_t)) != HUF_ERROR_SUCCESS) break;
+        outoff[0] = 0;
+        int sane = offs[0] == 0 && offs[nb] == length;
+        for (uint64_t b = 0; b < nb && sane; b++) {
+            if (offs[b + 1] < offs[b] + 10 || offs[b + 1] > length) { sane = 0; break; }
+            uint64_t bl;
+            memcpy(&bl, src + offs[b], sizeof(bl));                   /* block_len, little-endian (src/encoder.c:325) */
+            if (bl > ((uint64_t)1 << 40)) { sane = 0; break; }
+            outoff[b + 1] = outoff[b] + bl;
+        }
+        if (!sane) break;
+        const uint64_t total = outoff[nb];
+        if (mem_reserve(wmem, total) != HUF_ERROR_SUCCESS) break;
+        char *dst = (char *)*wmem->buf + wmem->len;
+        prefault_job_t job;
+        prefault_begin(&job, dst, (size_t)total, 1);
+        prefault_end(&job);
+        /* contiguous block ranges, balanced by compressed bytes: worker w takes the blocks whose header lies in
+         * its share of the stream */
+        const int nw = nextra + 1;
+        dfan_worker_t workers[HUF_MAX_SESSIONS];
+        int created[HUF_MAX_SESSIONS];
+        pthread_t th[HUF_MAX_SESSIONS];
+        uint64_t b = 0;
+        for (int w = 0; w < nw; w++) {
+            const uint64_t want = (uint64_t)(((unsigned __int128)length * (unsigned)(w + 1)) / (unsigned)nw);
+            uint64_t e = b;
+            while (e < nb && (w == nw - 1 || offs[e] < want)) e++;
+            workers[w].src = src; workers[w].dst = dst; workers[w].offs = offs; workers[w].outoff = outoff;
+            workers[w].b0 = b; workers[w].b1 = e; workers[w].flags = flags;
+            workers[w].session = (w == 0) ? mine : extra[w - 1];
+            workers[w].own = (w == 0);
+            workers[w].d_index = d_index;
+            workers[w].rc = HUF_ERROR_SUCCESS;
+            created[w] = 0;
+            b = e;
+        }
+        for (int w = 1; w < nw; w++) {
+            if (pthread_create(&th[w], NULL, dfan_main, &workers[w]) == 0) created[w] = 1;
+            else workers[w].rc = HUF_ERROR_FATAL;
+        }
+        dfan_main(&workers[0]);
+        t_session = mine;
+        int ok = workers[0].rc == HUF_ERROR_SUCCESS;
+        for (int w = 1; w < nw; w++) {
+            if (created[w]) pthread_join(th[w], NULL);
+            ok = ok && workers[w].rc == HUF_ERROR_SUCCESS;
+        }
+        if (!ok) break;                                               /* nothing committed: the ordinary path decides */
+        wmem->len += total;
+        rmem->off += length;
+        g_fanout_decodes.fetch_add(1);
+        *result = huf_bufio_read_writer_flush(dec->bufio_writer);
+        done = 1;
+    } while (0);
+    free(offs);
+    free(outoff);
+    for (int i = 0; i < nextra; i++) session_release_extra(extra[i]);
+    return done;
+}
+
 static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
 {
     const uint64_t length = dec->config->length;
@@ -1666,6 +1830,10 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
      * needs more input, ask the reader for more and decode again. */
     membuf_t *rmem = zero_copy_enabled() ? own_memstream_reader(dec->config->reader) : NULL;
     membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(dec->config->writer) : NULL;
+    if (!pieces) {
+        huf_error_t fan = HUF_ERROR_SUCCESS;
+        if (decode_fanout(dec, rmem, wmem, flags, &fan)) return fan;
+    }
     size_t avail = 0;
     const char *in_ptr = NULL;              /* host bytes [0, avail) of the input */
     const size_t start_off = rmem ? rmem->off : 0;
@@ -1814,6 +1982,14 @@ int huf_gpu_copy_out(void *dst, const void *src, size_t n)
 }
 
 /* sessions that hold a device context right now, and how many the device list allows */
+/* how many huf_encode() / huf_decode() calls of this process were spread over several sessions */
+int huf_gpu_fanouts(int *encodes, int *decodes)
+{
+    if (encodes) *encodes = g_fanout_encodes.load();
+    if (decodes) *decodes = g_fanout_decodes.load();
+    return g_fanout_encodes.load() + g_fanout_decodes.load();
+}
+
 int huf_gpu_sessions(int *configured)
 {
     pthread_mutex_lock(&g_pool_lock);

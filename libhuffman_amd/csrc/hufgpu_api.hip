@@ -887,6 +887,35 @@ static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64
                                  void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                                  uint64_t *consumed, void *stream);
 
+static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint64_t scan_len, int max_tree,
+                          uint8_t *out, uint64_t out_cap, hipStream_t s, uint64_t *m_out, uint64_t *resume_out,
+                          bool *complete_out, uint64_t *in_place_out);
+
+/* The block index of a raw stream without decoding it into anything: see include/huffman_gpu.h. */
+extern "C" int hufgpu_block_index(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length, uint32_t flags,
+                                  const uint64_t **d_index, uint64_t *nblocks, uint64_t *consumed, void *stream)
+{
+    if (!ctx || !d_index || !nblocks || !consumed) return HUFE_ARGUMENT;
+    *d_index = NULL; *nblocks = 0; *consumed = 0;
+    if (length == 0) return HUFE_OK;
+    if (!d_stream || ((uintptr_t)d_stream & 15u)) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
+    const uint64_t scan_len = length < avail ? length : avail;
+    if (scan_len < 4096) return HUFE_OK;
+    uint64_t m = 0, resume = 0, in_place = ~0ull;
+    bool complete = false;
+    const int rc = discover_chain(ctx, (const uint8_t *)d_stream, avail, length, scan_len, max_tree, NULL, 0, s, &m, &resume,
+                                  &complete, &in_place);
+    if (rc != HUFE_OK) return rc;
+    if (m == 0) return HUFE_OK;
+    *d_index = ctx->d_chain;
+    *nblocks = m;
+    *consumed = resume;
+    return HUFE_OK;
+}
+
 extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                                     void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                                     uint64_t *consumed, void *stream)
@@ -922,6 +951,69 @@ extern "C" int hufgpu_decode_stream(hufgpu_ctx_t *ctx, const void *d_stream, uin
     return err;
 }
 
+/* The block chain of a raw stream (kernels/discover.hpp): candidates, probes, links, walk.  On return
+ * ctx->d_chain holds the header offsets of the *m blocks the walk validated (+ the offset behind them),
+ * *resume = the stream offset behind the validated blocks, *complete = the chain ends the stream exactly
+ * as src/decoder.c:218 would, *in_place = output bytes the probes already put where they belong (~0: none;
+ * only when `out` has room for every candidate).  *m = 0: nothing validated. */
+static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint64_t scan_len, int max_tree,
+                          uint8_t *out, uint64_t out_cap, hipStream_t s, uint64_t *m_out, uint64_t *resume_out,
+                          bool *complete_out, uint64_t *in_place_out)
+{
+    *m_out = 0; *resume_out = 0; *complete_out = false; *in_place_out = ~0ull;
+        const uint64_t nwg = (scan_len + DISC_CHUNK - 1) / DISC_CHUNK;
+    if (nwg > ctx->disc_wgs) {
+        HIP_OK(ctx, hipStreamSynchronize(s));
+        free_disc_ws(ctx, 1);
+        const uint64_t cap = nwg + nwg / 8 + 16;
+        HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
+        HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1) * sizeof(uint64_t)));
+        HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_masks, cap * DISC_THREADS * sizeof(uint64_t)));
+        ctx->disc_wgs = cap;
+    }
+    discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
+    DISC_TRACE("discover count done");
+    scan_counts_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base);
+    DISC_TRACE("scan done");
+    HIP_OK(ctx, hipGetLastError());
+    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_wg_base + nwg, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipStreamSynchronize(s));
+    const uint64_t ncand = ctx->h_result[0];
+#ifdef DISC_DEBUG
+    fprintf(stderr, "disc: ncand=%llu nwg=%llu\n", (unsigned long long)ncand, (unsigned long long)nwg);
+#endif
+    if (ncand > 0 && ncand < 0x7fffffffull) {
+        if (ncand > ctx->disc_cands) {
+            free_disc_ws(ctx, 2);
+            const uint64_t cap = ncand + ncand / 8 + 16;
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand, cap * sizeof(uint64_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_end, cap * sizeof(uint64_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
+            HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
+            ctx->disc_cands = cap;
+        }
+        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks);
+        DISC_TRACE("discover write done");
+        cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(st, ctx->d_cand, ncand, ctx->d_spec_off);
+        probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap);
+        DISC_TRACE("probe done");
+        link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
+        DISC_TRACE("link done");
+        walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
+        DISC_TRACE("walk done");
+        HIP_OK(ctx, hipGetLastError());
+        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipStreamSynchronize(s));
+        *m_out = ctx->h_result[0];
+        *in_place_out = ctx->h_result[4];   /* bytes the probe already decoded into `out` for these m blocks */
+        *complete_out = ctx->h_result[2] != 0;
+        *resume_out = *complete_out ? ctx->h_result[3] : ctx->h_result[1];
+    }
+    return HUFE_OK;
+}
+
 static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length,
                                  void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len,
                                  uint64_t *consumed, void *stream)
@@ -941,55 +1033,10 @@ static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64
     const uint64_t scan_len = length < avail ? length : avail;
     const bool try_parallel = (((uintptr_t)st & 15u) == 0) && scan_len >= 4096 && !(flags & HUFGPU_SEQUENTIAL);
     if (try_parallel) {
-        const uint64_t nwg = (scan_len + DISC_CHUNK - 1) / DISC_CHUNK;
-        if (nwg > ctx->disc_wgs) {
-            HIP_OK(ctx, hipStreamSynchronize(s));
-            free_disc_ws(ctx, 1);
-            const uint64_t cap = nwg + nwg / 8 + 16;
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1) * sizeof(uint64_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_masks, cap * DISC_THREADS * sizeof(uint64_t)));
-            ctx->disc_wgs = cap;
-        }
-        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
-        DISC_TRACE("discover count done");
-        scan_counts_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base);
-        DISC_TRACE("scan done");
-        HIP_OK(ctx, hipGetLastError());
-        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_wg_base + nwg, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        HIP_OK(ctx, hipStreamSynchronize(s));
-        const uint64_t ncand = ctx->h_result[0];
-#ifdef DISC_DEBUG
-        fprintf(stderr, "disc: ncand=%llu nwg=%llu\n", (unsigned long long)ncand, (unsigned long long)nwg);
-#endif
-        if (ncand > 0 && ncand < 0x7fffffffull) {
-            if (ncand > ctx->disc_cands) {
-                free_disc_ws(ctx, 2);
-                const uint64_t cap = ncand + ncand / 8 + 16;
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand, cap * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_end, cap * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
-                HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
-                ctx->disc_cands = cap;
-            }
-            discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks);
-            DISC_TRACE("discover write done");
-            cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(st, ctx->d_cand, ncand, ctx->d_spec_off);
-            probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap);
-            DISC_TRACE("probe done");
-            link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
-            DISC_TRACE("link done");
-            walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
-            DISC_TRACE("walk done");
-            HIP_OK(ctx, hipGetLastError());
-            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIP_OK(ctx, hipStreamSynchronize(s));
-            const uint64_t m = ctx->h_result[0];
-            const uint64_t in_place = ctx->h_result[4];   /* bytes the probe already decoded into `out` for these m blocks */
-            complete = ctx->h_result[2] != 0;
-            resume = complete ? ctx->h_result[3] : ctx->h_result[1];
+        uint64_t m = 0, in_place = ~0ull;
+        const int drc = discover_chain(ctx, st, avail, length, scan_len, max_tree, out, out_cap, s, &m, &resume, &complete, &in_place);
+        if (drc != HUFE_OK) return drc;
+        {
             if (m > 0 && in_place != ~0ull) {
                 prefix_raw = in_place;                 /* every candidate was a block: nothing to decode again */
             } else if (m > 0) {

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__re
 
 /* tree_wave_kernel - tree_fast_wave (tree.hpp) as a launch of its own: one wavefront per block, counts from
  * hist_lanes_kernel; also sums the encoded sizes (two_level_arrive), like the fused kernel's tree wave. */
-__global__ __launch_bounds__(64) void tree_wave_kernel(const uint32_t *__restrict__ hist, hufcode_t *__restrict__ codetab,
+__global__ __launch_bounds__(64, 8) void tree_wave_kernel(const uint32_t *__restrict__ hist, hufcode_t *__restrict__ codetab,
                                                        int16_t *__restrict__ treebuf, HufBlockMeta *__restrict__ meta,
                                                        TwoLevel sizes)
 {

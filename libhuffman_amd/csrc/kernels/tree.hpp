@@ -263,10 +263,11 @@ __device__ __forceinline__ void wave_sort_r(uint32_t (&k)[4])
 }
 __device__ __forceinline__ void wave_sort256(uint32_t (&k)[4]) { wave_sort_r<4>(k); }
 
-struct TreeLds {                  /* 6 KiB: what bounds the tree waves a CU holds (they are latency bound) */
-    uint64_t state[HUF_NSLOT];    /* per node: its path to an ancestor, see TREE_STATE below */
+struct TreeLds {                  /* 5 KiB: what bounds the tree waves a CU holds (they are latency bound): 32 per CU */
+    uint64_t state[HUF_NSLOT];    /* per node: its path to an ancestor, see TREE_STATE below.  The entries of nodes that do
+                                     not exist yet also serve as scratch for keys on their way into fewer registers: with
+                                     `node` the next index, at most 512 - node keys are alive and 2 (512 - node) words free */
     uint16_t lcnt[HUF_NSLOT];     /* leaves below each slot */
-    uint32_t scratch[HUF_NSYM];   /* keys on their way into fewer registers */
 };
 
 /* A node's state while codes, depths and preorder positions are worked out: the path from the node up to
@@ -348,7 +349,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
      * other registers hold KMAX), because a round's sort costs what its register count costs.  Keys are moved
      * together through 1 KiB of LDS: a key's compact
      * index is its rank among the live ones. */
-    uint32_t *s_scratch = L.scratch;
+    uint32_t *s_scratch = reinterpret_cast<uint32_t *>(s_state + HUF_NSYM);   /* (moves up with `node`, see TreeLds) */
     uint32_t live, R = 4;
     {
         const unsigned long long nz0 = __ballot(rate[0] != 0), nz1 = __ballot(rate[1] != 0);
@@ -463,6 +464,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                 if (nr < R) {
                     /* fewer registers from here on: new node p (at position 2p) becomes key p, a key that was
                      * not paired (position q >= 2 pairs) key q - pairs */
+                    s_scratch = reinterpret_cast<uint32_t *>(s_state + node);
 #pragma unroll
                     for (uint32_t r = 0; r < 4; r++) {
                         const uint32_t q = (uint32_t)lane * R + r;

@@ -66,8 +66,10 @@ run(1)                                    # contexts, staging buffers
 dt = run(3)
 configured = C.c_int(0)
 live = L.huf_gpu_sessions(C.byref(configured))
+fe, fd = C.c_int(0), C.c_int(0)
+L.huf_gpu_fanouts(C.byref(fe), C.byref(fd))
 print(f"sessions live={live} configured={configured.value} threads={NTHREADS} "
-      f"seconds={dt:.3f} GiB/s={3 * NTHREADS * 2 * n / dt / 2**30:.2f}")
+      f"seconds={dt:.3f} GiB/s={3 * NTHREADS * 2 * n / dt / 2**30:.2f} fanout_encodes={fe.value} fanout_decodes={fd.value}")
 if errors:
     print("ERRORS", errors)
     sys.exit(1)

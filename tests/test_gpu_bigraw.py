@@ -359,6 +359,10 @@ def test_one_call_fans_out_over_free_sessions(torch_mod, bs):
     print("\n  " + r.stdout.strip().replace("\n", "\n  "))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "sessions live=3 configured=3" in r.stdout, r.stdout
+    # both directions went over the three sessions: 4 encodes and 4 decodes of 150 MiB (1 warm-up + 3 timed)
+    import re
+    m = re.search(r"fanout_encodes=(\d+) fanout_decodes=(\d+)", r.stdout)
+    assert m and int(m.group(1)) == 4 and int(m.group(2)) == 4, r.stdout
 
 
 @pytest.mark.parametrize("run_kib,limit_ms", [(2, 10.0), (24, 25.0), (300, 200.0), (2048, None)])

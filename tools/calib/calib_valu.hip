@@ -36,6 +36,10 @@ BOTH(cmp_s,    "v_cmp_lt_u32 s[20:21], %0, %1")
 BOTH(cmpcnd,   "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
 BOTH(cmpcnd64, "v_cmp_lt_u32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %1, s[20:21]")
 BOTH(cnd,      "v_cndmask_b32 %0, %0, %1, vcc")
+BOTH(cnds,     "v_cndmask_b32_e64 %0, %0, %1, s[22:23]")      /* a mask no VALU instruction wrote lately */
+BOTH(cndadd,   "v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %0, %0, %1")
+BOTH(bfi,      "v_bfi_b32 %0, %2, %0, %1")
+BOTH(adds,     "v_add_u32 %0, s22, %0")
 BOTH(min,      "v_min_u32 %0, %0, %1")
 BOTH(lshladd,  "v_lshl_add_u32 %0, %0, 2, %1")
 BOTH(add3,     "v_add3_u32 %0, %0, %1, %2")
@@ -69,7 +73,7 @@ int main()
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     printf("%d CUs, %.0f MHz; cycles = time x clock x SIMDs / wave-instructions\n", cus, clk_hz / 1e6);
     RUN(add, 1) RUN(or_, 1) RUN(sub, 1) RUN(lshr, 1) RUN(and_, 1) RUN(alignbit, 1) RUN(bfe, 1) RUN(cmp, 1) RUN(cmp_s, 1)
-    RUN(cmpcnd, 2) RUN(cmpcnd64, 2) RUN(cnd, 1) RUN(min, 1) RUN(lshladd, 1) RUN(add3, 1) RUN(mad24, 1) RUN(perm, 1) RUN(sdwa, 1)
+    RUN(cmpcnd, 2) RUN(cmpcnd64, 2) RUN(cnd, 1) RUN(cnds, 1) RUN(cndadd, 2) RUN(bfi, 1) RUN(adds, 1) RUN(min, 1) RUN(lshladd, 1) RUN(add3, 1) RUN(mad24, 1) RUN(perm, 1) RUN(sdwa, 1)
     RUN(dppmov, 1) RUN(dppmin, 1) RUN(readlane, 1) RUN(sadd, 1) RUN(vs_mix, 2) RUN(cbranch, 3) RUN(saveexec, 4)
     return 0;
 }

@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp
-COMMON="--secondary none --no-cpu-baseline --no-other-decode"
+COMMON="--secondary none --no-cpu-baseline --no-other-decode --no-index-free --no-python-layer"
 for WL in $WLS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -o run -- python3 $ROOT/bench.py --steps 20 --warmup 5 --workload $WL $COMMON > $OUT/${TAG}_${WL}_bench.json 2> $OUT/kt_$WL.err
   cp $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${WL}_kernel_stats.csv
@@ -30,7 +30,8 @@ python3 - <<PY
 import csv, glob, collections, json, sys
 sys.path.insert(0, "$ROOT")
 import bench
-names = {"hist_tree_kernel": "hist_tree", "pack_kernel": "pack", "decode_sub_kernel": "decode", "decode_kernel": "decode_selfsync",
+names = {"hist_tree_kernel": "hist_tree", "hist_lanes_kernel": "hist256", "tree_wave_kernel": "tree", "pack_kernel": "pack",
+         "decode_sub_kernel": "decode", "decode_kernel": "decode_selfsync",
          "decode_prepare_kernel": "prepare_scan", "decode_fix_kernel": "decode_fix"}
 def per_kernel(path, ctr):
     agg = collections.defaultdict(float); calls = collections.defaultdict(set)

@@ -675,7 +675,20 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
         const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
         decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
     } else {
-        decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res);
+        static const bool exact_only = getenv("HUF_GPU_EXACT_DECODE") && atoi(getenv("HUF_GPU_EXACT_DECODE")) != 0;   /* (measurements: the exact decoder for every block) */
+        if (exact_only) {
+            decode_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res);
+        } else {
+            /* the lean self-synchronising decoder (kernels/decode_fast.hpp); what it cannot vouch for - a damaged
+             * stream, an unusual tree - is decoded again by the exact one, which also reports the reference's error */
+            DecFixList fix;
+            fix.count = ctx->d_fix_count;
+            fix.blocks = ctx->d_fix_blocks;
+            fix.flag = ctx->d_fix_flag;
+            decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
+            const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+            decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
+        }
     }
     STAGE_MARK(ctx, s);
     HIP_OK(ctx, hipGetLastError());
@@ -892,6 +905,14 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
                           bool *complete_out, uint64_t *in_place_out);
 
 /* The block index of a raw stream without decoding it into anything: see include/huffman_gpu.h. */
+#ifdef DFAST_DEBUG
+extern "C" int hufgpu_debug_dfast(unsigned long long *out16, int reset)
+{
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(hufgpu::g_dfast_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(hufgpu::g_dfast_dbg), 16 * sizeof(unsigned long long));
+}
+#endif
+
 extern "C" int hufgpu_block_index(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t avail, uint64_t length, uint32_t flags,
                                   const uint64_t **d_index, uint64_t *nblocks, uint64_t *consumed, void *stream)
 {

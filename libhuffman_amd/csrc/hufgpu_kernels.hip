@@ -30,6 +30,7 @@
 #include "kernels/pack_chunk.hpp"
 #include "kernels/decode.hpp"
 #include "kernels/decode_sub.hpp"
+#include "kernels/decode_fast.hpp"
 #include "kernels/spec_index.hpp"
 #include "kernels/discover.hpp"
 #include "kernels/fill.hpp"

@@ -1,0 +1,346 @@
+/* decode_fast.hpp - decode_fast_kernel: indexed decode WITHOUT the encoder's sub-index (what huf_decode() and
+   streams written by the reference get; src/decoder.c:34-96), lean form.
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "decode.hpp"
+#include "decode_sub.hpp"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * The self-synchronising decoder of decode.hpp is exact for ANY stream, and pays for it: its count pass and
+ * its re-synchronisation rounds keep, per lane and 32-bit word, where the lane's track first entered the word -
+ * 54 instructions per symbol before a single byte is written (1.47 x 10^9 wave instructions per GiB, 0.12 of
+ * the HBM roofline).  This is the same idea without the bookkeeping, verified instead of proven, with
+ * decode_fix_kernel (= the exact decoder) behind it for every block where anything is off:
+ *
+ *   - the payload is staged LINEARLY in segments of 512 x 288 bits; lane i owns the codewords that start
+ *     in its 288 bits.  288 = 9 words: lanes that read "their" word k touch words 9 i + k - 64 different
+ *     banks' worth of addresses, no conflicts, no interleaved layout, and the 32 bits at a position are one
+ *     ds_read2_b32 + one v_alignbit_b32 of a position register that IS the LDS address (decode_sub.hpp);
+ *   - scan: every lane walks from its start to the first codeword start at or behind its end, two table
+ *     look-ups per window, counting - 10 instructions per symbol, no branch but the loop's;
+ *   - lane 0 starts at the segment's true first codeword, every other lane first at its own first bit
+ *     (speculation: a Huffman decoder falls into step within a few codewords), then at its left
+ *     neighbour's end, again and again until no start changes.  By induction over the lanes the tracks are
+ *     then the in-order decoder's: usually after two scans;
+ *   - counts are prefix-summed and every lane decodes its symbols once more, four to a 32-bit store.  THIS
+ *     pass checks what the in-order decoder would have met: a walk that leaves the tree or needs bits past
+ *     the payload before the block is complete sends the block to the exact decoder, which delivers the
+ *     reference's error code and byte count.  So does a block whose tree is not an ordinary one, whose
+ *     starts do not settle in 64 rounds, or whose codes run past the staged words.
+ * ==================================================================================== */
+#define DFAST_SUBW 9u                               /* words per lane */
+#define DFAST_SUB_BITS (32u * DFAST_SUBW)
+#define DFAST_SLACK_WORDS 16u                       /* staged behind the segment: the last lane's window, a walk of a long code */
+#define DFAST_RUNIN DFAST_SUB_BITS                   /* bits of a lane's share its first, speculative scan walks: all of them.
+                                                       (96: nearly every WAVE then holds a lane that has not fallen into step, and a wave
+                                                       rescans as long as its slowest lane - zipf255 1.87 -> 2.12 ms; codes of one length,
+                                                       uniform bytes, never fall into step at all) */
+#define DFAST_MAX_ROUNDS 64
+
+template <int THREADS>
+struct DfastLds {
+    static constexpr uint32_t AREA_WORDS = (uint32_t)((sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark)) / sizeof(uint32_t));
+    static constexpr uint32_t SEG_WORDS = (uint32_t)THREADS * DFAST_SUBW;
+    static constexpr uint32_t STAGE_WORDS = SEG_WORDS + DFAST_SLACK_WORDS;
+    static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
+    static_assert(STAGE_WORDS + 4u <= AREA_WORDS, "the linear stage fits the area of the interleaved stage and its marks");
+    static_assert(offsetof(DecShared<THREADS>, pay) % 16 == 0, "16-byte stage stores");
+};
+
+#ifdef DFAST_DEBUG
+__device__ unsigned long long g_dfast_dbg[16];
+#define DFAST_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_dfast_dbg[i], (unsigned long long)(v)); } while (0)
+#define DFAST_DBGW(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dfast_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define DFAST_DBG(i, v) do { } while (0)
+#define DFAST_DBGW(i, v) do { } while (0)
+#endif
+
+typedef const __attribute__((address_space(3))) uint32_t *dfast_lds_words;
+typedef const __attribute__((address_space(3))) uint16_t *dfast_lds_halves;
+
+/* One scan of a lane: from `start` to the first codeword start at or behind `hi` (positions are bits of the
+ * staged segment).  *end = that position, *cnt = table look-ups taken on the way (= codewords on a track that
+ * meets no walk out of the tree; the write pass checks that).  qbase = 8 x the LDS byte address of the stage,
+ * lut_addr = the LDS byte address of the table.  LONGS = the block's table has `long` entries (codes of more
+ * than 12 bits, walked bit by bit behind a ballot); blocks without them - most - run the loop without the test. */
+template <int THREADS, bool LONGS>
+__device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
+                                           uint32_t start, uint32_t hi, uint32_t lim, uint32_t *end, uint32_t *cnt)
+{
+    uint32_t Q = start - 1u + qbase;                 /* (position - 1) + 8 x stage address: see decode_sub.hpp */
+    const uint32_t hiQ = hi - 1u + qbase;
+    uint32_t c = 0;
+    DFAST_DBGW(8, 1);
+    for (;;) {
+        const bool act = Q < hiQ;
+        if (!__any(act)) break;
+        DFAST_DBGW(9, 1);
+        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+        const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+        const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
+        uint32_t l1 = (e1 >> 8) & 31u;
+        const uint32_t d2 = d1 << l1;
+        const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
+        uint32_t l2 = (e2 >> 8) & 31u;
+        /* the second look-up counts when the window still held a whole table index behind the first codeword */
+        if (l1 > 20u) l2 = 0;
+        if (LONGS) {
+            if (e2 >= DEC_E_LONG) l2 = 0;            /* (it is the next window's first) */
+            if (__builtin_expect(__ballot(act && e1 >= DEC_E_LONG) != 0ull, 0)) {
+                if (act && e1 >= DEC_E_LONG) {       /* a code of more than 12 bits: walked bit by bit */
+                    const uint32_t pos = Q + 1u - qbase;
+                    const uint64_t r = dec_rare_lin<THREADS>(sh, stage, e1, pos, lim);
+                    const int st = (int)(r >> 40);
+                    l1 = (st == CW_EXH) ? (hi > pos ? hi - pos : 1u) : (uint32_t)r - pos;   /* (walks out of the tree resume behind the failing bit) */
+                    l2 = 0;
+                }
+            }
+        }
+        /* a lane that has arrived stands still; a second look-up that starts at or behind `hi` is the neighbour's */
+        const uint32_t t1 = Q + (act ? l1 : 0u);
+        const bool take2 = t1 < hiQ && l2 != 0u;
+        c += (act ? 1u : 0u) + (take2 ? 1u : 0u);
+        Q = t1 + (take2 ? l2 : 0u);
+    }
+    *end = Q + 1u - qbase;
+    *cnt = c;
+}
+
+/* Write pass of a lane: its first `quota` symbols, from `start`, to g[0 .. quota).  Returns the position behind
+ * the last one; *ok is cleared when a look-up was not a codeword (a walk out of the tree, bits past `lim`). */
+template <int THREADS>
+__device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
+                                                uint32_t start, uint32_t quota, uint32_t lim, uint8_t *g, bool *ok_out)
+{
+    bool ok = true;
+    LinReader rd;
+    rd.st = stage;
+    rd.load(start);
+    /* bytes up to the first 4-byte boundary of the output */
+    const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
+    for (uint32_t c = 0; c < head; c++) {
+        g[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        if (rd.avail <= 32) rd.refill();
+    }
+    const uint32_t p0 = rd.pos();
+    uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
+    const uint32_t words = (quota - head) >> 2;
+    /* whole words: four table entries folded into one register, two per window, no branch; an entry that is
+     * not a leaf advances like one and is only remembered */
+    uint32_t Q = p0 - 1u + qbase;
+    uint32_t special = 0;
+    for (uint32_t k = 0; k < words; k++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
+            const uint32_t l1 = (e1 >> 8) & 31u;
+            const uint32_t d2 = d1 << l1;
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
+            special |= e1 | e2;
+            acc = __builtin_amdgcn_alignbit(e1, acc, 8);
+            acc = __builtin_amdgcn_alignbit(e2, acc, 8);
+            Q += l1 + ((e2 >> 8) & 31u);
+        }
+        gw[k] = acc;
+    }
+    uint32_t p1 = Q + 1u - qbase;
+    if (__builtin_expect(__ballot((special & 0xC000u) != 0u) != 0ull, 0)) {
+        if (special & 0xC000u) {                     /* a long code (or worse) among them: the words again, step by step */
+            rd.load(p0);
+            uint8_t *b = g + head;
+            for (uint32_t c = 0; c < 4u * words; c++) {
+                b[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+                if (rd.avail <= 32) rd.refill();
+            }
+            p1 = rd.pos();
+        }
+    }
+    rd.load(p1);
+    for (uint32_t c = head + 4u * words; c < quota; c++) {
+        g[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        if (rd.avail <= 32) rd.refill();
+    }
+    *ok_out = ok;
+    return rd.pos();
+}
+
+/* A block's payload (tables in sh, built by dec_build_tables<THREADS, true>).  Returns true (workgroup-uniform)
+ * when block_len symbols were written and everything the in-order decoder would have checked held.
+ * readable = bytes that may be loaded from `pay` on (to the end of the stream: what lies behind the block's
+ * payload is never part of a track that passes the checks, so it need not be zeroed). */
+template <int THREADS>
+__device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                    uint8_t *gout)
+{
+    typedef DfastLds<THREADS> L;
+    constexpr int WAVES = THREADS / 64;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t *stage = sh.pay;                                          /* linear, runs on into the marks' area */
+    const uint32_t qbase = 8u * (uint32_t)(uintptr_t)(dfast_lds_words)stage;
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)sh.lut;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+    const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;                  /* bits a walk may look at */
+    if (tid == 0) { sh.fastk = 0; sh.l2n = 0; }                        /* (the tables are dec_build_tables': dsub_next takes the walk for long codes) */
+    /* does the table hold `long` entries at all?  (eight entries per thread) */
+    bool longs;
+    {
+        const uint32_t *t = reinterpret_cast<const uint32_t *>(sh.lut) + 4 * tid;      /* (the table is 4-byte aligned) */
+        const uint32_t any = (t[0] | t[1] | t[2] | t[3]) & 0x80008000u;   /* bit 15: long (bad entries have bit 14 only) */
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && DEC_E_LONG == 0xC000u && DEC_E_BAD == 0x4000u, "eight entries per thread");
+        longs = __syncthreads_or(any != 0u) != 0;
+    }
+    uint64_t true_start = 0, produced = 0;
+    bool ok = true;
+    while (produced < block_len) {
+        if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }             /* input exhausted: the exact decoder says how */
+        const uint64_t seg0 = true_start & ~31ull;
+        __syncthreads();                                               /* the previous segment's readers are done */
+        {
+            /* four words per thread and step from 20 bytes at a 4-byte aligned address, as decode_sub stages */
+            struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
+            const uint64_t byte0 = seg0 >> 3;
+            constexpr uint32_t STEPS = (L::STAGE_WORDS + 4u * THREADS - 1u) / (4u * THREADS);
+            if (byte0 + 4ull * (4ull * THREADS * STEPS) + 24ull <= readable) {
+                const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));
+                const uint32_t m = (uint32_t)(a & 3u);
+                const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
+                const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
+                Q4 v[STEPS];
+                uint32_t x[STEPS];
+#pragma unroll
+                for (uint32_t k = 0; k < STEPS; k++) {
+                    const uint32_t i4 = 4u * ((uint32_t)tid + (uint32_t)THREADS * k);
+                    v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
+                    x[k] = qw[i4 + 4];
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < STEPS; k++) {
+                    const uint32_t i4 = 4u * ((uint32_t)tid + (uint32_t)THREADS * k);
+                    if (i4 < L::STAGE_WORDS)
+                        *reinterpret_cast<uint4 *>(stage + i4) =
+                            make_uint4(__builtin_amdgcn_perm(v[k].y, v[k].x, sel), __builtin_amdgcn_perm(v[k].z, v[k].y, sel),
+                                       __builtin_amdgcn_perm(v[k].w, v[k].z, sel), __builtin_amdgcn_perm(x[k], v[k].w, sel));
+                }
+            } else {
+                for (uint32_t i = (uint32_t)tid; i < L::STAGE_WORDS; i += THREADS) stage[i] = load_be32(pay, byte0 + 4ull * i, readable);
+            }
+        }
+        __syncthreads();
+        const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);   /* payload bits from seg0 on */
+        const uint32_t first = (uint32_t)(true_start - seg0);
+        const uint32_t hi = ((uint32_t)tid + 1u) * DFAST_SUB_BITS;
+        /* speculation: every lane but the first starts at its own first bit - a decoder that starts anywhere falls
+         * into step within a few codewords, and a lane that has not is found out below */
+        uint32_t start = tid == 0 ? first : hi - DFAST_RUNIN;
+        uint32_t end, cnt;
+        if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+        else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+        if (lane == 63) sh.wend[wave] = end;
+        __syncthreads();
+        int rounds = 0;
+        for (;;) {
+            /* left neighbour's end: a DPP move inside the wave, LDS across the wave seams */
+            uint32_t ns = wave_up1_u32(end);
+            if (lane == 0) ns = (tid == 0) ? first : sh.wend[wave - 1];
+            const int changed = (ns != start);
+            __syncthreads();                                           /* everyone has read sh.wend */
+            if (changed) {
+                start = ns;
+                if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+                else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+            }
+            if (lane == 63) sh.wend[wave] = end;
+            if (!__syncthreads_or(changed)) break;
+            DFAST_DBG(10, 1);
+            if (++rounds > DFAST_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }    /* (uniform: every thread counts the same rounds) */
+        }
+        if (!ok) break;
+        uint32_t seg_total;
+        const uint32_t ex = block_excl_scan_u32<THREADS>(cnt, sh.part, seg_total);
+        seg_total = uni32(seg_total);
+        const uint64_t remaining = block_len - produced;
+        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
+        uint32_t quota = 0;
+        if (ex < take) {
+            quota = take - ex;
+            if (quota > cnt) quota = cnt;
+        }
+        bool lane_ok = true;
+        if (quota) {
+            const uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok);
+#ifdef DFAST_DEBUG
+            if (!lane_ok) atomicAdd(&g_dfast_dbg[4], 1ull);
+            if (qe > pay_rel) atomicAdd(&g_dfast_dbg[5], 1ull);
+#endif
+            if (qe > pay_rel) { lane_ok = false; }                         /* a codeword of the block needs bits past the payload */
+        }
+        const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
+        if (!__syncthreads_and(lane_ok ? 1 : 0)) { ok = false; DFAST_DBG(2, 1); break; }
+        DFAST_DBG(11, 1);
+        produced += take;
+        if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }                          /* (no progress: cannot happen on a track that holds codewords) */
+        true_start = seg0 + last_end;
+    }
+    return ok;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kernel(
+    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
+    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
+    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
+    unsigned long long *__restrict__ result, DecFixList fix)
+{
+    __shared__ DecShared<THREADS> sh;
+    const int tid = (int)threadIdx.x;
+    const uint64_t blk = blockIdx.x;
+    HufDecodeMeta m = dmeta[blk];
+    m.block_len = uni64(m.block_len);
+    m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
+    m.leaf = (int16_t)uni32((uint32_t)(uint16_t)m.leaf);
+    m.status = (int32_t)uni32((uint32_t)m.status);
+    const uint64_t obase = uni64(lens.gprefix[blk / SCAN_GROUP] + lens.local[blk]);
+    if (tid == 0) out_offsets[blk] = obase;
+    if (m.status != HUFE_OK || m.block_len == 0) return;             /* header errors were recorded by decode_prepare */
+    if (obase + m.block_len > out_cap) {
+        if (tid == 0) {
+            status[blk] = HUFE_MEMORY;
+            atomicMin(&result[2], (unsigned long long)blk);
+        }
+        return;
+    }
+    const uint64_t o0 = uni64(offsets[blk]);
+    const uint64_t o1 = dmin<uint64_t>(uni64(offsets[blk + 1]), stream_len);
+    const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
+    const uint8_t *tree = stream + o0 + HUF_HEADER_FIXED;
+    const uint8_t *pay = tree + 2 * (int)m.tree_len;
+    int leaf = m.leaf;
+    int rc = HUFE_OK;
+    if (leaf < 0) rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+    bool good;
+    if (rc != HUFE_OK) {
+        good = false;
+    } else if (leaf >= 0) {
+        uint64_t eb = 0, produced = 0;
+        good = decode_single_leaf<THREADS, true>(sh, (uint32_t)leaf, pay, m.block_len, pay_bytes, out + obase, &eb, &produced) == HUFE_OK;
+    } else {
+        good = decode_payload_fast<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase);
+    }
+    if (!good && tid == 0) {
+        if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
+    }
+}
+
+}  // namespace hufgpu

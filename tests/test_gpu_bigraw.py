@@ -365,7 +365,7 @@ def test_one_call_fans_out_over_free_sessions(torch_mod, bs):
     assert m and int(m.group(1)) == 4 and int(m.group(2)) == 4, r.stdout
 
 
-@pytest.mark.parametrize("run_kib,limit_ms", [(2, 10.0), (24, 25.0), (300, 200.0), (2048, None)])
+@pytest.mark.parametrize("run_kib,limit_ms", [(2, 10.0), (24, 25.0), (300, 200.0), (2048, 4000.0)])
 def test_runs_of_one_byte_inside_a_big_block(torch_mod, codec, run_kib, limit_ms):
     """A run of one byte value is a periodic bit string: a lane that starts inside it can lock onto the
     pattern a bit off and never fall into step.  The broken chain is mended one share (512 payload

@@ -408,3 +408,47 @@ def test_codes_beyond_the_first_table(torch_mod, codec, oracle, kind, bs):
         assert res[0] == res[1], (kind, trial, res)
         if res[0][0] == 0:
             assert torch.equal(outs[0], outs[1]), (kind, trial)
+
+
+def test_index_only_decode_lean_and_exact_kernels_agree(torch_mod, codec, oracle):
+    """hufgpu_decode() without a sub-index runs decode_fast_kernel (lean, verified) with the exact decoder behind
+    it.  Inputs that the lean kernel cannot vouch for - a run of one byte value of many KiB is a periodic bit
+    string on which speculative lanes never fall into step, a block whose codes reach 24 bits - must come out
+    exactly like everything else; and HUF_GPU_EXACT_DECODE=1 (the exact kernel for every block) must give the
+    same bytes in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    torch = torch_mod
+    bs = 65536
+    rng = np.random.default_rng(123)
+    parts = [datagen.zipf255(3 * bs)]
+    runs = datagen.zipf255(4 * bs).copy()
+    runs[1000:1000 + 40000] = 0                       # 40 000 x the shortest code: ~280 lanes of one phase-ambiguous pattern
+    runs[bs + 5:bs + 5 + 30000] = 7
+    parts.append(runs)
+    w = 0.5 ** np.arange(1, 25)
+    parts.append(rng.choice(24, size=2 * bs, p=w / w.sum()).astype(np.uint8))      # codes up to 24 bits
+    parts.append(datagen.uniform255(2 * bs + 321))
+    data = np.concatenate(parts)
+    n = data.size
+    d = dev(torch, data)
+    stream, offs, length = codec.encode(d, bs)
+    assert np.array_equal(stream[:length].cpu().numpy(), oracle.encode(data, bs))
+    nb = codec.block_count(n, bs)
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert codec.decode(stream, length, offs, nb, out) == n and torch.equal(out, d)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from libhuffman_amd.codec import GpuCodec\n"
+        "c = GpuCodec(0); data = torch.from_numpy(np.load(sys.argv[1])).cuda(); bs = 65536\n"
+        "s, o, l = c.encode(data, bs); out = torch.zeros_like(data)\n"
+        "assert c.decode(s, l, o, c.block_count(data.numel(), bs), out) == data.numel() and torch.equal(out, data)\n"
+        "print('exact kernel ok')\n" % root)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "d.npy"), data)
+        r = subprocess.run([sys.executable, "-c", child, os.path.join(tmp, "d.npy")], env=dict(os.environ, HUF_GPU_EXACT_DECODE="1"),
+                           capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "exact kernel ok" in r.stdout, r.stdout + r.stderr

@@ -63,6 +63,86 @@ __device__ unsigned long long g_dfast_dbg[16];
 #define DFAST_DBGW(i, v) do { } while (0)
 #endif
 
+/* 64-bit left-aligned bit buffer over the linearly staged payload words (big-endian words): the edges of a
+ * lane's output and the step-by-step path */
+struct LinReader {
+    const uint32_t *st;
+    uint32_t hi, lo;
+    int32_t avail;
+    uint32_t gf;         /* next staged word to append */
+
+    __device__ __forceinline__ void load(uint32_t pos)
+    {
+        const uint32_t g = pos >> 5, off = pos & 31u;
+        const uint64_t b = (((uint64_t)st[g] << 32) | st[g + 1]) << off;
+        hi = (uint32_t)(b >> 32);
+        lo = (uint32_t)b;
+        avail = (int32_t)(64u - off);
+        gf = g + 2;
+    }
+    __device__ __forceinline__ uint32_t index() const { return hi >> (32 - DEC_LUT_BITS); }
+    __device__ __forceinline__ uint32_t pos() const { return (gf << 5) - (uint32_t)avail; }
+    __device__ __forceinline__ void consume(uint32_t adv)
+    {
+        const uint64_t b = (((uint64_t)hi << 32) | lo) << adv;
+        hi = (uint32_t)(b >> 32);
+        lo = (uint32_t)b;
+        avail -= (int32_t)adv;
+    }
+    __device__ __forceinline__ void refill()                   /* needs avail <= 32 */
+    {
+        const uint64_t t = (uint64_t)st[gf] << (32 - avail);
+        hi |= (uint32_t)(t >> 32);
+        lo |= (uint32_t)t;
+        avail += 32;
+        gf++;
+    }
+};
+
+/* bit-serial walk behind a `long` table entry on the linear stage; result as dec_rare_packed */
+template <int THREADS>
+__device__ __forceinline__ uint64_t dec_rare_lin(const DecShared<THREADS> &sh, const uint32_t *st, uint32_t e,
+                                                 uint32_t pos, uint32_t lim)
+{
+    uint32_t node = e & 0x7ffu;
+    uint32_t p = pos + DEC_LUT_BITS;
+    for (;;) {
+        if (p >= lim) return (uint64_t)CW_EXH << 40;
+        const uint32_t bit = (st[p >> 5] >> (31u - (p & 31u))) & 1u;
+        p++;
+        const uint32_t nx = dec_child(sh.lr[node], bit);
+        if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
+        node = nx;
+        if (sh.lr[node] == DEC_LEAF_LR) break;
+    }
+    return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
+}
+
+/* One table step of a lane (tables of dec_build_tables): returns the entry (low byte = symbol); *ok is cleared
+ * when the lookup is not a codeword.  The rare paths sit behind one wave-uniform branch. */
+template <int THREADS>
+__device__ __forceinline__ uint32_t dfast_next(const DecShared<THREADS> &sh, LinReader &rd, uint32_t lim, bool &ok)
+{
+    uint32_t e = sh.lut[rd.index()];
+    if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
+        if (e >= DEC_E_LONG) {
+            const uint64_t r = dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
+            if ((int)(r >> 40) == CW_OK) {
+                rd.load((uint32_t)r);
+                e = (uint32_t)(r >> 32) & 0xffu;           /* advance 0: the reader already stands behind it */
+            } else {
+                ok = false;
+                e = 0x0100u;
+            }
+        } else if (e >= DEC_E_BAD) {
+            ok = false;
+            e = 0x0100u;                                   /* keep moving: the lane's result is discarded anyway */
+        }
+    }
+    rd.consume(e >> 8);
+    return e;
+}
+
 typedef const __attribute__((address_space(3))) uint32_t *dfast_lds_words;
 typedef const __attribute__((address_space(3))) uint16_t *dfast_lds_halves;
 
@@ -127,7 +207,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
     /* bytes up to the first 4-byte boundary of the output */
     const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
     for (uint32_t c = 0; c < head; c++) {
-        g[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
         if (rd.avail <= 32) rd.refill();
     }
     const uint32_t p0 = rd.pos();
@@ -160,7 +240,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
             rd.load(p0);
             uint8_t *b = g + head;
             for (uint32_t c = 0; c < 4u * words; c++) {
-                b[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+                b[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
                 if (rd.avail <= 32) rd.refill();
             }
             p1 = rd.pos();
@@ -168,7 +248,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
     }
     rd.load(p1);
     for (uint32_t c = head + 4u * words; c < quota; c++) {
-        g[c] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
         if (rd.avail <= 32) rd.refill();
     }
     *ok_out = ok;
@@ -192,7 +272,6 @@ __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, 
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)sh.lut;
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;                  /* bits a walk may look at */
-    if (tid == 0) { sh.fastk = 0; sh.l2n = 0; }                        /* (the tables are dec_build_tables': dsub_next takes the walk for long codes) */
     /* does the table hold `long` entries at all?  (eight entries per thread) */
     bool longs;
     {

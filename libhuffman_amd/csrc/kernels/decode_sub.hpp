@@ -38,9 +38,14 @@ namespace hufgpu {
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
 
-/* 64-bit left-aligned bit buffer over the linearly staged payload words (big-endian words) */
-struct LinReader {
-    const uint32_t *st;
+/* The staged payload words of a wave lie in its LDS slice in REVERSED order: word g (big-endian, 32 payload bits)
+ * at top[-g].  The hot loop's position register then counts DOWN, and both the pair's LDS address and the
+ * v_alignbit_b32 shift amount are plain bit fields of it (see DSUB_WINDOW). */
+__device__ __forceinline__ uint32_t rev_word(const uint32_t *top, uint32_t g) { return top[-(int32_t)g]; }
+
+/* 64-bit left-aligned bit buffer over the reversed stage: the step-by-step path (long codes, short groups) */
+struct RevReader {
+    const uint32_t *top;
     uint32_t hi, lo;
     int32_t avail;
     uint32_t gf;         /* next staged word to append */
@@ -48,7 +53,7 @@ struct LinReader {
     __device__ __forceinline__ void load(uint32_t pos)
     {
         const uint32_t g = pos >> 5, off = pos & 31u;
-        const uint64_t b = (((uint64_t)st[g] << 32) | st[g + 1]) << off;
+        const uint64_t b = (((uint64_t)rev_word(top, g) << 32) | rev_word(top, g + 1)) << off;
         hi = (uint32_t)(b >> 32);
         lo = (uint32_t)b;
         avail = (int32_t)(64u - off);
@@ -65,7 +70,7 @@ struct LinReader {
     }
     __device__ __forceinline__ void refill()                   /* needs avail <= 32 */
     {
-        const uint64_t t = (uint64_t)st[gf] << (32 - avail);
+        const uint64_t t = (uint64_t)rev_word(top, gf) << (32 - avail);
         hi |= (uint32_t)(t >> 32);
         lo |= (uint32_t)t;
         avail += 32;
@@ -73,16 +78,30 @@ struct LinReader {
     }
 };
 
-/* bit-serial walk behind a `long` table entry on the linear stage; result as dec_rare_packed */
+/* Table entries of the sub-index path (uint16), laid out for the hot loop - the code length in the low five
+ * bits is a shift amount as it stands, the sum of two entries carries the sum of their lengths in its low byte:
+ *   leaf      byte << 8 | len                               len = 1..12 (first table), 13..18 (second level)
+ *   level 2   (offset / 4) << 8 | (bits / 2 - 1) << 6 | 0x20  the second-level table of a 12-bit prefix
+ *   long      0xFE00                                          a code the tables do not hold
+ *   bad       0xFF00                                          the walk leaves the tree
+ * An entry that is not a leaf has length 0; `long` and `bad` have a zero low BYTE: a lane that meets one stands
+ * still for the rest of its group, and its last look-up says so. */
+#define DSE_L2 0x20u
+#define DSE_LONG 0xFE00u
+#define DSE_BAD 0xFF00u
+#define DSE_LEN(e) ((e) & 31u)
+#define DSE_IS_L2(e) (((e) & 0x3fu) == DSE_L2)
+
+/* bit-serial walk from the root on the reversed stage (tables of dec_build_tables: sh.lr, sh.ent);
+ * result as dec_rare_packed */
 template <int THREADS>
-__device__ __forceinline__ uint64_t dec_rare_lin(const DecShared<THREADS> &sh, const uint32_t *st, uint32_t e,
-                                                 uint32_t pos, uint32_t lim)
+__device__ __forceinline__ uint64_t dsub_rare_walk(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t pos, uint32_t lim)
 {
-    uint32_t node = e & 0x7ffu;
-    uint32_t p = pos + DEC_LUT_BITS;
+    uint32_t node = 0;
+    uint32_t p = pos;
     for (;;) {
         if (p >= lim) return (uint64_t)CW_EXH << 40;
-        const uint32_t bit = (st[p >> 5] >> (31u - (p & 31u))) & 1u;
+        const uint32_t bit = (rev_word(top, p >> 5) >> (31u - (p & 31u))) & 1u;
         p++;
         const uint32_t nx = dec_child(sh.lr[node], bit);
         if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
@@ -230,22 +249,18 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
             const uint32_t idx = x0 + j;
             const uint32_t v = idx << (32 - DEC_LUT_BITS);
             if (v >> 31) {
-                /* the first bit leaves the tree (the root has no right child); the run of bits that fail
-                 * the same way, as in dec_build_tables */
-                const uint32_t skip = dmin<uint32_t>((uint32_t)__clz((int)~v), (uint32_t)DEC_LUT_BITS);
-                e[j] = DEC_E_BAD | DEC_E_NOCW | (skip << 8) | 1u;
+                e[j] = DSE_BAD;                  /* the first bit leaves the tree (the root has no right child) */
             } else {
                 while (k + 1u < K && code[k + 1u] <= v) k++;
                 const uint32_t dk = F::len(sh)[k];
-                e[j] = (dk <= (uint32_t)DEC_LUT_BITS) ? ((dk << 8) | (uint32_t)F::sym(sh)[k]) : (uint32_t)DEC_E_LONG;
+                e[j] = (dk <= (uint32_t)DEC_LUT_BITS) ? (((uint32_t)F::sym(sh)[k] << 8) | dk) : (uint32_t)DSE_LONG;
             }
         }
         *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
     /* ---- second level: the subtree below a 12-bit prefix whose codes are at most DSUB_L2_BITS longer
-     *      gets a table of its own in the LDS the tree entries occupied (they are not needed any more):
-     *      entry 0x8000 | (bits - 1) << 10 | offset in the first table, (length << 8) | byte in the second.
-     *      Codes beyond that keep their `long` entry. ---- */
+     *      gets a table of its own (2, 4 or 6 more bits) in the LDS the tree entries occupied (they are not
+     *      needed any more).  Codes beyond that keep their `long` entry. ---- */
     __syncthreads();                                     /* the first table is written, the tree entries are done with */
     {
         uint16_t *l2 = reinterpret_cast<uint16_t *>(sh.ent);
@@ -264,22 +279,22 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
             }
             const bool closed = !(jn < K && (code[jn] >> (32 - DEC_LUT_BITS)) == P);
             if (closed && maxd <= (uint32_t)DEC_LUT_BITS + DSUB_L2_BITS) {
-                nb = maxd - DEC_LUT_BITS;
+                nb = (maxd - DEC_LUT_BITS + 1u) & ~1u;
                 size = 1u << nb;
                 run_end = jn;
             }
         }
         uint32_t total;
-        const uint32_t off = block_excl_scan_u32<THREADS>(size, sh.part, total);
+        const uint32_t off = block_excl_scan_u32<THREADS>(size, sh.part, total);          /* (sizes are multiples of 4: so are the offsets) */
         if (size && off + size <= DSUB_L2_ENTRIES) {
             for (uint32_t jn = k; jn < run_end; jn++) {
                 const uint32_t dj = len[jn];
                 const uint32_t first = (code[jn] >> (32 - DEC_LUT_BITS - nb)) & (size - 1u);
                 const uint32_t count = 1u << (DEC_LUT_BITS + nb - dj);
-                const uint16_t entry = (uint16_t)((dj << 8) | (uint32_t)F::sym(sh)[jn]);
+                const uint16_t entry = (uint16_t)(((uint32_t)F::sym(sh)[jn] << 8) | dj);
                 for (uint32_t i = 0; i < count; i++) l2[off + first + i] = entry;
             }
-            sh.lut[P] = (uint16_t)(0x8000u | ((nb - 1u) << 10) | off);
+            sh.lut[P] = (uint16_t)(((off >> 2) << 8) | ((nb / 2u - 1u) << 6) | DSE_L2);
         }
         if (tid == 0) sh.l2n = dmin<uint32_t>(total, DSUB_L2_ENTRIES);
     }
@@ -288,23 +303,45 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
     return true;
 }
 
+/* The tables of dec_build_tables (any grammar-valid tree; taken when dsub_fast_tables declines) in the sub-index
+ * path's entry format: eight entries per thread.  `long` codes are then walked from the root. */
+template <int THREADS>
+__device__ __forceinline__ void dsub_convert_tables(DecShared<THREADS> &sh)
+{
+    static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
+    uint32_t *t = reinterpret_cast<uint32_t *>(sh.lut) + 4 * threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t two = t[i];
+        uint32_t r = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t e = (two >> (16 * h)) & 0xffffu;
+            const uint32_t n = (e >= DEC_E_LONG) ? DSE_LONG : (e >= DEC_E_BAD) ? DSE_BAD : (((e & 0xffu) << 8) | (e >> 8));
+            r |= n << (16 * h);
+        }
+        t[i] = r;
+    }
+    if (threadIdx.x == 0) { sh.fastk = 0; sh.l2n = 0; }
+    __syncthreads();
+}
+
 /* a second-level entry of the first table resolved with the 32 bits at the codeword's start */
 template <int THREADS>
 __device__ __forceinline__ uint32_t dsub_l2(const DecShared<THREADS> &sh, uint32_t e, uint32_t bits32)
 {
-    const uint32_t nb = ((e >> 10) & 7u) + 1u;
-    return reinterpret_cast<const uint16_t *>(sh.ent)[(e & 0x3ffu) + ((bits32 << DEC_LUT_BITS) >> (32u - nb))];
+    const uint32_t nb = ((e >> 5) & 6u) + 2u;
+    return reinterpret_cast<const uint16_t *>(sh.ent)[((e >> 8) << 2) + ((bits32 << DEC_LUT_BITS) >> (32u - nb))];
 }
-#define DSUB_IS_L2(e) (((e) & 0xC000u) == 0x8000u)
 
 /* a codeword longer than the table's 12 bits with dsub_fast_tables' tables: the leaf whose code
  * interval holds the 32 bits at the position; result as dec_rare_packed */
 template <int THREADS>
-__device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, const uint32_t *st, uint32_t pos, uint32_t lim)
+__device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t pos, uint32_t lim)
 {
     typedef DsubFastLds<THREADS> F;
     const uint32_t g = pos >> 5, o = pos & 31u;
-    const uint32_t w = o ? ((st[g] << o) | (st[g + 1] >> (32u - o))) : st[g];
+    const uint32_t w = o ? ((rev_word(top, g) << o) | (rev_word(top, g + 1) >> (32u - o))) : rev_word(top, g);
     if (w >> 31) return ((uint64_t)CW_BAD << 40) | (pos + 1u);
     const uint32_t k = dsub_leaf_of(F::code(sh), sh.fastk, w);
     const uint32_t p = pos + (uint32_t)F::len(sh)[k];
@@ -312,29 +349,30 @@ __device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, 
     return ((uint64_t)CW_OK << 40) | ((uint64_t)F::sym(sh)[k] << 32) | p;
 }
 
-/* One table step of a lane: returns the entry (low byte = symbol); *ok is cleared when the lookup is
- * not a codeword.  The rare paths sit behind one wave-uniform branch. */
+/* One table step of a lane on the step-by-step path: returns the entry (high byte = symbol); *ok is cleared
+ * when the lookup is not a codeword.  The rare paths sit behind one wave-uniform branch. */
 template <int THREADS>
-__device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, LinReader &rd, uint32_t lim, bool &ok)
+__device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, RevReader &rd, uint32_t lim, bool &ok)
 {
     uint32_t e = sh.lut[rd.index()];
-    if (DSUB_IS_L2(e)) e = dsub_l2<THREADS>(sh, e, rd.hi);
-    if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
-        if (e >= DEC_E_LONG) {
-            const uint64_t r = sh.fastk ? dec_rare_fast<THREADS>(sh, rd.st, rd.pos(), lim) : dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
+    if (__builtin_expect(__ballot(DSE_LEN(e) == 0u) != 0ull, 0)) {
+        if (DSE_IS_L2(e)) {
+            e = dsub_l2<THREADS>(sh, e, rd.hi);
+        } else if (e == DSE_LONG) {
+            const uint64_t r = sh.fastk ? dec_rare_fast<THREADS>(sh, rd.top, rd.pos(), lim) : dsub_rare_walk<THREADS>(sh, rd.top, rd.pos(), lim);
             if ((int)(r >> 40) == CW_OK) {
                 rd.load((uint32_t)r);
-                e = (uint32_t)(r >> 32) & 0xffu;           /* advance 0: the reader already stands behind it */
+                e = ((uint32_t)(r >> 32) & 0xffu) << 8;    /* advance 0: the reader already stands behind it */
             } else {
                 ok = false;
-                e = 0x0100u;
+                e = 1u;
             }
-        } else if (e >= DEC_E_BAD) {
+        } else if (DSE_LEN(e) == 0u) {
             ok = false;
-            e = 0x0100u;                                   /* keep moving: the lane's result is discarded anyway */
+            e = 1u;                                        /* keep moving: the lane's result is discarded anyway */
         }
     }
-    rd.consume(e >> 8);
+    rd.consume(DSE_LEN(e));
     return e;
 }
 
@@ -380,42 +418,76 @@ __device__ __forceinline__ void dsub_prefetch(DecShared<THREADS> &sh, const uint
 /* A group again, step by step with the rare paths (long codes; the block's last, short group).
  * Out of line: inlined, its state competes with the hot loop's for the 64 VGPRs. */
 template <int THREADS>
-__device__ __noinline__ bool dsub_redo_group(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t s, uint32_t nsym,
+__device__ __noinline__ bool dsub_redo_group(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t s, uint32_t nsym,
                                              uint32_t lim, uint32_t gb, uint8_t *dst)
 {
     bool ok = true;
-    LinReader rd;
-    rd.st = stage;
+    RevReader rd;
+    rd.top = top;
     rd.load(s);
     for (uint32_t k = 0; k < nsym; k++) {
-        dst[k] = (uint8_t)dsub_next<THREADS>(sh, rd, lim, ok);
+        dst[k] = (uint8_t)(dsub_next<THREADS>(sh, rd, lim, ok) >> 8);
         if (rd.avail <= 32) rd.refill();
     }
     return ok && rd.pos() - s == gb;
 }
 
+/* A wave tile whose bits do not fit the wave's slice in one piece (codes far longer than the 9-bit average), or
+ * whose words cannot be loaded 16 bytes at a time (the stream ends right behind them): the lanes in several
+ * runs, staged word by word, decoded step by step.  Rare, and out of line for the hot path's registers.
+ * first = the tile's first payload bit, ex / incl = the lane's exclusive / inclusive bit counts inside the tile,
+ * active = the lane's group is to be decoded. */
+template <int THREADS>
+__device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32_t *top, const uint8_t *pay, uint64_t pay_bytes,
+                                            uint64_t first_bit, uint32_t ex, uint32_t incl, uint32_t nsym, bool active, uint8_t *dst)
+{
+    constexpr uint32_t CAP_BITS = DsubLds<THREADS>::CAP_BITS;
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t gb = incl - ex;
+    bool ok = true;
+    uint32_t l0 = 0;
+    while (l0 < 64u) {
+        const uint32_t base = wave_lane_u32(ex, uni32(l0));
+        const uint64_t first = first_bit + base;
+        const uint64_t origin = first & ~31ull;                  /* payload bit of stage word 0 */
+        const uint32_t lead = (uint32_t)(first - origin);
+        const unsigned long long over = __ballot(lane >= l0 && lead + (incl - base) > CAP_BITS);
+        const uint32_t l1 = over ? (uint32_t)__builtin_ctzll(over) : 64u;      /* > l0: one group always fits */
+        const uint32_t need_bits = lead + (wave_lane_u32(incl, uni32(l1 - 1u)) - base);
+        const uint32_t nwords = ((need_bits + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;   /* <= SLICE_WORDS - 4 */
+        const uint32_t lim = ((need_bits + 31u) >> 5) * 32u + 64u;                  /* bits a walk may look at */
+        for (uint32_t i = lane; i < nwords; i += 64u)
+            top[-(int32_t)i] = load_be32(pay, (origin >> 3) + 4ull * i, pay_bytes);
+        if (lane >= l0 && lane < l1 && nsym && active) {
+            if (!dsub_redo_group<THREADS>(sh, top, lead + (ex - base), nsym, lim, gb, dst)) ok = false;
+        }
+        l0 = l1;
+    }
+    return ok;
+}
+
 /* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.
  * Tables are in sh, dsub_prefetch has been called.  Returns true (workgroup-uniform) when everything
  * was verified; *end_bit = the payload bit behind the chunk's last symbol.  T0 = the chunk's first
- * payload bit, as told.
+ * payload bit, as told; readable = bytes that may be loaded from `pay` on (to the end of the stream).
  *
  * After one scan of the group counts every WAVE is on its own: a wave tile = 64 groups = 2 048
  * symbols; wave w takes tiles w, w + 8, ...; it stages the tile's payload words in its private LDS
- * slice (LDS operations of one wave are in order: no barrier), decodes, stores.  The waves of a
- * workgroup drift apart, so one wave's memory latency passes under the other waves' decoding; the
- * version with workgroup-wide tiles spent 2/3 of its time in barriers behind loads. */
+ * slice (LDS operations of one wave are in order: no barrier), decodes, stores.  The words of the wave's
+ * NEXT tile are requested before it decodes this one and wait in twelve registers: the HBM latency
+ * (a quarter of a workgroup's life when every tile waited for its own loads) passes under the decoding. */
 template <int THREADS>
-__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes,
+__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable,
                                    uint64_t sym0, uint64_t sym1, uint64_t T0, uint8_t *gout, uint64_t *end_bit)
 {
     typedef DsubLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP_BITS = L::CAP_BITS;
     const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = (int)uni32((uint32_t)tid >> 6);       /* (the compiler does not know that a wave's threads share tid >> 6) */
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint16_t *s_gb = reinterpret_cast<const uint16_t *>(L::gb(sh));
-    uint32_t *stage = L::slice(sh, wave);
+    uint32_t *top = L::slice(sh, wave) + (L::SLICE_WORDS - 1u);      /* staged word g of the wave's tile at top[-g] */
     const uint32_t ngrp = (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL);
     bool ok = true;
     unsigned long long pt = DPROF_T();
@@ -426,7 +498,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     __syncthreads();
     if (sym0 == 0 && T0 != 0) ok = false;          /* (a) */
 
-    /* bits of every wave tile, then their exclusive sums (lane q of every wave holds tile q's) */
+    /* bits of every wave tile, then their inclusive sums (lane q of every wave holds tile q's) */
 #pragma unroll
     for (uint32_t k = 0; k < L::WTILES / WAVES; k++) {
         const uint32_t q = (uint32_t)wave * (L::WTILES / WAVES) + k;
@@ -437,16 +509,67 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
         if (lane == 0) sh.wtile[q] = v;
     }
     __syncthreads();
-    const uint32_t tbits_q = ((uint32_t)lane < L::WTILES) ? sh.wtile[lane] : 0u;
-    const uint32_t tincl = wave_incl_scan_u32(tbits_q);
-    const uint32_t tstart_q = tincl - tbits_q;                       /* lane q: first bit of tile q relative to T0 */
+    const uint32_t tincl = wave_incl_scan_u32(((uint32_t)lane < L::WTILES) ? sh.wtile[lane] : 0u);   /* lane q: bits of tiles 0 .. q */
     const uint32_t chunk_bits = wave_lane_u32(tincl, 63);
     if (T0 + chunk_bits > pay_bits) ok = false;                      /* (b): bits past the payload */
     const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
     DPROF_ADD(8, pt);
 
+    typedef const __attribute__((address_space(3))) uint32_t *lds_words;
+    typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
+    typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
+    typedef uint32_t dwords4 __attribute__((ext_vector_type(4)));
+    typedef dwords4 dwords4_a4 __attribute__((aligned(4)));                       /* 16 bytes at a 4-byte aligned address */
+    typedef const __attribute__((address_space(1))) dwords4_a4 *global_q4;
+    /* The position register: R = 8 * (LDS byte address of top[-1]) + 31 - (position - 1), position = bits from the
+     * stage's word 0.  With the words in reversed order, (R >> 3) & ~3 IS the LDS address of the SECOND word of the
+     * pair that holds bit position - 1, and the low five bits of R are the amount v_alignbit_b32 shifts that pair
+     * by to leave the 32 bits at the position (0..31: the position is never the pair's first bit) - no negation,
+     * and a codeword is R -= len. */
+    const uint32_t r_origin = 8u * (uint32_t)(uintptr_t)(lds_words)(top - 1) + 32u;       /* R of position 0 */
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
+    const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
+
+    /* A tile's staging, all wave-uniform: word 0 of the stage is the aligned 32-bit word of MEMORY that holds the
+     * tile's first bit (the stage words are then byte-swapped dwords, whatever the payload's alignment);
+     * `lead` = bits of that word in front of the tile, `nwords` = words to stage; `quick` = its bits fit the slice
+     * and 16-byte loads of all of them stay inside the stream. */
+    uint32_t q = (uint32_t)wave;
+    uint4 V[3];
+    uint32_t lead = 0, nwords = 0;
+    bool quick = false;
+    uint64_t first = 0;
+#define DSUB_GEOMETRY(Q_)                                                                                      \
+    {                                                                                                         \
+        const uint32_t t0_ = (Q_) ? wave_lane_u32(tincl, (Q_) - 1u) : 0u;                                      \
+        const uint32_t tb_ = wave_lane_u32(tincl, (Q_)) - t0_;                                                 \
+        first = T0 + t0_;                                                                                     \
+        const uintptr_t a_ = pay_a + (uintptr_t)(first >> 3);                                                 \
+        lead = (uint32_t)(first & 7u) + 8u * (uint32_t)(a_ & 3u);                                             \
+        const uint32_t need_ = lead + tb_;                                                                    \
+        nwords = ((need_ + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;                                                \
+        /* (the aligned word may begin up to 3 bytes in front of the payload: header and tree lie there) */      \
+        quick = need_ <= CAP_BITS && (uint64_t)(a_ & ~(uintptr_t)3) + 4ull * nwords + 16ull <= (uint64_t)pay_a + readable; \
+        if (quick) {                                                                                          \
+            global_bytes base_ = (global_bytes)(a_ & ~(uintptr_t)3);                                          \
+            const uint32_t last16_ = 4u * ((nwords - 1u) & ~3u);                                              \
+            _Pragma("unroll")                                                                                 \
+            for (int k = 0; k < 3; k++) {                                                                     \
+                /* every lane loads (lanes past the needed words load the last ones again and do not store them) */ \
+                const uint32_t off_ = dmin<uint32_t>(16u * (uint32_t)lane + 1024u * (uint32_t)k, last16_);    \
+                const dwords4 v_ = *(global_q4)(base_ + off_);                                                \
+                V[k] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                                    \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    if (q * 64u < ngrp) DSUB_GEOMETRY(q)
+    /* what the loop leaves for later (bit i = the wave's i-th tile): tiles that are not `quick`, and - per lane -
+     * groups to be decoded again step by step.  Those go through dsub_tile_slow BEHIND the loop: a call inside
+     * it would have the loop's registers saved and restored around a path that is next to never taken. */
+    uint32_t slow_tiles = 0, redo_tiles = 0;
+
 #pragma unroll 1
-    for (uint32_t q = (uint32_t)wave; q * 64u < ngrp; q += WAVES) {
+    for (uint32_t ti = 0; q * 64u < ngrp; q += WAVES, ti++) {
         pt = DPROF_T();
         const uint32_t g = q * 64u + (uint32_t)lane;
         const uint64_t my0 = sym0 + (uint64_t)g * DSUB_SPL;
@@ -457,227 +580,117 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
         }
         const uint32_t incl = wave_incl_scan_u32(gb);
         const uint32_t ex = incl - gb;                               /* my first bit relative to the tile's */
-        const uint64_t tstart = T0 + wave_lane_u32(tstart_q, uni32(q));
-
-        /* one pass stages the bits of all 64 lanes; only when they do not fit the slice (codes far
-         * longer than the 9-bit average) the lanes are taken in several runs */
-        uint32_t l0 = 0;
-        while (l0 < 64u) {
-            const uint32_t base = wave_lane_u32(ex, uni32(l0));
-            const uint64_t first = tstart + base;
-            const uint64_t origin = first & ~31ull;                  /* payload bit of stage word 0 */
-            const uint32_t lead = (uint32_t)(first - origin);
-            const unsigned long long over = __ballot((uint32_t)lane >= l0 && lead + (incl - base) > CAP_BITS);
-            const uint32_t l1 = over ? (uint32_t)__builtin_ctzll(over) : 64u;      /* > l0: one group always fits */
-            const uint32_t need_bits = lead + (wave_lane_u32(incl, uni32(l1 - 1u)) - base);
-            const uint32_t nwords = ((need_bits + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;   /* <= SLICE_WORDS - 4 */
-            const uint32_t lim = ((need_bits + 31u) >> 5) * 32u + 64u;                  /* bits a walk may look at */
-#ifndef DSUB_ABLATE_STAGE
-            {
-                /* Four words per lane and step: 20 payload bytes at a 4-byte aligned address (one
-                 * 16-byte and one 4-byte load), four v_perm (byte order and the payload's byte
-                 * misalignment in one selector), one 16-byte LDS store; all loads before the first use. */
-                struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
-                constexpr int STEPS = 3;
-                const uint64_t byte0 = origin >> 3;
-                if (byte0 + 4ull * nwords + 24ull <= pay_bytes) {
-                    const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));
-                    const uint32_t m = (uint32_t)(a & 3u);
-                    const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
-                    const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
-                    Q4 v[STEPS];
-                    uint32_t x[STEPS];
-                    /* every lane loads (lanes past the needed words load the last ones again and do not
-                     * store them): a load under a condition leaves its 15 destination registers
-                     * "maybe unchanged", which the compiler then carries around the whole tile loop */
-                    const uint32_t last4 = (nwords - 1u) & ~3u;
+        uint8_t *dst = gout + my0;
+        const uint32_t qn = q + WAVES;
+        if (!quick) {
+            slow_tiles |= 1u << ti;
+            if (qn * 64u < ngrp) DSUB_GEOMETRY(qn)
+            continue;
+        }
+        const uint32_t s = lead + ex;
+        /* the words into the slice: four byte-swapped dwords per lane and step, one 16-byte LDS store
+         * (words i4 .. i4 + 3 at top[-i4 - 3 .. -i4]) */
 #pragma unroll
-                    for (int k = 0; k < STEPS; k++) {
-                        const uint32_t i4 = dmin<uint32_t>(4u * ((uint32_t)lane + 64u * (uint32_t)k), last4);
-                        v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
-                        x[k] = qw[i4 + 4];
-                    }
-#pragma unroll
-                    for (int k = 0; k < STEPS; k++) {
-                        const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
-                        if (i4 < nwords)
-                            *reinterpret_cast<uint4 *>(stage + i4) =
-                                make_uint4(__builtin_amdgcn_perm(v[k].y, v[k].x, sel), __builtin_amdgcn_perm(v[k].z, v[k].y, sel),
-                                           __builtin_amdgcn_perm(v[k].w, v[k].z, sel), __builtin_amdgcn_perm(x[k], v[k].w, sel));
-                    }
-                } else {
-                    for (uint32_t i = (uint32_t)lane; i < nwords; i += 64u)
-                        stage[i] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
-                }
-            }
-#endif
-            DPROF_ADD(9, pt); pt = DPROF_T();
-#ifdef DSUB_ABLATE_LANES
-            if (false) {
-#else
-            if ((uint32_t)lane >= l0 && (uint32_t)lane < l1 && nsym) {
-#endif
-                const uint32_t s = lead + (ex - base);
-                LinReader rd;
-                rd.st = stage;
-                rd.load(s);
-                uint8_t *dst = gout + my0;
-                uint32_t special = 0;                               /* OR of the table entries: bits 14/15 = not a leaf */
-                if (nsym == DSUB_SPL) {
-                    /* The common case has no branch: an entry that is not a leaf (a `long` code, a
-                     * walk that leaves the tree) advances by its 5-bit field like a leaf and is only
-                     * remembered; such a lane decodes its group again below, step by step.
-                     * Two rounds of 16 symbols (rolled: the unrolled form does not fit 64 VGPRs), each
-                     * stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half of a
-                     * 32-byte sector and the other half follows a round later; streaming (nt) stores
-                     * then reach HBM as partial writes (1.05 -> 0.81 ms per GiB without nt; turning the
-                     * wave's 2 KiB round in LDS for whole-line nt stores needs 8 more registers, and with
-                     * 80 VGPRs = 3 workgroups per CU the kernel takes 0.97 ms). */
-                    const bool aligned = (((uintptr_t)dst) & 15u) == 0;
-#ifndef DSUB_BUF_READER
-                    /* Position-based window: every two symbols the 64 bits at the position are read
-                     * again from the stage (one ds_read2_b32, one 64-bit shift) - no bit buffer to
-                     * refill, no branch: 8 wave instructions per symbol where the refilled 64-bit buffer
-                     * (-DDSUB_BUF_READER) has 14, most of them in the refill block that some lane needs at
-                     * every test; more LDS reads instead (zipf255 0.65 -> 0.62 ms, uniform bytes +-0). */
-#ifndef DSUB_WINDOW_V1
-                    /* The position register holds (payload bit - 1) + 8 * (LDS byte address of the
-                     * stage): (Q >> 3) & ~3 IS the LDS address of the word pair, and the 32 bits at the
-                     * position are ONE v_alignbit_b32 of the pair by ~Q (shift amounts 0..31: the pair
-                     * is the one that holds bit position - 1, so the position is never the pair's first
-                     * bit).  The second table index comes from a 32-bit shift of that register: 13 simple
-                     * instructions per two symbols where the 64-bit window (-DDSUB_WINDOW_V1) had 15 with
-                     * two 64-bit shifts (zipf255 0.643 -> 0.626 ms).
-                     * (Measured and dropped: a lane decoding the two halves of its group side by side -
-                     * the encoder also wrote the bits of every group's first half - to have two
-                     * independent chains of LDS reads per lane.  At 64 VGPRs the tile loop spills
-                     * (0.88 ms), at 78 VGPRs = 3 workgroups per CU it takes 0.72 ms: the loop is bound by
-                     * VALU + LDS throughput, not by the latency of its dependent reads.) */
-                    typedef const __attribute__((address_space(3))) uint32_t *lds_words;
-                    typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
-                    const uint32_t q0 = s - 1u + 8u * (uint32_t)(uintptr_t)(lds_words)stage;
-                    const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
+        for (int k = 0; k < 3; k++) {
+            const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
+            if (i4 < nwords)
+                *reinterpret_cast<uint4 *>(top - (i4 + 3u)) =
+                    make_uint4(__builtin_bswap32(V[k].w), __builtin_bswap32(V[k].z), __builtin_bswap32(V[k].y), __builtin_bswap32(V[k].x));
+        }
+        /* the next tile's words are on their way while this one is decoded */
+        if (qn * 64u < ngrp) DSUB_GEOMETRY(qn)
+        DPROF_ADD(9, pt); pt = DPROF_T();
+        if (nsym) {
+            bool redo = nsym != DSUB_SPL;                       /* the block's last, short group */
+            bool group_ok = false;
+            if (nsym == DSUB_SPL) {
+                /* The common case has no branch.  Every two symbols the 32 bits at the position are read
+                 * again from the stage (one ds_read2_b32, one v_alignbit_b32) - no bit buffer to refill -
+                 * and looked up twice; the entries' low five bits shift the window and their sum moves the
+                 * position as they stand.  An entry that is not a leaf has length 0: the lane stands still
+                 * from then on (a `long` code, a walk that leaves the tree: the low byte is 0) and its last
+                 * look-up tells; such a lane decodes its group again below, step by step.
+                 * Two rounds of 16 symbols (rolled: the unrolled form does not fit 64 VGPRs), each
+                 * stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half of a
+                 * 32-byte sector and the other half follows a round later; streaming (nt) stores
+                 * then reach HBM as partial writes.
+                 * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
+                 * symbol; a lane decoding the two halves of its group side by side.) */
+                const bool aligned = (((uintptr_t)dst) & 15u) == 0;
+                const uint32_t r0 = r_origin - s;
+                uint32_t R = r0;
+                uint32_t special = 0, e_last = 0;
 /* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
- * wave by a ballot - goes on to the second table with the bits behind the 12-bit prefix.  Blocks
- * without such codes (zipf255, uniform bytes) run the loop without the two ballots per window. */
-#define DSUB_WINDOW(Q, acc, L2)                                                                               \
-                    {                                                                                         \
-                        lds_words wp_ = (lds_words)(uintptr_t)(((Q) >> 3) & ~3u);                              \
-                        const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[0], wp_[1], ~(Q));                 \
-                        uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));          \
-                        if (L2 && __ballot(DSUB_IS_L2(e1_))) {                                                \
-                            if (DSUB_IS_L2(e1_)) e1_ = dsub_l2<THREADS>(sh, e1_, d1_);                        \
-                        }                                                                                     \
-                        const uint32_t l1_ = (e1_ >> 8) & 31u;                                                \
-                        const uint32_t d2_ = d1_ << l1_;                                                      \
-                        uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));          \
-                        if (L2 && __ballot(DSUB_IS_L2(e2_))) {                                                \
-                            /* (the window has 32 - l1 bits left: a second code of the second level behind  \
-                             *  a long first one is left to the step-by-step path) */                        \
-                            if (DSUB_IS_L2(e2_))                                                              \
-                                e2_ = (l1_ + DEC_LUT_BITS + DSUB_L2_BITS <= 32u) ? dsub_l2<THREADS>(sh, e2_, d2_) : (uint32_t)DEC_E_LONG; \
-                        }                                                                                     \
-                        special |= e1_ | e2_;                                                                 \
-                        acc = __builtin_amdgcn_alignbit(e1_, acc, 8);                                         \
-                        acc = __builtin_amdgcn_alignbit(e2_, acc, 8);                                         \
-                        (Q) += l1_ + ((e2_ >> 8) & 31u);                                                      \
-                    }
+ * wave by a ballot - goes on to the second table with the bits behind the 12-bit prefix; one that cannot
+ * (too few bits left in the window) stays what it is and is remembered in `special`.  Blocks
+ * without such codes (zipf255, uniform bytes) run the loop without the ballots. */
+#define DSUB_WINDOW(PAIR, L2)                                                                                 \
+                {                                                                                             \
+                    lds_words wp_ = (lds_words)(uintptr_t)((R >> 3) & ~3u);                                    \
+                    const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[1], wp_[0], R);                         \
+                    uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));              \
+                    if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
+                        if (DSE_IS_L2(e1_)) e1_ = dsub_l2<THREADS>(sh, e1_, d1_);                             \
+                    }                                                                                         \
+                    const uint32_t d2_ = d1_ << (e1_ & 31u);                                                  \
+                    uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));              \
+                    if (L2 && __ballot(DSE_IS_L2(e2_))) {                                                     \
+                        /* (the window has 32 - len bits left) */                                             \
+                        if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
+                            e2_ = dsub_l2<THREADS>(sh, e2_, d2_);                                             \
+                    }                                                                                         \
+                    if (L2) special |= e1_ | e2_;                                                             \
+                    R -= (e1_ + e2_) & 0xffu;                                                                 \
+                    PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
+                    e_last = e2_;                                                                             \
+                }
 #define DSUB_ROUNDS(L2)                                                                                        \
-                    _Pragma("unroll 1")                                                                       \
-                    for (int h = 0; h < 2; h++) {                                                             \
-                        uint32_t w[4];                                                                        \
+                _Pragma("unroll 1")                                                                           \
+                for (int h = 0; h < 2; h++) {                                                                 \
+                    uint32_t w[4];                                                                            \
+                    _Pragma("unroll")                                                                         \
+                    for (int k = 0; k < 4; k++) {                                                             \
+                        uint32_t p01, p23;                                                                    \
+                        DSUB_WINDOW(p01, L2)                                                                  \
+                        DSUB_WINDOW(p23, L2)                                                                  \
+                        w[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                  \
+                    }                                                                                         \
+                    if (aligned) {                                                                            \
+                        reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);               \
+                    } else {                                                                                  \
                         _Pragma("unroll")                                                                     \
-                        for (int k = 0; k < 4; k++) {                                                         \
-                            uint32_t acc = 0;                                                                 \
-                            _Pragma("unroll")                                                                 \
-                            for (int j = 0; j < 2; j++) DSUB_WINDOW(Q, acc, L2)                               \
-                            w[k] = acc;                                                                       \
-                        }                                                                                     \
-                        if (aligned) {                                                                        \
-                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);           \
-                        } else {                                                                              \
-                            _Pragma("unroll")                                                                 \
-                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
-                        }                                                                                     \
-                    }
-                    uint32_t Q = q0;
-                    if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }
+                        for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
+                    }                                                                                         \
+                }
+                if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }
 #undef DSUB_ROUNDS
 #undef DSUB_WINDOW
-                    const uint32_t p = s + (Q - q0);
-#else
-                    uint32_t p = s;
-#pragma unroll 1
-                    for (int h = 0; h < 2; h++) {
-                        uint32_t w[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t acc = 0;
-#pragma unroll
-                            for (int j = 0; j < 2; j++) {
-                                const uint32_t *wp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(stage) + ((p >> 3) & ~3u));
-                                uint64_t b = (((uint64_t)wp[0] << 32) | wp[1]) << (p & 31u);
-                                const uint32_t e1 = sh.lut[(uint32_t)(b >> 32) >> (32 - DEC_LUT_BITS)];
-                                const uint32_t l1 = (e1 >> 8) & 31u;
-                                b <<= l1;
-                                const uint32_t e2 = sh.lut[(uint32_t)(b >> 32) >> (32 - DEC_LUT_BITS)];
-                                special |= e1 | e2;
-                                acc = __builtin_amdgcn_alignbit(e1, acc, 8);
-                                acc = __builtin_amdgcn_alignbit(e2, acc, 8);
-                                p += l1 + ((e2 >> 8) & 31u);
-                            }
-                            w[k] = acc;
-                        }
-                        if (aligned) {
-                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                        }
-                    }
-#endif
-                    rd.load(p);
-                }
-#else
-#pragma unroll 1
-                    for (int h = 0; h < 2; h++) {
-                        uint32_t w[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t acc = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const uint32_t e = sh.lut[rd.index()];
-                                special |= e;
-                                acc = __builtin_amdgcn_alignbit(e, acc, 8);
-                                rd.consume((e >> 8) & 31u);
-                                if (j & 1) { if (rd.avail <= 32) rd.refill(); }
-                            }
-                            w[k] = acc;
-                        }
-#ifdef DSUB_ABLATE_STORES
-                        if (w[0] == 0x12345678u && w[3] == 0x9abcdef0u) dst[0] = 1;
-                        else if (false) {
-#else
-                        if (aligned) {
-#endif
-                            reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                        }
-                    }
-                }
-#endif
-                bool group_ok = rd.pos() - s == gb;                 /* (b): exactly the bits of the group */
-                if (__builtin_expect(__ballot(nsym != DSUB_SPL || (special & 0xC000u)) != 0ull, 0)) {
-                    if (nsym != DSUB_SPL || (special & 0xC000u))    /* the block's last, short group; groups with long codes */
-                        group_ok = dsub_redo_group<THREADS>(sh, stage, s, nsym, lim, gb, dst);
-                }
-                if (!group_ok) ok = false;
+                redo = DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u;
+                group_ok = r0 - R == gb;                        /* (b): exactly the bits of the group */
             }
-            DPROF_ADD(10, pt); pt = DPROF_T();
-            l0 = l1;
+            if (redo) redo_tiles |= 1u << ti;
+            else if (!group_ok) ok = false;
+        }
+        DPROF_ADD(10, pt);
+    }
+#undef DSUB_GEOMETRY
+    if (__builtin_expect(slow_tiles != 0u || __ballot(redo_tiles != 0u) != 0ull, 0)) {
+#pragma unroll 1
+        for (uint32_t ti = 0; ti < L::WTILES / WAVES; ti++) {
+            const bool whole = ((slow_tiles >> ti) & 1u) != 0u;
+            const bool mine = whole || ((redo_tiles >> ti) & 1u) != 0u;
+            if (!__ballot(mine)) continue;
+            q = (uint32_t)wave + ti * WAVES;
+            const uint32_t g = q * 64u + (uint32_t)lane;
+            const uint64_t my0 = sym0 + (uint64_t)g * DSUB_SPL;
+            uint32_t nsym = 0, gb = 0;
+            if (g < ngrp) {
+                nsym = (uint32_t)dmin<uint64_t>(DSUB_SPL, sym1 - my0);
+                gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
+            }
+            const uint32_t incl = wave_incl_scan_u32(gb);
+            const uint64_t tfirst = T0 + (q ? wave_lane_u32(tincl, q - 1u) : 0u);
+            if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + my0)) ok = false;
         }
     }
     *end_bit = T0 + chunk_bits;
@@ -704,10 +717,15 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
     unsigned long long *__restrict__ result, HufSubIndex sub, uint64_t blocksize, uint32_t cpb, DecFixList fix)
 {
     __shared__ DecShared<THREADS> sh;
+#ifdef DSUB_LDS_PAD             /* (occupancy experiments: fewer workgroups per CU) */
+    __shared__ uint32_t lds_pad[DSUB_LDS_PAD / 4];
+    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
+#endif
     static_assert(DSUB_CHUNK_SYMS % (THREADS * DSUB_SPL) == 0 && (THREADS * DSUB_SPL) % HUF_SUB_TILE == 0, "chunks are whole tiles");
     const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x / cpb;
     const uint32_t c = (uint32_t)(blockIdx.x % cpb);
+    unsigned long long kt = DPROF_T();
     /* everything about the block is the same in all lanes: kept in SGPRs (held in VGPRs these
      * values pushed the tile loop's state out to scratch, 8 reloads per wave tile) */
     HufDecodeMeta m = dmeta[blk];
@@ -746,14 +764,19 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
         dsub_prefetch<THREADS>(sh, sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL,
                                (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
     const uint64_t T0 = uni64(sub.tile_bits[blk * sub.tpb + sym0 / HUF_SUB_TILE]);   /* first payload bit of the chunk, as told */
+    DPROF_ADD(2, kt); kt = DPROF_T();
 #ifndef DSUB_ABLATE_TABLES      /* (diagnostic builds: what the kernel costs without one of its phases) */
     if (leaf < 0) {
 #ifndef DSUB_NO_FAST_TABLES
         if (!dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM))
 #endif
+        {
             rc = dec_build_tables<THREADS, false>(sh, tree, m.tree_len, &leaf);
+            if (rc == HUFE_OK && leaf < 0) dsub_convert_tables<THREADS>(sh);
+        }
     }
 #endif
+    DPROF_ADD(3, kt);
     if (rc != HUFE_OK) {
         good = false;
     } else if (leaf >= 0) {
@@ -764,7 +787,7 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
         uint64_t end_bit = 0;
-        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, sym0, sym1, T0, out + obase, &end_bit);
+        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), sym0, sym1, T0, out + obase, &end_bit);
         /* (c) the next chunk starts where this one ends */
         if (good && sym1 < m.block_len && sub.tile_bits[blk * sub.tpb + sym1 / HUF_SUB_TILE] != end_bit) good = false;
     }

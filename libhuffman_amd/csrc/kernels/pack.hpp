@@ -283,11 +283,8 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
         if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
         if (staged) {
-#ifdef PACK_DBG_GLOBAL_FLUSH
-            uint8_t *const g16 = reinterpret_cast<uint8_t *>(g_w0 + w_lo) - 4 * (size_t)i_lo;
-#else
-            uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
-#endif
+            uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);   /* (a flat store; as a global one - the pointer
+                                                                               derived from `out` - it is exactly as fast) */
             for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
                 const uint32_t i0 = 4 * u;
                 if (i0 >= i_lo && i0 + 4 <= i_hi) {

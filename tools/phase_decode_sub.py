@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from libhuffman_amd.codec import GpuCodec
 c = GpuCodec(0)
-names = {0: "tree", 1: "table", 8: "index+scan", 9: "staging", 10: "lanes"}
+names = {0: "tree", 1: "table", 2: "block setup", 3: "fast tables", 8: "index+scan", 9: "staging", 10: "lanes"}
 for wl in sys.argv[1:] or ["zipf255"]:
     n, bs = 1 << 30, 65536
     d = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(d, wl)

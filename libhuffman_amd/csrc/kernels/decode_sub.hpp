@@ -36,6 +36,9 @@ namespace hufgpu {
 #define DSUB_L2_ENTRIES 1024u               /* it lives in DecShared::ent */
 #define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: 31 table codewords + two refills of a lane that runs wild */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
+#ifndef DSUB_ROUNDS_UNROLL
+#define DSUB_ROUNDS_UNROLL "unroll"
+#endif
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
 
 /* The staged payload words of a wave lie in its LDS slice in REVERSED order: word g (big-endian, 32 payload bits)
@@ -469,7 +472,8 @@ __device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32
 /* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.
  * Tables are in sh, dsub_prefetch has been called.  Returns true (workgroup-uniform) when everything
  * was verified; *end_bit = the payload bit behind the chunk's last symbol.  T0 = the chunk's first
- * payload bit, as told; readable = bytes that may be loaded from `pay` on (to the end of the stream).
+ * payload bit, as told; readable = bytes that may be loaded from `pay` on (to the end of the stream); safe = an
+ * address with 19 readable bytes behind it (the block's header and tree).
  *
  * After one scan of the group counts every WAVE is on its own: a wave tile = 64 groups = 2 048
  * symbols; wave w takes tiles w, w + 8, ...; it stages the tile's payload words in its private LDS
@@ -477,7 +481,7 @@ __device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32
  * NEXT tile are requested before it decodes this one and wait in twelve registers: the HBM latency
  * (a quarter of a workgroup's life when every tile waited for its own loads) passes under the decoding. */
 template <int THREADS>
-__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable,
+__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, const uint8_t *safe,
                                    uint64_t sym0, uint64_t sym1, uint64_t T0, uint8_t *gout, uint64_t *end_bit)
 {
     typedef DsubLds<THREADS> L;
@@ -511,7 +515,10 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     __syncthreads();
     const uint32_t tincl = wave_incl_scan_u32(((uint32_t)lane < L::WTILES) ? sh.wtile[lane] : 0u);   /* lane q: bits of tiles 0 .. q */
     const uint32_t chunk_bits = wave_lane_u32(tincl, 63);
-    if (T0 + chunk_bits > pay_bits) ok = false;                      /* (b): bits past the payload */
+    if (T0 + chunk_bits > pay_bits) {                                /* (b): bits past the payload (the same in every thread) */
+        *end_bit = 0;
+        return false;
+    }
     const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
     DPROF_ADD(8, pt);
 
@@ -521,6 +528,8 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     typedef uint32_t dwords4 __attribute__((ext_vector_type(4)));
     typedef dwords4 dwords4_a4 __attribute__((aligned(4)));                       /* 16 bytes at a 4-byte aligned address */
     typedef const __attribute__((address_space(1))) dwords4_a4 *global_q4;
+    typedef __attribute__((address_space(1))) uint8_t *global_out;
+    typedef __attribute__((address_space(1))) dwords4 *global_out4;
     /* The position register: R = 8 * (LDS byte address of top[-1]) + 31 - (position - 1), position = bits from the
      * stage's word 0.  With the words in reversed order, (R >> 3) & ~3 IS the LDS address of the SECOND word of the
      * pair that holds bit position - 1, and the low five bits of R are the amount v_alignbit_b32 shifts that pair
@@ -529,6 +538,11 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     const uint32_t r_origin = 8u * (uint32_t)(uintptr_t)(lds_words)(top - 1) + 32u;       /* R of position 0 */
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
     const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
+    const uintptr_t cout_a = (uintptr_t)uni64((uint64_t)(uintptr_t)(gout + sym0));           /* the chunk's first output byte */
+    const global_out cout = (global_out)cout_a;
+    const uint32_t nchunk = (uint32_t)(sym1 - sym0);
+    const uint64_t end_a = uni64((uint64_t)pay_a + readable);                                 /* the stream's end */
+    const uintptr_t safe_a = ((uintptr_t)uni64((uint64_t)(uintptr_t)safe) + 3u) & ~(uintptr_t)3;
 
     /* A tile's staging, all wave-uniform: word 0 of the stage is the aligned 32-bit word of MEMORY that holds the
      * tile's first bit (the stage words are then byte-swapped dwords, whatever the payload's alignment);
@@ -538,31 +552,51 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     uint4 V[3];
     uint32_t lead = 0, nwords = 0;
     bool quick = false;
-    uint64_t first = 0;
-#define DSUB_GEOMETRY(Q_)                                                                                      \
+/* (The loads are issued - and waited for further down - for every tile, also when there is nothing to load: the words
+ * of the block's first bytes then, not stored.  Loads under a condition leave the compiler with "maybe pending"
+ * registers at the top of the loop, and its wait for those is a wait for the previous tile's STORES as well.) */
+#define DSUB_GEOMETRY(Q_, VALID_)                                                                              \
     {                                                                                                         \
-        const uint32_t t0_ = (Q_) ? wave_lane_u32(tincl, (Q_) - 1u) : 0u;                                      \
-        const uint32_t tb_ = wave_lane_u32(tincl, (Q_)) - t0_;                                                 \
-        first = T0 + t0_;                                                                                     \
-        const uintptr_t a_ = pay_a + (uintptr_t)(first >> 3);                                                 \
-        lead = (uint32_t)(first & 7u) + 8u * (uint32_t)(a_ & 3u);                                             \
+        const uint32_t qq_ = (VALID_) ? (Q_) : 0u;                                                            \
+        const uint32_t t0_ = qq_ ? wave_lane_u32(tincl, qq_ - 1u) : 0u;                                        \
+        const uint32_t tb_ = wave_lane_u32(tincl, qq_) - t0_;                                                  \
+        const uint64_t first_ = T0 + t0_;                                                                     \
+        const uintptr_t a_ = pay_a + (uintptr_t)(first_ >> 3);                                                \
+        lead = (uint32_t)(first_ & 7u) + 8u * (uint32_t)(a_ & 3u);                                            \
         const uint32_t need_ = lead + tb_;                                                                    \
         nwords = ((need_ + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;                                                \
         /* (the aligned word may begin up to 3 bytes in front of the payload: header and tree lie there) */      \
-        quick = need_ <= CAP_BITS && (uint64_t)(a_ & ~(uintptr_t)3) + 4ull * nwords + 16ull <= (uint64_t)pay_a + readable; \
-        if (quick) {                                                                                          \
-            global_bytes base_ = (global_bytes)(a_ & ~(uintptr_t)3);                                          \
-            const uint32_t last16_ = 4u * ((nwords - 1u) & ~3u);                                              \
-            _Pragma("unroll")                                                                                 \
-            for (int k = 0; k < 3; k++) {                                                                     \
-                /* every lane loads (lanes past the needed words load the last ones again and do not store them) */ \
-                const uint32_t off_ = dmin<uint32_t>(16u * (uint32_t)lane + 1024u * (uint32_t)k, last16_);    \
-                const dwords4 v_ = *(global_q4)(base_ + off_);                                                \
-                V[k] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                                    \
-            }                                                                                                 \
+        const int64_t left_ = (int64_t)(end_a - (uint64_t)(a_ & ~(uintptr_t)3));    /* readable bytes from the aligned word on */ \
+        quick = (VALID_) && need_ <= CAP_BITS && left_ >= (int64_t)(4u * nwords + 16u);                       \
+        global_bytes base_ = (global_bytes)(uintptr_t)uni64((uint64_t)(quick ? (a_ & ~(uintptr_t)3) : safe_a)); \
+        const uint32_t last16_ = uni32(quick ? 4u * ((nwords - 1u) & ~3u) : 0u);                              \
+        if (!quick) nwords = 0;                                                                               \
+        uint32_t ln_ = (uint32_t)lane;                                                                        \
+        asm volatile("" : "+v"(ln_));            /* (offsets computed here, not kept in registers around the tile loop) */ \
+        _Pragma("unroll")                                                                                     \
+        for (int k = 0; k < 3; k++) {                                                                         \
+            /* every lane loads (lanes past the needed words load the last ones again and do not store them) */ \
+            const uint32_t off_ = dmin<uint32_t>(16u * ln_ + 1024u * (uint32_t)k, last16_);                   \
+            const dwords4 v_ = *(global_q4)(base_ + off_);                                                    \
+            V[k] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                                        \
         }                                                                                                     \
     }
-    if (q * 64u < ngrp) DSUB_GEOMETRY(q)
+/* the loaded words into the slice: four byte-swapped dwords per lane and step, one 16-byte LDS store
+ * (words i4 .. i4 + 3 at top[-i4 - 3 .. -i4]) */
+#define DSUB_TO_SLICE()                                                                                        \
+    {                                                                                                         \
+        uint32_t ln_ = (uint32_t)lane;                                                                        \
+        asm volatile("" : "+v"(ln_));                                                                         \
+        _Pragma("unroll")                                                                                     \
+        for (int k = 0; k < 3; k++) {                                                                         \
+            const uint32_t i4 = 4u * (ln_ + 64u * (uint32_t)k);                                               \
+            if (i4 < nwords)                                                                                  \
+                *reinterpret_cast<uint4 *>(top - (i4 + 3u)) =                                                 \
+                    make_uint4(__builtin_bswap32(V[k].w), __builtin_bswap32(V[k].z), __builtin_bswap32(V[k].y), __builtin_bswap32(V[k].x)); \
+        }                                                                                                     \
+    }
+    DSUB_GEOMETRY(q, q * 64u < ngrp)
+    DSUB_TO_SLICE()
     /* what the loop leaves for later (bit i = the wave's i-th tile): tiles that are not `quick`, and - per lane -
      * groups to be decoded again step by step.  Those go through dsub_tile_slow BEHIND the loop: a call inside
      * it would have the loop's registers saved and restored around a path that is next to never taken. */
@@ -572,35 +606,20 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
     for (uint32_t ti = 0; q * 64u < ngrp; q += WAVES, ti++) {
         pt = DPROF_T();
         const uint32_t g = q * 64u + (uint32_t)lane;
-        const uint64_t my0 = sym0 + (uint64_t)g * DSUB_SPL;
+        const uint32_t my0 = g * DSUB_SPL;                              /* relative to the chunk: 32-bit arithmetic, one offset register */
         uint32_t nsym = 0, gb = 0;
         if (g < ngrp) {
-            nsym = (uint32_t)dmin<uint64_t>(DSUB_SPL, sym1 - my0);
+            nsym = dmin<uint32_t>(DSUB_SPL, nchunk - my0);
             gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
         }
-        const uint32_t incl = wave_incl_scan_u32(gb);
-        const uint32_t ex = incl - gb;                               /* my first bit relative to the tile's */
-        uint8_t *dst = gout + my0;
-        const uint32_t qn = q + WAVES;
-        if (!quick) {
-            slow_tiles |= 1u << ti;
-            if (qn * 64u < ngrp) DSUB_GEOMETRY(qn)
-            continue;
-        }
-        const uint32_t s = lead + ex;
-        /* the words into the slice: four byte-swapped dwords per lane and step, one 16-byte LDS store
-         * (words i4 .. i4 + 3 at top[-i4 - 3 .. -i4]) */
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t i4 = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
-            if (i4 < nwords)
-                *reinterpret_cast<uint4 *>(top - (i4 + 3u)) =
-                    make_uint4(__builtin_bswap32(V[k].w), __builtin_bswap32(V[k].z), __builtin_bswap32(V[k].y), __builtin_bswap32(V[k].x));
-        }
-        /* the next tile's words are on their way while this one is decoded */
-        if (qn * 64u < ngrp) DSUB_GEOMETRY(qn)
+        const uint32_t s = lead + wave_incl_scan_u32(gb) - gb;          /* the stage bit of my first symbol */
+        const bool cur_quick = quick;
+        /* the next tile's words are requested now and arrive while this one is decoded */
+        DSUB_GEOMETRY(q + WAVES, (q + WAVES) * 64u < ngrp)
         DPROF_ADD(9, pt); pt = DPROF_T();
-        if (nsym) {
+        if (!cur_quick) {
+            slow_tiles |= 1u << ti;
+        } else if (nsym) {
             bool redo = nsym != DSUB_SPL;                       /* the block's last, short group */
             bool group_ok = false;
             if (nsym == DSUB_SPL) {
@@ -609,14 +628,13 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                  * and looked up twice; the entries' low five bits shift the window and their sum moves the
                  * position as they stand.  An entry that is not a leaf has length 0: the lane stands still
                  * from then on (a `long` code, a walk that leaves the tree: the low byte is 0) and its last
-                 * look-up tells; such a lane decodes its group again below, step by step.
-                 * Two rounds of 16 symbols (rolled: the unrolled form does not fit 64 VGPRs), each
-                 * stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half of a
-                 * 32-byte sector and the other half follows a round later; streaming (nt) stores
-                 * then reach HBM as partial writes.
+                 * look-up tells; such a lane decodes its group again behind the loop, step by step.
+                 * 16 symbols are stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half
+                 * of a 32-byte sector and the other half follows; streaming (nt) stores then reach HBM as
+                 * partial writes.
                  * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
                  * symbol; a lane decoding the two halves of its group side by side.) */
-                const bool aligned = (((uintptr_t)dst) & 15u) == 0;
+                const bool aligned = (cout_a & 15u) == 0;             /* (the offset is a multiple of 32) */
                 const uint32_t r0 = r_origin - s;
                 uint32_t R = r0;
                 uint32_t special = 0, e_last = 0;
@@ -645,7 +663,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                     e_last = e2_;                                                                             \
                 }
 #define DSUB_ROUNDS(L2)                                                                                        \
-                _Pragma("unroll 1")                                                                           \
+                _Pragma(DSUB_ROUNDS_UNROLL)                                                                   \
                 for (int h = 0; h < 2; h++) {                                                                 \
                     uint32_t w[4];                                                                            \
                     _Pragma("unroll")                                                                         \
@@ -655,11 +673,16 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
                         DSUB_WINDOW(p23, L2)                                                                  \
                         w[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                  \
                     }                                                                                         \
+                    /* (the address from the 32-bit offset right here: scalar base + offset register, not a   \
+                     *  64-bit address kept in two registers around the loop) */                             \
+                    uint32_t o_ = my0;                                                                        \
+                    asm volatile("" : "+v"(o_));                                                              \
                     if (aligned) {                                                                            \
-                        reinterpret_cast<uint4 *>(dst)[h] = make_uint4(w[0], w[1], w[2], w[3]);               \
+                        dwords4 w4_; w4_.x = w[0]; w4_.y = w[1]; w4_.z = w[2]; w4_.w = w[3];                  \
+                        *(global_out4)(cout + o_ + 16 * h) = w4_;                                             \
                     } else {                                                                                  \
                         _Pragma("unroll")                                                                     \
-                        for (int k = 0; k < 16; k++) dst[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
+                        for (int k = 0; k < 16; k++) (cout + o_)[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
                     }                                                                                         \
                 }
                 if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }
@@ -672,7 +695,10 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
             else if (!group_ok) ok = false;
         }
         DPROF_ADD(10, pt);
+        /* the slice is free: the next tile's words (the wait for them counts the stores behind them out) */
+        DSUB_TO_SLICE()
     }
+#undef DSUB_TO_SLICE
 #undef DSUB_GEOMETRY
     if (__builtin_expect(slow_tiles != 0u || __ballot(redo_tiles != 0u) != 0ull, 0)) {
 #pragma unroll 1
@@ -682,15 +708,15 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
             if (!__ballot(mine)) continue;
             q = (uint32_t)wave + ti * WAVES;
             const uint32_t g = q * 64u + (uint32_t)lane;
-            const uint64_t my0 = sym0 + (uint64_t)g * DSUB_SPL;
+            const uint32_t my0 = g * DSUB_SPL;
             uint32_t nsym = 0, gb = 0;
             if (g < ngrp) {
-                nsym = (uint32_t)dmin<uint64_t>(DSUB_SPL, sym1 - my0);
+                nsym = dmin<uint32_t>(DSUB_SPL, nchunk - my0);
                 gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
             }
             const uint32_t incl = wave_incl_scan_u32(gb);
             const uint64_t tfirst = T0 + (q ? wave_lane_u32(tincl, q - 1u) : 0u);
-            if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + my0)) ok = false;
+            if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + sym0 + my0)) ok = false;
         }
     }
     *end_bit = T0 + chunk_bits;
@@ -787,7 +813,7 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
         uint64_t end_bit = 0;
-        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), sym0, sym1, T0, out + obase, &end_bit);
+        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), stream + o0, sym0, sym1, T0, out + obase, &end_bit);
         /* (c) the next chunk starts where this one ends */
         if (good && sym1 < m.block_len && sub.tile_bits[blk * sub.tpb + sym1 / HUF_SUB_TILE] != end_bit) good = false;
     }

@@ -161,72 +161,110 @@ __device__ __forceinline__ uint32_t dsub_leaf_of(const uint32_t *code, uint32_t 
     return lo;
 }
 
+/* (Latency is what this costs - a workgroup builds its tables before it can do anything else: the tree entries
+ * go from global memory straight into the registers that classify them, the checks do not vote one by one
+ * - what follows a failed check works on clamped values and is thrown away by the one vote at the end -, the
+ * scans are DPP scans with one barrier each, and blocks without codes beyond 12 bits skip the second level.) */
 template <int THREADS>
 __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *__restrict__ lens_g)
 {
     typedef DsubFastLds<THREADS> F;
     constexpr int ENT = DecShared<THREADS>::ENT;
-    static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256, "two entries per thread");
+    constexpr int WAVES = THREADS / 64;
+    static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256 && WAVES <= 8, "two entries per thread");
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const uint32_t K = (uint32_t)(tree_len - 1) >> 2;
     if (tid == 0) { sh.fastk = 0; sh.l2n = 0; }
     if (tree_len < 9 || tree_len > HUF_TREE_MAX || ((tree_len - 1) & 3) != 0) return false;     /* uniform */
     uint8_t *s_lens = reinterpret_cast<uint8_t *>(sh.pay);                      /* [256] the claimed lengths by byte value */
     uint16_t *s_pos = reinterpret_cast<uint16_t *>(sh.pay + 64);                /* [256] entry index of the k-th leaf */
-    __syncthreads();                                                            /* previous user of sh is done */
+    uint32_t *s_cpart = sh.wtile;                                               /* [3][WAVES] partial sums of the code scan */
+    static_assert(sizeof(sh.wtile) >= 3 * WAVES * sizeof(uint32_t), "partials of the code scan");
+    bool ok = true;
+    /* ---- shape: leaves, nodes, markers.  Thread t looks at entries 2t .. 2t+3 (three aligned dwords, shifted
+     *      by the tree's byte misalignment; entries at or past tree_len read -1) ---- */
+    uint32_t k0;                                                                /* leaves in front of entry 2t */
+    bool l0, l1;
+    int e0, e1;
     {
-        /* entries 2t and 2t+1 from two aligned 32-bit loads per thread, as in dec_build_tables */
         const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
         const uint32_t mis = (uint32_t)(a & 3u);
         const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);
-        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;
-        for (int t = tid; 2 * t < ENT; t += THREADS) {
-            const uint32_t lo = (4u * (uint32_t)t < nbytes) ? q[t] : 0u;
-            const uint32_t hi = (4u * (uint32_t)t + 4u < nbytes) ? q[t + 1] : 0u;
-            const uint32_t two = mis ? __builtin_amdgcn_alignbit(hi, lo, 8u * mis) : lo;
-            const int i = 2 * t;
-            sh.ent[i] = (i < tree_len) ? (int16_t)(two & 0xffffu) : (int16_t)-1;
-            if (i + 1 < ENT) sh.ent[i + 1] = (i + 1 < tree_len) ? (int16_t)(two >> 16) : (int16_t)-1;
-        }
+        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;                  /* bytes from q[0] to the tree's end */
+        const uint32_t t4 = 4u * (uint32_t)tid;
+        const uint32_t d0 = (t4 < nbytes) ? q[tid] : 0u;
+        const uint32_t d1 = (t4 + 4u < nbytes) ? q[tid + 1] : 0u;
+        const uint32_t d2 = (t4 + 8u < nbytes) ? q[tid + 2] : 0u;
         if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = reinterpret_cast<const uint32_t *>(lens_g)[tid];
-    }
-    __syncthreads();
-    bool ok = true;
-    /* ---- shape: leaves, nodes, markers ---- */
-    {
+        const uint32_t two01 = mis ? __builtin_amdgcn_alignbit(d1, d0, 8u * mis) : d0;
+        const uint32_t two23 = mis ? __builtin_amdgcn_alignbit(d2, d1, 8u * mis) : d1;
         const int i0 = 2 * tid;
-        const int e0 = sh.ent[i0], e1 = sh.ent[i0 + 1], e2 = (i0 + 2 < ENT) ? sh.ent[i0 + 2] : -1, e3 = (i0 + 3 < ENT) ? sh.ent[i0 + 3] : -1;
-        const bool n0 = e0 != -1, n1 = e1 != -1;                                /* (entries at or past tree_len read -1) */
-        const bool l0 = n0 && e1 == -1 && e2 == -1 && i0 + 2 < tree_len;
-        const bool l1 = n1 && e2 == -1 && e3 == -1 && i0 + 3 < tree_len;
-        uint32_t tot;
+        e0 = (i0 < tree_len) ? (int)(int16_t)(two01 & 0xffffu) : -1;
+        e1 = (i0 + 1 < tree_len) ? (int)(int16_t)(two01 >> 16) : -1;
+        const int e2 = (i0 + 2 < tree_len) ? (int)(int16_t)(two23 & 0xffffu) : -1;
+        const int e3 = (i0 + 3 < tree_len) ? (int)(int16_t)(two23 >> 16) : -1;
+        const bool n0 = e0 != -1, n1 = e1 != -1;
+        l0 = n0 && e1 == -1 && e2 == -1 && i0 + 2 < tree_len;
+        l1 = n1 && e2 == -1 && e3 == -1 && i0 + 3 < tree_len;
+        if (tid == 0 && !n0) ok = false;                                        /* the root */
+        if ((i0 == tree_len - 1 && n0) || (i0 + 1 == tree_len - 1 && n1)) ok = false;      /* the last entry is a marker */
+        if (tid == THREADS - 1 && i0 + 2 == tree_len - 1 && e2 != -1) ok = false;          /* (entry 1024 has no thread of its own) */
         const uint32_t mine = (uint32_t)l0 + (uint32_t)l1 + (((uint32_t)n0 + (uint32_t)n1) << 16);
-        const uint32_t ex = block_excl_scan_u32<THREADS>(mine, sh.part, tot);
+        const uint32_t inc = wave_incl_scan_u32(mine);
+        if (lane == 63) sh.part[wave] = inc;
+        __syncthreads();                                                        /* (also: s_lens is written) */
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const uint32_t x = sh.part[i];
+            if (i < wave) base += x;
+            tot += x;
+        }
         if ((tot & 0xffffu) != K || (tot >> 16) != 2u * K) ok = false;
-        if (tid == 0 && (sh.ent[0] == -1 || sh.ent[tree_len - 1] != -1)) ok = false;
-        uint32_t k = ex & 0xffffu;
+        k0 = (base + inc - mine) & 0xffffu;
+        uint32_t k = k0;
         if (l0 && k < 256u) { s_pos[k] = (uint16_t)i0; F::sym(sh)[k] = (uint8_t)e0; k++; }
         if (l1 && k < 256u) { s_pos[k] = (uint16_t)(i0 + 1); F::sym(sh)[k] = (uint8_t)e1; }
     }
-    if (!__syncthreads_and(ok ? 1 : 0)) return false;
-    /* ---- claimed lengths -> codes; they must fill the left half of the code space exactly ---- */
-    uint32_t d = 0;
+    __syncthreads();
+    /* ---- claimed lengths -> codes; they must fill the left half of the code space exactly.  A code's share of
+     *      the 32-bit code space is 2^(32 - d) <= 2^30: scanned as two 16-bit halves (DPP, no 64-bit shuffles) ---- */
+    uint32_t d = 2;
+    bool anylong;
     {
-        uint64_t width = 0;
+        uint32_t whi = 0, wlo = 0;
         if ((uint32_t)tid < K) {
             d = s_lens[F::sym(sh)[tid]];
-            if (d < 2u || d > 32u) ok = false;
-            else width = 1ull << (32u - d);
+            if (d < 2u || d > 32u) { ok = false; d = 2; }
+            else if (d >= 16u) wlo = 1u << (32u - d);                           /* <= 2^16 */
+            else whi = 1u << (16u - d);                                         /* 2^(32 - d) >> 16 */
         }
-        uint64_t tot;
-        const uint64_t ex = block_excl_scan<THREADS, uint64_t>(width, reinterpret_cast<uint64_t *>(sh.wtile), tot);
+        const uint32_t ihi = wave_incl_scan_u32(whi), ilo = wave_incl_scan_u32(wlo);
+        const unsigned long long lg = __ballot(d > (uint32_t)DEC_LUT_BITS);
+        if (lane == 63) {
+            s_cpart[wave] = ihi;
+            s_cpart[WAVES + wave] = ilo;
+            s_cpart[2 * WAVES + wave] = lg != 0ull;
+        }
+        __syncthreads();
+        uint64_t base = 0, tot = 0;
+        uint32_t lf = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const uint64_t x = ((uint64_t)s_cpart[i] << 16) + s_cpart[WAVES + i];
+            if (i < wave) base += x;
+            tot += x;
+            lf |= s_cpart[2 * WAVES + i];
+        }
+        anylong = uni32(lf) != 0u;
         if (tot != (1ull << 31)) ok = false;
         if ((uint32_t)tid < K) {
-            F::code(sh)[tid] = (uint32_t)ex;
+            F::code(sh)[tid] = (uint32_t)(base + (((uint64_t)(ihi - whi)) << 16) + (ilo - wlo));
             F::len(sh)[tid] = (uint8_t)d;
         }
     }
-    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    __syncthreads();
     /* ---- the entry positions the lengths imply are the stream's ---- */
     if ((uint32_t)tid < K) {
         const uint32_t k = (uint32_t)tid;
@@ -239,7 +277,6 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
             if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
         } else if (pos + 4u != (uint32_t)tree_len) ok = false;                  /* leaf, its two markers, the root's */
     }
-    if (!__syncthreads_and(ok ? 1 : 0)) return false;
     /* ---- the table: eight consecutive entries per thread, one 16-byte store ---- */
     {
         static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
@@ -262,10 +299,10 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
         *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
     /* ---- second level: the subtree below a 12-bit prefix whose codes are at most DSUB_L2_BITS longer
-     *      gets a table of its own (2, 4 or 6 more bits) in the LDS the tree entries occupied (they are not
-     *      needed any more).  Codes beyond that keep their `long` entry. ---- */
-    __syncthreads();                                     /* the first table is written, the tree entries are done with */
-    {
+     *      gets a table of its own (2, 4 or 6 more bits) in sh.ent.  Codes beyond that keep their `long`
+     *      entry. ---- */
+    if (anylong) {
+        __syncthreads();                                 /* the first table is written */
         uint16_t *l2 = reinterpret_cast<uint16_t *>(sh.ent);
         const uint32_t *code = F::code(sh);
         const uint8_t *len = F::len(sh);
@@ -275,13 +312,14 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
         if (k < K && d > (uint32_t)DEC_LUT_BITS &&
             (k == 0 || len[k - 1] <= DEC_LUT_BITS || (code[k - 1] >> (32 - DEC_LUT_BITS)) != P)) {
             /* first leaf below its prefix: the leaves below one prefix are neighbours (preorder = code order) */
-            uint32_t maxd = d, jn = k + 1u;
+            uint32_t maxd = d, mind = d, jn = k + 1u;
             while (jn < K && jn - k <= (1u << DSUB_L2_BITS) && (code[jn] >> (32 - DEC_LUT_BITS)) == P) {
                 maxd = dmax<uint32_t>(maxd, len[jn]);
+                mind = dmin<uint32_t>(mind, len[jn]);
                 jn++;
             }
             const bool closed = !(jn < K && (code[jn] >> (32 - DEC_LUT_BITS)) == P);
-            if (closed && maxd <= (uint32_t)DEC_LUT_BITS + DSUB_L2_BITS) {
+            if (closed && maxd <= (uint32_t)DEC_LUT_BITS + DSUB_L2_BITS && mind > (uint32_t)DEC_LUT_BITS) {
                 nb = (maxd - DEC_LUT_BITS + 1u) & ~1u;
                 size = 1u << nb;
                 run_end = jn;
@@ -295,15 +333,14 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
                 const uint32_t first = (code[jn] >> (32 - DEC_LUT_BITS - nb)) & (size - 1u);
                 const uint32_t count = 1u << (DEC_LUT_BITS + nb - dj);
                 const uint16_t entry = (uint16_t)(((uint32_t)F::sym(sh)[jn] << 8) | dj);
-                for (uint32_t i = 0; i < count; i++) l2[off + first + i] = entry;
+                for (uint32_t i = 0; i < count && first + i < size; i++) l2[off + first + i] = entry;
             }
             sh.lut[P] = (uint16_t)(((off >> 2) << 8) | ((nb / 2u - 1u) << 6) | DSE_L2);
         }
         if (tid == 0) sh.l2n = dmin<uint32_t>(total, DSUB_L2_ENTRIES);
     }
-    if (tid == 0) sh.fastk = K;
-    __syncthreads();
-    return true;
+    if (tid == 0 && __builtin_expect(true, 1)) sh.fastk = K;
+    return __syncthreads_and(ok ? 1 : 0) != 0;
 }
 
 /* The tables of dec_build_tables (any grammar-valid tree; taken when dsub_fast_tables declines) in the sub-index
@@ -794,6 +831,9 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
 #ifndef DSUB_ABLATE_TABLES      /* (diagnostic builds: what the kernel costs without one of its phases) */
     if (leaf < 0) {
 #ifndef DSUB_NO_FAST_TABLES
+#ifdef DSUB_TABLES_TWICE        /* (what one table build costs where it stands: the kernel with two of them) */
+        dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM);
+#endif
         if (!dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM))
 #endif
         {

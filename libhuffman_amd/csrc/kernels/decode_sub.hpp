@@ -165,8 +165,30 @@ __device__ __forceinline__ uint32_t dsub_leaf_of(const uint32_t *code, uint32_t 
  * go from global memory straight into the registers that classify them, the checks do not vote one by one
  * - what follows a failed check works on clamped values and is thrown away by the one vote at the end -, the
  * scans are DPP scans with one barrier each, and blocks without codes beyond 12 bits skip the second level.) */
+/* what a thread of the table build needs from global memory: the three aligned dwords that hold tree entries
+ * 2t .. 2t+3, and (threads 0..63) four of the claimed lengths - requested early, used by dsub_fast_tables */
+struct DsubTreeWords {
+    uint32_t d0, d1, d2, lens4, mis;
+};
 template <int THREADS>
-__device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *__restrict__ lens_g)
+__device__ __forceinline__ DsubTreeWords dsub_tree_request(const uint8_t *tree, int tree_len, const uint8_t *__restrict__ lens_g)
+{
+    DsubTreeWords w;
+    const int tid = (int)threadIdx.x;
+    const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
+    w.mis = (uint32_t)(a & 3u);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a - w.mis);
+    const uint32_t nbytes = w.mis + 2u * (uint32_t)(tree_len > 0 ? tree_len : 0);      /* bytes from q[0] to the tree's end */
+    const uint32_t t4 = 4u * (uint32_t)tid;
+    w.d0 = (t4 < nbytes) ? q[tid] : 0u;
+    w.d1 = (t4 + 4u < nbytes) ? q[tid + 1] : 0u;
+    w.d2 = (t4 + 8u < nbytes) ? q[tid + 2] : 0u;
+    w.lens4 = (tid < 64) ? reinterpret_cast<const uint32_t *>(lens_g)[tid] : 0u;
+    return w;
+}
+
+template <int THREADS>
+__device__ bool dsub_fast_tables(DecShared<THREADS> &sh, int tree_len, const DsubTreeWords &tw)
 {
     typedef DsubFastLds<THREADS> F;
     constexpr int ENT = DecShared<THREADS>::ENT;
@@ -188,15 +210,8 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, const uint8_t *tree, in
     bool l0, l1;
     int e0, e1;
     {
-        const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
-        const uint32_t mis = (uint32_t)(a & 3u);
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);
-        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;                  /* bytes from q[0] to the tree's end */
-        const uint32_t t4 = 4u * (uint32_t)tid;
-        const uint32_t d0 = (t4 < nbytes) ? q[tid] : 0u;
-        const uint32_t d1 = (t4 + 4u < nbytes) ? q[tid + 1] : 0u;
-        const uint32_t d2 = (t4 + 8u < nbytes) ? q[tid + 2] : 0u;
-        if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = reinterpret_cast<const uint32_t *>(lens_g)[tid];
+        const uint32_t mis = tw.mis, d0 = tw.d0, d1 = tw.d1, d2 = tw.d2;
+        if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = tw.lens4;
         const uint32_t two01 = mis ? __builtin_amdgcn_alignbit(d1, d0, 8u * mis) : d0;
         const uint32_t two23 = mis ? __builtin_amdgcn_alignbit(d2, d1, 8u * mis) : d1;
         const int i0 = 2 * tid;
@@ -518,9 +533,12 @@ __device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32
  * NEXT tile are requested before it decodes this one and wait in twelve registers: the HBM latency
  * (a quarter of a workgroup's life when every tile waited for its own loads) passes under the decoding. */
 template <int THREADS>
-__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, const uint8_t *safe,
+__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *lens_g,
+                                   const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, const uint8_t *safe,
                                    uint64_t sym0, uint64_t sym1, uint64_t T0, uint8_t *gout, uint64_t *end_bit)
 {
+    /* the table build's words from global memory are on their way while the group counts are scanned */
+    const DsubTreeWords tw = dsub_tree_request<THREADS>(tree, tree_len, lens_g);
     typedef DsubLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
     constexpr uint32_t CAP_BITS = L::CAP_BITS;
@@ -556,7 +574,6 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
         *end_bit = 0;
         return false;
     }
-    const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
     DPROF_ADD(8, pt);
 
     typedef const __attribute__((address_space(3))) uint32_t *lds_words;
@@ -633,6 +650,25 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *pay, u
         }                                                                                                     \
     }
     DSUB_GEOMETRY(q, q * 64u < ngrp)
+    /* ... and the wave's first tile is on its way while the tables are built.  Tables the quick way from the
+     * sub-index's code lengths, checked against the tree; any other tree: walked (dec_build_tables) */
+    {
+        unsigned long long kt = DPROF_T();
+#ifdef DSUB_TABLES_TWICE        /* (what one table build costs where it stands: the kernel with two of them) */
+        dsub_fast_tables<THREADS>(sh, tree_len, tw);
+#endif
+        if (!dsub_fast_tables<THREADS>(sh, tree_len, tw)) {
+            int leaf = -1;
+            const int rc = dec_build_tables<THREADS, false>(sh, tree, tree_len, &leaf);
+            if (rc != HUFE_OK || leaf >= 0) {                       /* (an unusual one-leaf tree: the exact decoder's) */
+                *end_bit = 0;
+                return false;
+            }
+            dsub_convert_tables<THREADS>(sh);
+        }
+        DPROF_ADD(3, kt);
+    }
+    const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
     DSUB_TO_SLICE()
     /* what the loop leaves for later (bit i = the wave's i-th tile): tiles that are not `quick`, and - per lane -
      * groups to be decoded again step by step.  Those go through dsub_tile_slow BEHIND the loop: a call inside
@@ -789,14 +825,19 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
     const uint64_t blk = blockIdx.x / cpb;
     const uint32_t c = (uint32_t)(blockIdx.x % cpb);
     unsigned long long kt = DPROF_T();
-    /* everything about the block is the same in all lanes: kept in SGPRs (held in VGPRs these
-     * values pushed the tile loop's state out to scratch, 8 reloads per wave tile) */
+    /* Everything about the block is the same in all lanes: kept in SGPRs (held in VGPRs these values pushed the
+     * tile loop's state out to scratch), and everything is REQUESTED before the first of it is looked at: six
+     * scalar loads, one wait (one after the other they were a sixth of a workgroup's life). */
     HufDecodeMeta m = dmeta[blk];
+    const uint64_t out_group = lens.gprefix[blk / SCAN_GROUP], out_local = lens.local[blk];
+    const uint64_t off0 = offsets[blk], off1 = offsets[blk + 1];
+    const uint64_t t0_told = sub.tile_bits[blk * sub.tpb + (uint64_t)c * (DSUB_CHUNK_SYMS / HUF_SUB_TILE)];   /* (c < cpb: inside the block's row) */
+    pin_uniform(m.block_len); pin_uniform(out_group); pin_uniform(out_local); pin_uniform(off0); pin_uniform(off1); pin_uniform(t0_told);
     m.block_len = uni64(m.block_len);
     m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
     m.leaf = (int16_t)uni32((uint32_t)(uint16_t)m.leaf);
     m.status = (int32_t)uni32((uint32_t)m.status);
-    const uint64_t obase = uni64(lens.gprefix[blk / SCAN_GROUP] + lens.local[blk]);
+    const uint64_t obase = uni64(out_group + out_local);
     if (tid == 0 && c == 0) out_offsets[blk] = obase;
     if (m.status != HUFE_OK || m.block_len == 0) return;            /* header errors were recorded by decode_prepare */
     const uint64_t sym0 = (uint64_t)c * DSUB_CHUNK_SYMS;
@@ -815,45 +856,26 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
         return;
     }
     const uint64_t sym1 = dmin<uint64_t>(m.block_len, sym0 + DSUB_CHUNK_SYMS);
-    const uint64_t o0 = uni64(offsets[blk]);
-    const uint64_t o1 = dmin<uint64_t>(uni64(offsets[blk + 1]), stream_len);
+    const uint64_t o0 = uni64(off0);
+    const uint64_t o1 = dmin<uint64_t>(uni64(off1), stream_len);
     const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
     const uint8_t *tree = stream + o0 + HUF_HEADER_FIXED;
     const uint8_t *pay = tree + 2 * (int)m.tree_len;
     bool good;
-    int leaf = m.leaf;
-    int rc = HUFE_OK;
-    if (leaf < 0)
-        dsub_prefetch<THREADS>(sh, sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL,
-                               (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
-    const uint64_t T0 = uni64(sub.tile_bits[blk * sub.tpb + sym0 / HUF_SUB_TILE]);   /* first payload bit of the chunk, as told */
-    DPROF_ADD(2, kt); kt = DPROF_T();
-#ifndef DSUB_ABLATE_TABLES      /* (diagnostic builds: what the kernel costs without one of its phases) */
-    if (leaf < 0) {
-#ifndef DSUB_NO_FAST_TABLES
-#ifdef DSUB_TABLES_TWICE        /* (what one table build costs where it stands: the kernel with two of them) */
-        dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM);
-#endif
-        if (!dsub_fast_tables<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM))
-#endif
-        {
-            rc = dec_build_tables<THREADS, false>(sh, tree, m.tree_len, &leaf);
-            if (rc == HUFE_OK && leaf < 0) dsub_convert_tables<THREADS>(sh);
-        }
-    }
-#endif
-    DPROF_ADD(3, kt);
-    if (rc != HUFE_OK) {
-        good = false;
-    } else if (leaf >= 0) {
+    if (m.leaf >= 0) {
         /* one 0 bit per symbol: the chunk's bits start at payload bit sym0 (a multiple of 8) */
         uint64_t eb = 0, produced = 0;
         good = (sym0 >> 3) <= pay_bytes &&
-               decode_single_leaf<THREADS, true>(sh, (uint32_t)leaf, pay + (sym0 >> 3), sym1 - sym0,
+               decode_single_leaf<THREADS, true>(sh, (uint32_t)m.leaf, pay + (sym0 >> 3), sym1 - sym0,
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
+        dsub_prefetch<THREADS>(sh, sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL,
+                               (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
+        const uint64_t T0 = uni64(t0_told);                           /* first payload bit of the chunk, as told */
+        DPROF_ADD(2, kt);
         uint64_t end_bit = 0;
-        good = decode_payload_sub<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), stream + o0, sym0, sym1, T0, out + obase, &end_bit);
+        good = decode_payload_sub<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM, pay, pay_bytes,
+                                           stream_len - (uint64_t)(pay - stream), stream + o0, sym0, sym1, T0, out + obase, &end_bit);
         /* (c) the next chunk starts where this one ends */
         if (good && sym1 < m.block_len && sub.tile_bits[blk * sub.tpb + sym1 / HUF_SUB_TILE] != end_bit) good = false;
     }

@@ -19,6 +19,12 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
 {
     return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
 }
+/* "this wave-uniform value is needed HERE": keeps the compiler from sinking the load of it to its first use
+ * (scalar loads requested together wait once; one at a time they wait once each) */
+__device__ __forceinline__ void pin_uniform(uint64_t v)
+{
+    asm volatile("" :: "s"((uint32_t)v), "s"((uint32_t)(v >> 32)));
+}
 
 template <typename T>
 __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }

@@ -702,9 +702,10 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
                  * position as they stand.  An entry that is not a leaf has length 0: the lane stands still
                  * from then on (a `long` code, a walk that leaves the tree: the low byte is 0) and its last
                  * look-up tells; such a lane decodes its group again behind the loop, step by step.
-                 * 16 symbols are stored as 16 bytes with the DEFAULT cache policy: a lane's store covers half
-                 * of a 32-byte sector and the other half follows; streaming (nt) stores then reach HBM as
-                 * partial writes.
+                 * The lane's 32 bytes leave as two 16-byte stores back to back, DEFAULT cache policy: one whole
+                 * 32-byte sector (a store per 16 symbols left half-written sectors in L2 for a round, and one in
+                 * nine of them was evicted like that and written twice; streaming stores reach HBM as partial
+                 * writes altogether).
                  * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
                  * symbol; a lane decoding the two halves of its group side by side.) */
                 const bool aligned = (cout_a & 15u) == 0;             /* (the offset is a multiple of 32) */
@@ -730,17 +731,19 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
                         if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
                             e2_ = dsub_l2<THREADS>(sh, e2_, d2_);                                             \
                     }                                                                                         \
-                    if (L2) special |= e1_ | e2_;                                                             \
+                    if (L2) {                                                                                 \
+                        special |= e1_ | e2_;                                                                 \
+                        asm volatile("" : "+v"(special));     /* (now: not 32 entries kept for one big OR at the end) */ \
+                    }                                                                                         \
                     R -= (e1_ + e2_) & 0xffu;                                                                 \
                     PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
                     e_last = e2_;                                                                             \
                 }
 #define DSUB_ROUNDS(L2)                                                                                        \
-                _Pragma(DSUB_ROUNDS_UNROLL)                                                                   \
-                for (int h = 0; h < 2; h++) {                                                                 \
-                    uint32_t w[4];                                                                            \
+                {                                                                                             \
+                    uint32_t w[8];                                                                            \
                     _Pragma("unroll")                                                                         \
-                    for (int k = 0; k < 4; k++) {                                                             \
+                    for (int k = 0; k < 8; k++) {                                                             \
                         uint32_t p01, p23;                                                                    \
                         DSUB_WINDOW(p01, L2)                                                                  \
                         DSUB_WINDOW(p23, L2)                                                                  \
@@ -751,11 +754,14 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
                     uint32_t o_ = my0;                                                                        \
                     asm volatile("" : "+v"(o_));                                                              \
                     if (aligned) {                                                                            \
-                        dwords4 w4_; w4_.x = w[0]; w4_.y = w[1]; w4_.z = w[2]; w4_.w = w[3];                  \
-                        *(global_out4)(cout + o_ + 16 * h) = w4_;                                             \
+                        dwords4 a4_, b4_;                                                                     \
+                        a4_.x = w[0]; a4_.y = w[1]; a4_.z = w[2]; a4_.w = w[3];                               \
+                        b4_.x = w[4]; b4_.y = w[5]; b4_.z = w[6]; b4_.w = w[7];                               \
+                        *(global_out4)(cout + o_) = a4_;                                                      \
+                        *(global_out4)(cout + o_ + 16) = b4_;                                                 \
                     } else {                                                                                  \
                         _Pragma("unroll")                                                                     \
-                        for (int k = 0; k < 16; k++) (cout + o_)[16 * h + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); \
+                        for (int k = 0; k < 32; k++) (cout + o_)[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));  \
                     }                                                                                         \
                 }
                 if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }

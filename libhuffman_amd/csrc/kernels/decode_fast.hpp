@@ -383,6 +383,10 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kerne
     unsigned long long *__restrict__ result, DecFixList fix)
 {
     __shared__ DecShared<THREADS> sh;
+#ifdef DFAST_LDS_PAD            /* (occupancy experiments: fewer workgroups per CU) */
+    __shared__ uint32_t lds_pad[DFAST_LDS_PAD / 4];
+    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
+#endif
     const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x;
     HufDecodeMeta m = dmeta[blk];

@@ -323,9 +323,16 @@ __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, 
         /* speculation: every lane but the first starts at its own first bit - a decoder that starts anywhere falls
          * into step within a few codewords, and a lane that has not is found out below */
         uint32_t start = tid == 0 ? first : hi - DFAST_RUNIN;
-        uint32_t end, cnt;
-        if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
-        else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+        /* a lane whose share lies behind the payload holds nothing and ends where its share ends (the block's last
+         * segment is a quarter full on average: its other lanes scanned what follows the block, and passed every
+         * change of their neighbour's on) */
+        const bool dead = hi - DFAST_SUB_BITS >= pay_rel;
+        uint32_t end = hi, cnt = 0;
+        if (__ballot(!dead)) {
+            if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            if (dead) { end = hi; cnt = 0; }
+        }
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
         int rounds = 0;
@@ -333,12 +340,14 @@ __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, 
             /* left neighbour's end: a DPP move inside the wave, LDS across the wave seams */
             uint32_t ns = wave_up1_u32(end);
             if (lane == 0) ns = (tid == 0) ? first : sh.wend[wave - 1];
-            const int changed = (ns != start);
+            const int changed = (ns != start) && !dead;
             __syncthreads();                                           /* everyone has read sh.wend */
-            if (changed) {
-                start = ns;
-                if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
-                else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, start, hi, lim, &end, &cnt);
+            if (__ballot(changed != 0)) {
+                if (changed) start = ns;
+                uint32_t e2 = end, c2 = cnt;
+                if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                if (changed) { end = e2; cnt = c2; }
             }
             if (lane == 63) sh.wend[wave] = end;
             if (!__syncthreads_or(changed)) break;

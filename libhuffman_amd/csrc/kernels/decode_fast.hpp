@@ -204,14 +204,13 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
     LinReader rd;
     rd.st = stage;
     rd.load(start);
-    /* bytes up to the first 4-byte boundary of the output */
-    const uint32_t head = dmin<uint32_t>(quota, (4u - (uint32_t)((uintptr_t)g & 3u)) & 3u);
-    for (uint32_t c = 0; c < head; c++) {
-        g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
-        if (rd.avail <= 32) rd.refill();
-    }
-    const uint32_t p0 = rd.pos();
-    uint32_t *gw = reinterpret_cast<uint32_t *>(g + head);
+    /* (the words go out from the lane's first symbol on, wherever the output stands: 32-bit stores need no
+     * alignment on gfx950, and the symbols in front of a 4-byte boundary, one step-by-step look-up each, cost as
+     * much as the two words behind them) */
+    const uint32_t head = 0;
+    const uint32_t p0 = start;
+    typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
+    unaligned_u32 *gw = reinterpret_cast<unaligned_u32 *>(g + head);
     const uint32_t words = (quota - head) >> 2;
     /* whole words: four table entries folded into one register, two per window, no branch; an entry that is
      * not a leaf advances like one and is only remembered */

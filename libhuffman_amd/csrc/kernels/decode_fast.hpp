@@ -194,6 +194,80 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
     *cnt = c;
 }
 
+/* Runs of one byte value.  A run is a periodic bit string, and a speculative lane inside it locks onto the pattern
+ * a few bits off: nothing in the run tells the phases apart, so the lanes of a run are put right one per round,
+ * from the left (a 16 KiB run of zeros in a 64 KiB block: 114 lanes).  But inside a run everything is known from
+ * its beginning: every codeword start is the first one plus a multiple of the code length.
+ *
+ * dfast_run_at: does ONE codeword, repeated, fill the stage from bit `pos` to bit `hi` and a codeword further?
+ * Returns its length (1..12), or 0.  (The 32 bits at pos + 32 k, k = 0..10; the string is periodic with period L
+ * when every one of them, shifted on by L bits, is itself again.) */
+__device__ __forceinline__ uint32_t dfast_run_at(uint32_t qbase, uint32_t lut_addr, uint32_t pos, uint32_t hi)
+{
+    const uint32_t Q0 = pos - 1u + qbase;
+    uint32_t w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const uint32_t Q = Q0 + 32u * (uint32_t)k;
+        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+        w[k] = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+    }
+    const uint32_t e = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((w[0] >> 19) & 0x1ffeu));
+    const uint32_t L = e >> 8;
+    if (e >= DEC_E_BAD || L == 0u) return 0u;                          /* not a codeword of the table */
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        /* the 32 bits at pos + 32 k + L; only those that begin in front of hi count */
+        const bool counts = pos + 32u * (uint32_t)k < hi;
+        if (counts && __builtin_amdgcn_alignbit(w[k], w[k + 1], 32u - L) != w[k]) same = false;
+    }
+    return same ? L : 0u;
+}
+
+/* dfast_run_jump: a lane that has just been put right (`changed`) and holds one codeword over and over is the
+ * beginning of a run, as far as this wave is concerned; the lanes to its right take the codeword starts that follow
+ * from it - if THEIR shares hold the same repetition from there on, which each of them checks in its own bits -
+ * and a stretch of any length inside the wave settles in this round.  A guess that does not hold is found out like
+ * any wrong start: by the neighbour's end in the next round.  Returns (start, end, count, moved) of the lane.
+ * (Out of line: it runs in the rounds after the second only, and its registers are its own.) */
+__device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, bool changed, bool dead, uint32_t hi, uint32_t pay_rel,
+                                             uint32_t start, uint32_t end, uint32_t cnt0)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t myL = (changed && start < hi) ? dfast_run_at(qbase, lut_addr, start, hi) : 0u;
+    /* the nearest such lane to the left (max-scan of lane indices), its start and code length */
+    int src = (myL != 0u) ? (int)lane : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(src, o);
+        if ((int)lane >= o && t > src) src = t;
+    }
+    const uint32_t P = (uint32_t)__shfl((int)start, src < 0 ? 0 : src);
+    const uint32_t L = (uint32_t)__shfl((int)myL, src < 0 ? 0 : src);
+    bool pass = false;
+    uint32_t cand = 0;
+    if (src >= 0 && src < (int)lane && !dead && !changed) {
+        /* the first codeword start at or behind my first bit: P plus a multiple of L */
+        const uint32_t lo = hi - DFAST_SUB_BITS;
+        const uint32_t back = (lo - P) % L;
+        cand = lo + (back ? L - back : 0u);
+        pass = cand >= hi || (cand < pay_rel && dfast_run_at(qbase, lut_addr, cand, hi) == L);
+    }
+    /* ... as far as every lane on the way agrees: the last lane that does not, against the source */
+    int bad = (src >= 0 && src < (int)lane && !pass) ? (int)lane : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(bad, o);
+        if ((int)lane >= o && t > bad) bad = t;
+    }
+    if (pass && bad <= src && cand != start) {
+        const uint32_t cnt = (cand < hi) ? (hi - cand + L - 1u) / L : 0u;
+        return make_uint4(cand, cand + cnt * L, cnt, 1u);
+    }
+    return make_uint4(start, end, cnt0, 0u);                 /* (start, end, count, moved) */
+}
+
 /* Write pass of a lane: its first `quota` symbols, from `start`, to g[0 .. quota).  Returns the position behind
  * the last one; *ok is cleared when a look-up was not a codeword (a walk out of the tree, bits past `lim`). */
 template <int THREADS>
@@ -348,8 +422,14 @@ __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, 
                 else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, changed ? start : hi, hi, lim, &e2, &c2);
                 if (changed) { end = e2; cnt = c2; }
             }
+            /* ---- runs of one byte value (only when the starts have not settled in two rounds): dfast_run_jump ---- */
+            int jumped = 0;
+            if (rounds >= 1 && __ballot(changed != 0)) {
+                const uint4 r = dfast_run_jump(qbase, lut_addr, changed != 0, dead, hi, pay_rel, start, end, cnt);
+                start = r.x; end = r.y; cnt = r.z; jumped = (int)r.w;
+            }
             if (lane == 63) sh.wend[wave] = end;
-            if (!__syncthreads_or(changed)) break;
+            if (!__syncthreads_or(changed | jumped)) break;
             DFAST_DBG(10, 1);
             if (++rounds > DFAST_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }    /* (uniform: every thread counts the same rounds) */
         }

@@ -452,3 +452,38 @@ def test_index_only_decode_lean_and_exact_kernels_agree(torch_mod, codec, oracle
         r = subprocess.run([sys.executable, "-c", child, os.path.join(tmp, "d.npy")], env=dict(os.environ, HUF_GPU_EXACT_DECODE="1"),
                            capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "exact kernel ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_index_only_decode_of_runs(torch_mod, codec):
+    """Runs of one byte value are periodic bit strings: the lean decoder settles them from their beginning
+    (dfast_run_jump) instead of one lane per round.  Runs of all kinds of lengths and places - inside a lane, across
+    waves and segments, one behind the other, of bytes with long codes, alternating pairs (periodic, but not ONE
+    codeword) - must come out like everything else."""
+    torch = torch_mod
+    bs = 65536
+    rng = np.random.default_rng(20261003)
+    blocks = []
+    for b in range(40):
+        blk = datagen.zipf255(bs).copy() if b % 3 else rng.integers(0, 255, bs, dtype=np.uint8)     # (255 values: the reference's limit)
+        pos = int(rng.integers(0, 3000))
+        while pos < bs - 64:
+            kind = int(rng.integers(0, 4))
+            length = int(rng.choice([40, 300, 2304, 5000, 20000, 48000]))
+            length = min(length, bs - pos)
+            if kind == 0:
+                blk[pos:pos + length] = 0
+            elif kind == 1:
+                blk[pos:pos + length] = int(rng.integers(0, 255))          # may be a byte with a long code
+            elif kind == 2:
+                pair = rng.integers(0, 255, 2, dtype=np.uint8)
+                blk[pos:pos + length] = np.resize(pair, length)            # ABAB...
+            pos += length + int(rng.integers(1, 9000))
+        blocks.append(blk)
+    data = np.concatenate(blocks)
+    d = dev(torch, data)
+    stream, offs, length = codec.encode(d, bs)
+    nb = codec.block_count(data.size, bs)
+    out = torch.zeros(data.size, dtype=torch.uint8, device="cuda")
+    assert codec.decode(stream, length, offs, nb, out) == data.size
+    assert torch.equal(out, d)

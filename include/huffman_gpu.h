@@ -192,6 +192,10 @@ struct __huf_read_writer;
 struct __huf_encoder_config;
 void huf_gpu_set_relaxed_tree(int enabled);
 int huf_gpu_memwrap(struct __huf_read_writer **self, const void *data, size_t length);
+/* huf_gpu_memwrap_out: a WRITER over `capacity` bytes of memory the caller provides (the buffer that is to hold
+ * the result): huf_encode()/huf_decode() write there directly; a write that does not fit fails with
+ * HUF_ERROR_MEMORY_ALLOCATION (the memory is never grown, moved or freed).  huf_memlen() = bytes written. */
+int huf_gpu_memwrap_out(struct __huf_read_writer **self, void *buffer, size_t capacity);
 /* huf_gpu_decode_blocks: huf_decode() for a caller that holds only a PIECE of a stream (a file read
  * in bounded rounds, src/decoder.c:218 has the whole stream behind its reader): the blocks that lie
  * completely inside config->length bytes are decoded and written, *consumed = their stream bytes.

@@ -67,7 +67,7 @@ hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_dec
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_set_profiling
 hufgpu_get_profile hufgpu_sub_index_bytes hufgpu_encode_sub hufgpu_decode_sub
-hufgpu_decode_stream_complete hufgpu_block_index huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_decode_blocks huf_gpu_sessions huf_gpu_fanouts huf_gpu_copy_out""".split()
+hufgpu_decode_stream_complete hufgpu_block_index huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_memwrap_out huf_gpu_decode_blocks huf_gpu_sessions huf_gpu_fanouts huf_gpu_copy_out""".split()
 
 
 def so_path() -> str:
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
     L.huf_gpu_set_relaxed_tree.argtypes = [i32]
     L.huf_gpu_set_relaxed_tree.restype = None
     L.huf_gpu_memwrap.argtypes = [C.POINTER(C.POINTER(ReadWriter)), vp, C.c_size_t]
+    L.huf_gpu_memwrap_out.argtypes = [C.POINTER(C.POINTER(ReadWriter)), vp, C.c_size_t]
     L.huf_gpu_copy_out.argtypes = [vp, vp, C.c_size_t]
     L.huf_gpu_copy_out.restype = i32
     L.huf_gpu_sessions.argtypes = [C.POINTER(C.c_int)]

@@ -95,8 +95,9 @@ typedef struct {
     size_t off;     /* read cursor */
     size_t len;
     size_t cap;
-    void *wrapped;  /* huf_gpu_memwrap(): the caller's bytes (buf points here); never written or freed */
-    int readonly;
+    void *wrapped;  /* huf_gpu_memwrap[_out](): the caller's bytes (buf points here); never freed */
+    int readonly;   /* huf_gpu_memwrap(): never written either */
+    int fixed;      /* huf_gpu_memwrap_out(): written up to cap, never grown */
 } membuf_t;
 
 /* A stream buffer: zeroed like the reference's calloc (src/io.c:79-104, :181), free()d by the caller
@@ -104,14 +105,18 @@ typedef struct {
  * first write into such a buffer is bound by page faults, and a 2 MiB page is one fault instead of
  * 512 (transparent huge pages are in "madvise" mode on the GPU boxes). */
 #define HUF_BIG_BUFFER ((size_t)4 << 20)
-static void *stream_alloc(size_t bytes)
+static void advise_huge_pages(void *p, size_t bytes)
 {
-    void *p = calloc(bytes ? bytes : 1, 1);
     if (p && bytes >= HUF_BIG_BUFFER) {
         const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
         const uintptr_t lo = ((uintptr_t)p + page - 1) & ~(page - 1), hi = ((uintptr_t)p + bytes) & ~(page - 1);
         if (hi > lo) (void)madvise((void *)lo, (size_t)(hi - lo), MADV_HUGEPAGE);      /* advice only: failure is fine */
     }
+}
+static void *stream_alloc(size_t bytes)
+{
+    void *p = calloc(bytes ? bytes : 1, 1);
+    advise_huge_pages(p, bytes);
     return p;
 }
 
@@ -119,6 +124,7 @@ static void *stream_alloc(size_t bytes)
 static huf_error_t mem_reserve(membuf_t *m, size_t count)
 {
     if (m->readonly) return HUF_ERROR_INVALID_ARGUMENT;
+    if (m->fixed && m->cap - m->len < count) return HUF_ERROR_MEMORY_ALLOCATION;      /* the caller's memory ends here */
     if (m->cap - m->len < count) {
         /* growth policy of src/io.c:79-84 (double, or twice the request), but never smaller
          * than what is needed - the reference under-allocates here */
@@ -195,6 +201,32 @@ int huf_gpu_memwrap(huf_read_writer_t **self, const void *data, size_t length)
     m->buf = &m->wrapped;
     m->len = m->cap = length;
     m->readonly = 1;
+    rw->stream = m;
+    rw->write = memwrite;
+    rw->read = memread;
+    *self = rw;
+    return HUF_ERROR_SUCCESS;
+}
+
+/* Extension: a WRITER over memory the caller provides (`capacity` bytes, e.g. a Python bytes object that is
+ * to become the result): what huf_encode()/huf_decode() write goes there directly, a write that does not fit
+ * fails with HUF_ERROR_MEMORY_ALLOCATION (the memory is never grown, moved or freed).  huf_memlen() says how
+ * much was written; closed with huf_memclose(). */
+int huf_gpu_memwrap_out(huf_read_writer_t **self, void *buffer, size_t capacity)
+{
+    GUARD(self);
+    if (!buffer && capacity) return HUF_ERROR_INVALID_ARGUMENT;
+    huf_read_writer_t *rw = (huf_read_writer_t *)calloc(1, sizeof(*rw));
+    membuf_t *m = (membuf_t *)calloc(1, sizeof(*m));
+    if (!rw || !m) {
+        free(rw); free(m);
+        return HUF_ERROR_MEMORY_ALLOCATION;
+    }
+    m->wrapped = buffer;
+    m->buf = &m->wrapped;
+    m->cap = capacity;
+    m->fixed = 1;
+    advise_huge_pages(buffer, capacity);            /* (a fresh result buffer: its first write is bound by page faults) */
     rw->stream = m;
     rw->write = memwrite;
     rw->read = memread;

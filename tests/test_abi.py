@@ -410,3 +410,28 @@ def test_session_pool_follows_the_device_list():
             assert configured >= 1
         else:
             assert configured == want, (value, configured)
+
+
+def test_memwrap_out_is_a_fixed_capacity_writer():
+    """huf_gpu_memwrap_out (extension): a writer over memory the caller provides - what is written lands there,
+    what does not fit is refused (error 1), nothing is grown, moved or freed."""
+    import ctypes as C
+    from libhuffman_amd import _native as N
+    L = N.load()
+    buf = (C.c_char * 16)()
+    rw = C.POINTER(N.ReadWriter)()
+    assert L.huf_gpu_memwrap_out(C.byref(rw), C.addressof(buf), 16) == 0
+    w = rw.contents
+    assert w.write(w.stream, b"0123456789", 10) == 0
+    n = C.c_size_t()
+    assert L.huf_memlen(rw, C.byref(n)) == 0 and n.value == 10
+    assert w.write(w.stream, b"abcdefg", 7) == N.HUF_ERROR_MEMORY_ALLOCATION          # 17 > 16
+    assert L.huf_memlen(rw, C.byref(n)) == 0 and n.value == 10
+    assert w.write(w.stream, b"abcdef", 6) == 0
+    assert bytes(buf) == b"0123456789abcdef"
+    got = (C.c_char * 16)()
+    cnt = C.c_size_t(16)
+    assert w.read(w.stream, got, C.byref(cnt)) == 0 and cnt.value == 16 and bytes(got) == bytes(buf)
+    assert L.huf_memclose(C.byref(rw)) == 0
+    assert bytes(buf) == b"0123456789abcdef"                                             # the memory is the caller's
+    assert L.huf_gpu_memwrap_out(C.byref(rw), None, 4) != 0

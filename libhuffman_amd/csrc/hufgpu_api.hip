@@ -540,7 +540,7 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
         geo.n = n;
         geo.blocksize = blocksize;
         geo.cpb = (uint32_t)cpb;
-        chunk_hist_kernel<HIST_THREADS><<<dim3((unsigned)nchunks), dim3(HIST_THREADS), 0, s>>>(in, geo, ctx->d_chunk_hist);
+        chunk_hist_kernel<HL_THREADS><<<dim3((unsigned)nchunks), dim3(HL_THREADS), 0, s>>>(in, geo, ctx->d_chunk_hist);
         block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, (uint64_t *)ctx->d_hist);
         STAGE_MARK(ctx, s);
         tree_kernel<uint64_t, uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>((const uint64_t *)ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);

@@ -18,8 +18,9 @@ namespace hufgpu {
  *
  * The self-synchronising decoder (decode.hpp) has to find out where codewords start: every symbol
  * is decoded at least twice (count pass + write pass) plus the synchronisation rounds.  Here a
- * lane is TOLD where its 32 symbols start, decodes them once through the same 2^12-entry table
- * and stores them as two 16-byte words.  What it is told is verified, not trusted:
+ * lane is TOLD where its 32 symbols start, decodes them once through a 2^12-entry table (a second
+ * level for codes of up to 18 bits) and stores them as one 32-byte sector.  What it is told is
+ * verified, not trusted:
  *   (a) the block's first tile starts at payload bit 0,
  *   (b) a lane's 32 codewords take exactly the bits its group is said to have, none of its walks
  *       leaves the tree and none needs bits past the payload,
@@ -34,11 +35,8 @@ namespace hufgpu {
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
 #define DSUB_L2_BITS 6u                     /* a second-level table takes codes of up to 12 + 6 bits */
 #define DSUB_L2_ENTRIES 1024u               /* it lives in DecShared::ent */
-#define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: 31 table codewords + two refills of a lane that runs wild */
+#define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: what a lane that runs wild (32 look-ups of at most 18 bits) or a long code's walk may look at */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
-#ifndef DSUB_ROUNDS_UNROLL
-#define DSUB_ROUNDS_UNROLL "unroll"
-#endif
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
 
 /* The staged payload words of a wave lie in its LDS slice in REVERSED order: word g (big-endian, 32 payload bits)

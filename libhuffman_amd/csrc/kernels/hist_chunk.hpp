@@ -8,6 +8,7 @@
 #include "../hufgpu_common.h"
 #include "histogram.hpp"
 #include "offsets.hpp"
+#include "hist_lanes.hpp"
 
 namespace hufgpu {
 
@@ -33,46 +34,18 @@ struct ChunkGeom {
     }
 };
 
-/* byte counts of every chunk: hist256's counting loop (histogram.hpp) on a chunk */
+/* byte counts of every chunk: lane-private counters (hist_lanes.hpp: hl_count), one workgroup per chunk */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void chunk_hist_kernel(const uint8_t *__restrict__ in, ChunkGeom geo,
                                                              uint32_t *__restrict__ chunk_hist)
 {
-    constexpr int WAVES = THREADS / 64;
-    constexpr int COPIES = WAVES * HIST_COPIES;
-    __shared__ uint32_t s_hist[COPIES * HUF_NSYM];
-    const int tid = (int)threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HUF_NSYM * 64 * 4];
     uint64_t base, len;
-    const bool any = geo.locate(blockIdx.x, base, len);
-    for (int i = tid; i < COPIES * HUF_NSYM; i += THREADS) s_hist[i] = 0;
-    __syncthreads();
-    if (any) {
-        uint32_t *mine = s_hist + ((tid >> 6) * HIST_COPIES + (tid & (HIST_COPIES - 1))) * HUF_NSYM;
-        const uint8_t *p = in + base;
-        const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
-        if ((uint64_t)tid < head) atomicAdd(&mine[p[tid]], 1u);
-        const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
-        const uint64_t nvec = (len - head) >> 4;
-        uint64_t i = (uint64_t)tid;
-        for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {           /* four loads in flight per lane */
-            const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
-                        v2 = load_stream16(q + i + 2 * THREADS), v3 = load_stream16(q + i + 3 * THREADS);
-            hist_add_chunk(mine, v0);
-            hist_add_chunk(mine, v1);
-            hist_add_chunk(mine, v2);
-            hist_add_chunk(mine, v3);
-        }
-        for (; i < nvec; i += THREADS) hist_add_chunk(mine, load_stream16(q + i));
-        const uint64_t tail0 = head + (nvec << 4);
-        if (tail0 + (uint64_t)tid < len) atomicAdd(&mine[p[tail0 + tid]], 1u);   /* < 16 bytes */
+    if (!geo.locate(blockIdx.x, base, len)) {            /* (a chunk behind the stream's last, short block) */
+        for (int b = (int)threadIdx.x; b < HUF_NSYM; b += THREADS) chunk_hist[(uint64_t)blockIdx.x * HUF_NSYM + b] = 0;
+        return;
     }
-    __syncthreads();
-    for (int b = tid; b < HUF_NSYM; b += THREADS) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int w = 0; w < COPIES; w++) sum += s_hist[w * HUF_NSYM + b];
-        chunk_hist[(uint64_t)blockIdx.x * HUF_NSYM + b] = sum;
-    }
+    hl_count<THREADS>(hl_lds, in + base, len, chunk_hist + (uint64_t)blockIdx.x * HUF_NSYM);
 }
 
 /* byte counts of every block = the sums over its chunks (64-bit: a block may be longer than 2^32 bytes) */

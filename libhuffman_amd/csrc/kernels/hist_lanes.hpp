@@ -48,14 +48,10 @@ __device__ __forceinline__ void hl_add_vec(uint8_t *hl_lds, uint4 v, uint32_t co
     hl_add_dword(hl_lds, v.w, col);
 }
 
+/* the 256 counts of `len` bytes at `p` -> out[256] (the whole workgroup; hl_lds = its 64 KiB) */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__restrict__ in, uint64_t n, uint64_t blocksize,
-                                                             uint32_t *__restrict__ hist)
+__device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restrict__ p, uint64_t len, uint32_t *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HUF_NSYM * 64 * 4];      /* uint32 [256 byte values][64 lanes] */
-    const uint64_t blk = blockIdx.x;
-    const uint64_t base = blk * blocksize;
-    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
     const int tid = (int)threadIdx.x;
     const uint32_t col = (uint32_t)(tid & 63) << 2;
 
@@ -65,7 +61,6 @@ __global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__re
 #pragma unroll
         for (int i = 0; i < (HUF_NSYM * 64 * 4) / 16 / THREADS; i++) z[i * THREADS + tid] = zero;
     }
-    const uint8_t *p = in + base;
     const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
@@ -100,7 +95,6 @@ __global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__re
      * four words and then the sixteen lanes of the row (DPP row_shr 1, 2, 4, 8: the sum ends in the row's lane 15) */
     constexpr int WAVES = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t *out = hist + blk * HUF_NSYM;
 #pragma unroll
     for (int it = 0; it < HUF_NSYM / (4 * WAVES); it++) {
         const int row = (it * WAVES + wave) * 4 + (lane >> 4);
@@ -112,6 +106,17 @@ __global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__re
         s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
         if ((lane & 15) == 15) out[row] = s;
     }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__restrict__ in, uint64_t n, uint64_t blocksize,
+                                                             uint32_t *__restrict__ hist)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HUF_NSYM * 64 * 4];      /* uint32 [256 byte values][64 lanes] */
+    const uint64_t blk = blockIdx.x;
+    const uint64_t base = blk * blocksize;
+    const uint64_t len = dmin<uint64_t>(blocksize, n - base);
+    hl_count<THREADS>(hl_lds, in + base, len, hist + blk * HUF_NSYM);
 }
 
 /* tree_wave_kernel - tree_fast_wave (tree.hpp) as a launch of its own: one wavefront per block, counts from

@@ -85,6 +85,7 @@ struct PackAcc {
         const uint32_t l1 = e1 & 0xffu, l2 = e2 & 0xffu;
         push32(((((e0 >> 8) << l1) | (e1 >> 8)) << l2) | (e2 >> 8), (e0 & 0xffu) + l1 + l2);
     }
+    __device__ __forceinline__ uint32_t tail() const { return (uint32_t)(acc & ((1ull << nacc) - 1ull)); }
     __device__ __forceinline__ void push(CodeT e)
     {
         uint32_t len = (uint32_t)(e & 0xffu);
@@ -100,6 +101,52 @@ struct PackAcc {
         }
     }
 };
+
+/* Codes of at most 24 bits (the short-code launch; blocks of any launch whose longest code is that short): ONE
+ * 32-bit register of bits not yet emitted.  At most 31 of them are valid between pushes (what lies above is
+ * history on its way out), a push adds at most 31, and the word that becomes complete is cut from the register
+ * pair {bits that left the register, register} - no 64-bit shift anywhere: half the registers of the 64-bit
+ * accumulator, cheaper instructions, and nothing for the gfx950 last-VGPR shift hazard to bite. */
+#ifndef PACK_ACC64           /* (-DPACK_ACC64: the 64-bit accumulator for every code width, as in round 2 - the build that
+                                showed the hazard at seven waves per SIMD, kept for tests/test_isa_check.py) */
+template <>
+struct PackAcc<uint32_t> {
+    uint32_t acc;       /* right-aligned bits not yet emitted (the low `nacc` of them count) */
+    uint32_t nacc;      /* number of them (< 32 between pushes) */
+    uint32_t first;     /* first finished word (its leading bits belong to the left neighbour) */
+    bool have_first;
+    uint32_t *gw;       /* where the next finished word goes (LDS stage or HBM, fixed per tile) */
+
+    __device__ __forceinline__ void emit(uint32_t word)
+    {
+        if (!have_first) { first = word; have_first = true; }
+        else *gw = __builtin_bswap32(word);
+        gw++;
+    }
+    __device__ __forceinline__ void push32(uint32_t code, uint32_t len)     /* len <= 31 */
+    {
+        const uint32_t out = acc >> ((32u - len) & 31u);     /* the bits the shift pushes out (used only when len >= 1) */
+        acc = (acc << len) | code;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            emit(__builtin_amdgcn_alignbit(out, acc, nacc));
+        }
+    }
+    __device__ __forceinline__ void push_pair(uint32_t e0, uint32_t e1)      /* two codes of at most 15 bits each */
+    {
+        const uint32_t l1 = e1 & 0xffu;
+        push32(((e0 >> 8) << l1) | (e1 >> 8), (e0 & 0xffu) + l1);
+    }
+    __device__ __forceinline__ void push_triple(uint32_t e0, uint32_t e1, uint32_t e2)   /* three codes of at most 10 bits each */
+    {
+        const uint32_t l1 = e1 & 0xffu, l2 = e2 & 0xffu;
+        push32(((((e0 >> 8) << l1) | (e1 >> 8)) << l2) | (e2 >> 8), (e0 & 0xffu) + l1 + l2);
+    }
+    __device__ __forceinline__ void push(uint32_t e) { push32(e >> 8, e & 0xffu); }
+    __device__ __forceinline__ uint32_t tail() const { return acc & ((1u << nacc) - 1u); }
+};
+#endif
 
 /* byte j of the block header (encoder.c:325-339, little-endian fields) */
 __device__ __forceinline__ uint32_t header_byte(uint32_t j, uint64_t block_len, uint32_t tree_len,
@@ -252,7 +299,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
             for (int k = 0; k < PACK_SPT; k++) a.push(code[k]);
         }
         const uint32_t nwords = (uint32_t)(a.gw - (staged ? s_first : g_first));   /* finished words of this lane */
-        const uint32_t tail_val = (uint32_t)(a.acc & ((1ull << a.nacc) - 1ull));
+        const uint32_t tail_val = a.tail();
 
         /* ---- tails hop one lane to the right ---- */
         uint32_t in_tail = wave_up1_u32(tail_val);
@@ -305,12 +352,14 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
  * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
  * registers, more waves. */
 #ifndef PACK_WAVES_PER_SIMD
-#define PACK_WAVES_PER_SIMD 6          /* 75 of 80 VGPRs.  With 7 (72 of 72 VGPRs; zipf255 0.50 -> 0.47 ms) hipcc 7.2 keeps code[5] of the
-                                          one-code-per-push form in v71, the LAST register of the allocation, and on gfx950 a 64-bit shift
-                                          whose shift amount is the last allocated VGPR shifts by something else (here: by the lane number) in
-                                          every wave that is not the first on its SIMD - wrong payload bits in blocks 256 and up.  Root cause,
-                                          reproducer and the build-time check: DESIGN.md 3.3, tools/calib/last_vgpr_probe.hip,
-                                          libhuffman_amd/isa_check.py (the build FAILS if any kernel shows the pattern). */
+#define PACK_WAVES_PER_SIMD 6          /* Round 2's build with 7 (72 of 72 VGPRs) kept code[5] of the one-code-per-push form in v71, the
+                                          LAST register of the allocation, and on gfx950 a 64-bit shift whose shift amount is the last
+                                          allocated VGPR shifts by something else (there: by the lane number) in every wave that is not
+                                          the first on its SIMD - wrong payload bits in blocks 256 and up.  Root cause, reproducer and the
+                                          build-time check: DESIGN.md 3.3, tools/calib/last_vgpr_probe.hip, libhuffman_amd/isa_check.py
+                                          (the build FAILS if any kernel shows the pattern).  Since round 3 the short-code accumulator shifts
+                                          32 bits at a time (PackAcc<uint32_t>: 69 VGPRs, seven waves would fit and pass the check) - and
+                                          seven waves are not faster: pack waits for the memory system, not for a wave slot. */
 #endif
 template <int THREADS, bool SHORT>
 __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack_kernel(const uint8_t *__restrict__ in, uint64_t n,
@@ -351,7 +400,7 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     if (m.max_len <= 10)                 /* three codes per push */
         pack_block<THREADS, uint32_t, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                          reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
-    else if (m.max_len <= 16)            /* two codes per push */
+    else if (m.max_len <= 15)            /* two codes per push (at most 31 bits: PackAcc<uint32_t>) */
         pack_block<THREADS, uint32_t, 2>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                             reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
     else if (SHORT || m.max_len <= 24)

@@ -28,12 +28,17 @@ def build_variant(name, flags):
     return path
 
 
-@pytest.mark.parametrize("variant", ["default", "w7_slack"])
+@pytest.mark.parametrize("variant", ["default", "w7", "acc64_w7_slack"])
 def test_deep_code_stress_on_the_six_and_the_seven_wave_build(variant):
+    """default = the shipped build (32-bit accumulator for short codes, six waves); w7 = the same at seven waves
+    (no 64-bit shift left: nothing for the hazard to bite); acc64_w7_slack = round 2's code generation (64-bit
+    accumulator, seven waves) with its one register of slack."""
     env = dict(os.environ)
     env.pop("HUF_LIB_PATH", None)
-    if variant == "w7_slack":
-        env["HUF_LIB_PATH"] = build_variant("w7_slack", '-DPACK_WAVES_PER_SIMD=7 -DPACK_VGPR_SLACK="v72"')
+    if variant == "w7":
+        env["HUF_LIB_PATH"] = build_variant("w7", "-DPACK_WAVES_PER_SIMD=7")
+    if variant == "acc64_w7_slack":
+        env["HUF_LIB_PATH"] = build_variant("acc64_w7_slack", '-DPACK_ACC64 -DPACK_WAVES_PER_SIMD=7 -DPACK_VGPR_SLACK="v72"')
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_pack.py"), "n2400", "11", "2"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-12:]) + r.stderr[-2000:]

@@ -75,10 +75,23 @@ def test_the_shipped_kernels_are_clean(shipped_table):
 
 
 def test_the_seven_wave_pack_build_is_rejected_and_its_slack_build_accepted():
-    """round 2's 'faster, and wrong' build: 72 of 72 VGPRs with code[5] in v71"""
+    """round 2's 'faster, and wrong' build: the 64-bit accumulator (-DPACK_ACC64), 72 of 72 VGPRs with code[5] in v71"""
     with pytest.raises(RuntimeError) as e:
-        build.check_isa(extra_flags=["-DPACK_WAVES_PER_SIMD=7"])
+        build.check_isa(extra_flags=["-DPACK_ACC64", "-DPACK_WAVES_PER_SIMD=7"])
     assert "pack_kernel" in str(e.value) and "v71" in str(e.value)
-    table = build.check_isa(extra_flags=["-DPACK_WAVES_PER_SIMD=7", '-DPACK_VGPR_SLACK="v72"'])
+    table = build.check_isa(extra_flags=["-DPACK_ACC64", "-DPACK_WAVES_PER_SIMD=7", '-DPACK_VGPR_SLACK="v72"'])
     (vg,) = [r["vgprs"] for n, r in table.items() if "pack_kernelILi256ELb1" in n]
     assert vg == 73
+
+
+def test_the_short_code_accumulator_has_no_64_bit_shift_left():
+    """round 3: PackAcc<uint32_t> - the accumulator of the shipped short-code pack_kernel shifts 32 bits at a time
+    (what is left of 64-bit shifts there: the header's block length by a byte count, addresses by constants), and
+    the seven-wave build passes the check"""
+    asm = build.device_asm([])
+    body = asm[asm.index("_ZN6hufgpu11pack_kernelILi256ELb1EE"):]
+    body = body[:body.index(".amdhsa_kernel")]
+    assert "v_lshlrev_b64" not in body
+    table = build.check_isa(extra_flags=["-DPACK_WAVES_PER_SIMD=7"])
+    (vg,) = [r["vgprs"] for n, r in table.items() if "pack_kernelILi256ELb1" in n]
+    assert vg <= 72

@@ -351,7 +351,7 @@ class Bench:
             dom = max((k for k in ("pack", "decode", "hist256", "tree", "hist_tree") if k in kernels),
                       key=lambda k: kernels[k]["avg_ms"])
             achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
-            kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_kernel", "pack": "pack_kernel",
+            kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_fast_kernel", "pack": "pack_kernel",
                             "hist_tree": "hist_tree_kernel", "hist256": "hist_lanes_kernel" if bs < (1 << 22) else "chunk_hist_kernel",
                             "tree": "tree_wave_kernel" if bs < (1 << 22) else "tree_kernel"}
             pipeline_bytes = 2 * (n + comp_len)     # the metric's bytes (side tables are implementation traffic)
@@ -370,7 +370,7 @@ class Bench:
                                       else "self-synchronising (block index only)"},
                 "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 1),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                             "traffic": measured_traffic(workload, dom, n, bs),
+                             "traffic": measured_traffic(workload, "decode_index" if (dom == "decode" and not use_sub) else dom, n, bs),
                              "alg_bytes_per_launch": alg[dom],
                              "side_bytes_per_launch": sub_bytes if dom in ("pack", "decode") else 0,
                              "pipeline_frac": round(pipeline_bytes / 1e9 / (gpu_ms / 1e3) / HBM_PEAK_GBS, 4)},

@@ -334,7 +334,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
  * payload is never part of a track that passes the checks, so it need not be zeroed). */
 template <int THREADS>
 __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
-                                    uint8_t *gout)
+                                    uint8_t *gout, uint64_t *end_bits = nullptr)
 {
     typedef DfastLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
@@ -452,12 +452,14 @@ __device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, 
             if (qe > pay_rel) atomicAdd(&g_dfast_dbg[5], 1ull);
 #endif
             if (qe > pay_rel) { lane_ok = false; }                         /* a codeword of the block needs bits past the payload */
+            if (end_bits && ex + quota == take && (uint64_t)take == remaining) sh.qend = qe;      /* behind the block's last symbol */
         }
         const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
         if (!__syncthreads_and(lane_ok ? 1 : 0)) { ok = false; DFAST_DBG(2, 1); break; }
         DFAST_DBG(11, 1);
         produced += take;
         if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }                          /* (no progress: cannot happen on a track that holds codewords) */
+        if (end_bits && produced == block_len) *end_bits = seg0 + (uint64_t)uni32(sh.qend);      /* payload bits up to and including the last symbol */
         true_start = seg0 + last_end;
     }
     return ok;

@@ -333,7 +333,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
  * readable = bytes that may be loaded from `pay` on (to the end of the stream: what lies behind the block's
  * payload is never part of a track that passes the checks, so it need not be zeroed). */
 template <int THREADS>
-__device__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+__device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
                                     uint8_t *gout, uint64_t *end_bits = nullptr)
 {
     typedef DfastLds<THREADS> L;

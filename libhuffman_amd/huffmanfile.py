@@ -59,10 +59,14 @@ _PyBytes_AsString.argtypes = [C.py_object]
 
 # the same object handled by its address: a result that is filled in place and then cut to size must not be
 # referenced from Python before _PyBytes_Resize (which wants the only reference)
-_PyBytes_NewRaw = C.PYFUNCTYPE(C.c_void_p, C.c_void_p, C.c_ssize_t)(("PyBytes_FromStringAndSize", C.pythonapi))
-_PyBytes_AsStringRaw = C.PYFUNCTYPE(C.c_void_p, C.c_void_p)(("PyBytes_AsString", C.pythonapi))
-_PyBytes_ResizeRaw = C.PYFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_ssize_t)(("_PyBytes_Resize", C.pythonapi))
-_Py_DecRefRaw = C.PYFUNCTYPE(None, C.c_void_p)(("Py_DecRef", C.pythonapi))
+try:
+    _PyBytes_NewRaw = C.PYFUNCTYPE(C.c_void_p, C.c_void_p, C.c_ssize_t)(("PyBytes_FromStringAndSize", C.pythonapi))
+    _PyBytes_AsStringRaw = C.PYFUNCTYPE(C.c_void_p, C.c_void_p)(("PyBytes_AsString", C.pythonapi))
+    _PyBytes_ResizeRaw = C.PYFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_ssize_t)(("_PyBytes_Resize", C.pythonapi))
+    _Py_DecRefRaw = C.PYFUNCTYPE(None, C.c_void_p)(("Py_DecRef", C.pythonapi))
+    _IN_PLACE = True
+except (AttributeError, ValueError):      # an interpreter without these entry points: results go through a stream buffer
+    _IN_PLACE = False
 _BIG_RESULT = 8 << 20        # from here on a result is produced in place (below, the copies cost less than the calls)
 
 
@@ -209,7 +213,7 @@ class HuffmanCompressor:
         n = len(data)
         if n == 0:
             return b""
-        if n >= _BIG_RESULT:
+        if _IN_PLACE and n >= _BIG_RESULT:
             # straight into the result: header + tree are at most 2 060 bytes a block, a code at most 9 bits on
             # average (8 + the wrap root's) - the bound the device path allocates by, and then some
             nblocks = (n + self._blocksize - 1) // self._blocksize
@@ -278,7 +282,7 @@ class HuffmanDecompressor:
         n = len(view)
         if n == 0:
             return b""
-        if n >= _BIG_RESULT:
+        if _IN_PLACE and n >= _BIG_RESULT:
             # straight into the result, with room for four times the stream (more than that - long runs of one
             # byte - does not fit, and the growable stream below takes the call)
             # (a stream that begins with a one-symbol block - tree_len 5: one bit a symbol - may be all of them)

@@ -292,3 +292,27 @@ def test_large_results_take_the_threaded_copy():
         c = huffmanfile.HuffmanCompressor(blocksize=65536)
         parts = [c.compress(data[i:i + (4 << 20)]) for i in range(0, n, 4 << 20)] + [c.flush()]
         assert b"".join(parts) == comp
+
+
+@gpu
+def test_results_in_place_and_the_growable_stream_behind_them(monkeypatch):
+    """compress()/decompress() of 8 MiB and more write straight into the bytes object they return
+    (huf_gpu_memwrap_out); a result that does not fit the room that was made - here: a stream that begins like
+    any other and then holds 200 MiB of one byte in 25 MiB - goes through the growable stream instead, and a
+    stream that BEGINS with one-symbol blocks is given nine times its size at once.  Same bytes either way."""
+    from libhuffman_amd import huffmanfile as hf
+    assert hf._IN_PLACE
+    head = datagen.zipf255(1 << 20).tobytes()
+    data = head + bytes(200 << 20)
+    comp = huffmanfile.compress(data, blocksize=1 << 20)
+    assert (8 << 20) < len(comp) < (40 << 20)                  # in place, and more than four times smaller than the data
+    back = huffmanfile.decompress(comp)                        # does not fit 4 x len(comp): the growable stream
+    assert type(back) is bytes and len(back) == len(data) and back == data
+    zeros = bytes(128 << 20)
+    zc = huffmanfile.compress(zeros, blocksize=1 << 20)        # 16 MiB of one-symbol blocks
+    assert len(zc) > (8 << 20) and huffmanfile.decompress(zc) == zeros
+    # with the in-place path switched off the same bytes come out
+    monkeypatch.setattr(hf, "_IN_PLACE", False)
+    assert huffmanfile.compress(data, blocksize=1 << 20) == comp
+    assert huffmanfile.decompress(comp) == data
+

@@ -352,7 +352,7 @@ class Bench:
                       key=lambda k: kernels[k]["avg_ms"])
             achieved = alg[dom] / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
             kernel_names = {"decode": "decode_sub_kernel" if use_sub else "decode_fast_kernel", "pack": "pack_kernel",
-                            "hist_tree": "hist_tree_kernel", "hist256": "hist_lanes_kernel" if bs < (1 << 22) else "chunk_hist_kernel",
+                            "hist_tree": "hist_tree_kernel", "hist256": "hist_lanes_kernel" if bs < (1 << 21) else "chunk_hist_kernel",
                             "tree": "tree_wave_kernel" if bs < (1 << 22) else "tree_kernel"}
             pipeline_bytes = 2 * (n + comp_len)     # the metric's bytes (side tables are implementation traffic)
             gpu_ms = ev0.elapsed_time(ev1) / K

@@ -506,7 +506,7 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
     STAGE_BEGIN(ctx, s, PROF_ENCODE);
     TwoLevel sizes = ctx->enc_sizes;
     static const bool fused_only = getenv("HUF_GPU_FUSED_HIST") && atoi(getenv("HUF_GPU_FUSED_HIST")) != 0;   /* (measurements: the one-launch form) */
-    if (blocksize < HUF_BIG_BLOCK) {
+    if (blocksize < HUF_CHUNKED_FROM) {
         /* counts, tree and the sums of the encoded sizes in one launch (the profile's "tree" and
          * "scan_sizes" stages are then empty) */
         sizes.total = offs + nb;
@@ -541,12 +541,21 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
         geo.blocksize = blocksize;
         geo.cpb = (uint32_t)cpb;
         chunk_hist_kernel<HL_THREADS><<<dim3((unsigned)nchunks), dim3(HL_THREADS), 0, s>>>(in, geo, ctx->d_chunk_hist);
-        block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, (uint64_t *)ctx->d_hist);
-        STAGE_MARK(ctx, s);
-        tree_kernel<uint64_t, uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>((const uint64_t *)ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        if (blocksize < HUF_BIG_BLOCK) {
+            /* rates below 2^23: the wave-per-block tree with 32-bit keys (its sums of the encoded sizes are not used
+             * here: scan_sizes_kernel writes the index below) */
+            sizes.total = offs + nb;
+            block_hist32_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_hist);
+            STAGE_MARK(ctx, s);
+            tree_wave_kernel<<<dim3((unsigned)nb), dim3(64), 0, s>>>(ctx->d_hist, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, sizes);
+        } else {
+            block_hist_kernel<<<dim3((unsigned)nb), dim3(HUF_NSYM), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, (uint64_t *)ctx->d_hist);
+            STAGE_MARK(ctx, s);
+            tree_kernel<uint64_t, uint64_t><<<dim3((unsigned)nb), dim3(64), 0, s>>>((const uint64_t *)ctx->d_hist, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta);
+        }
         STAGE_MARK(ctx, s);
         scan_sizes_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_meta, nb, offs);
-        chunk_total_kernel<<<dim3((unsigned)nchunks), dim3(64), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_codetab, ctx->d_chunk_tot);
+        chunk_total_kernel<<<dim3((unsigned)nchunks), dim3(64), 0, s>>>(ctx->d_chunk_hist, (uint32_t)cpb, ctx->d_codetab, ctx->d_meta, ctx->d_chunk_tot);
         chunk_scan_kernel<SCAN_THREADS><<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(ctx->d_chunk_tot, (uint32_t)cpb, ctx->d_chunk_bits);
         STAGE_MARK(ctx, s);
         sizes.local = NULL;              /* pack reads the finished index */
@@ -556,7 +565,7 @@ static int encode_impl(hufgpu_ctx_t *ctx, const void *d_in, uint64_t n, uint64_t
         ck.cpb = (uint32_t)cpb;
         pack_chunk_kernel<PACK_THREADS, false><<<dim3((unsigned)nchunks), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub, ck);
     }
-    if (blocksize >= HUF_BIG_BLOCK) {
+    if (blocksize >= HUF_CHUNKED_FROM) {
         /* (packed above) */
     } else if (blocksize <= 121392ull)   /* deepest possible code <= 24 bits: 32-bit code path only */
         pack_kernel<PACK_THREADS, true><<<dim3((unsigned)nb), dim3(PACK_THREADS), 0, s>>>(in, n, blocksize, ctx->d_codetab, ctx->d_treebuf, ctx->d_meta, offs, sizes, (uint8_t *)d_out, sub);

@@ -16,7 +16,10 @@ namespace hufgpu {
  * stream's last block may have fewer).  Chunk c of block b = input bytes
  * [b * blocksize + c * HUF_CHUNK_SYMS, ...).  cpb = chunks per block. */
 #define HUF_CHUNK_SYMS 262144u          /* 32 pack tiles: the sub-index' tiles and groups align with chunks */
-#define HUF_BIG_BLOCK  (1ull << 22)     /* from here on blocks are chunked (as before: from here on 64-bit tree keys) */
+#define HUF_BIG_BLOCK  (1ull << 22)     /* from here on 64-bit tree keys (a rate may reach 2^23) and, when decoding raw streams, a sub-index built on the device */
+#define HUF_CHUNKED_FROM (1ull << 21)   /* from here on blocks are ENCODED in chunks: one workgroup per block leaves most of the 256 CUs
+                                           without work when a GiB is only a few hundred blocks (pack at 2 / 3 MiB blocks: 0.81 / 1.19 ms per
+                                           GiB, chunked 0.57; at 1 MiB both forms take 0.64) */
 
 struct ChunkGeom {
     uint64_t n, blocksize;
@@ -61,17 +64,30 @@ __global__ __launch_bounds__(HUF_NSYM) void block_hist_kernel(const uint32_t *__
     hist[blk * HUF_NSYM + threadIdx.x] = sum;
 }
 
+/* the same with 32-bit sums (blocks below HUF_BIG_BLOCK: the wave-per-block tree of tree.hpp takes those) */
+__global__ __launch_bounds__(HUF_NSYM) void block_hist32_kernel(const uint32_t *__restrict__ chunk_hist, uint32_t cpb,
+                                                                uint32_t *__restrict__ hist)
+{
+    const uint64_t blk = blockIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t c = 0; c < cpb; c++) sum += chunk_hist[(blk * cpb + c) * HUF_NSYM + threadIdx.x];
+    hist[blk * HUF_NSYM + threadIdx.x] = sum;
+}
+
 /* payload bits of every chunk = sum over the bytes of count * code length (one wave per chunk) */
 __global__ __launch_bounds__(64) void chunk_total_kernel(const uint32_t *__restrict__ chunk_hist, uint32_t cpb,
-                                                         const hufcode_t *__restrict__ codetab,
+                                                         const hufcode_t *__restrict__ codetab, const HufBlockMeta *__restrict__ meta,
                                                          uint64_t *__restrict__ chunk_tot)
 {
+    asm volatile("; one VGPR more than the kernel uses (the build's ISA check: a 64-bit shift by the last of sixteen)" ::: "v16");
     const uint64_t chunk = blockIdx.x, blk = chunk / cpb;
+    /* a one-symbol block has no code table (the wave-per-block tree does not write one): one bit a symbol */
+    const bool one = meta[blk].tree_len == 5;
     uint64_t bits = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int s = lane_id() + 64 * j;
-        bits += (uint64_t)chunk_hist[chunk * HUF_NSYM + s] * (uint64_t)(codetab[blk * HUF_NSYM + s] & 0xffu);
+        bits += (uint64_t)chunk_hist[chunk * HUF_NSYM + s] * (one ? 1ull : (uint64_t)(codetab[blk * HUF_NSYM + s] & 0xffu));
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) bits += shfl_xor_u64(bits, o);

@@ -257,9 +257,15 @@ def test_full_size_sub_index_roundtrip(torch_mod, codec):
     ("const41", 12 << 20, 6 << 20),                 # one-symbol blocks, chunked
     ("logtext", 20 << 20, 0),                       # blocksize 0: ONE block of the whole input (src/encoder.c:163-165)
     ("zipf255", (4 << 20) + 1, 0),
+    # 2 MiB .. 4 MiB: chunked like the big ones, but with the wave-per-block tree (rates below 2^23); 1 MiB: one workgroup per block
+    ("zipf255", (5 << 20) + 4321, 1 << 20),         # configs[4]'s block size, a short last block
+    ("logtext", (7 << 20) + 1, (2 << 20) + 77777),  # chunks that do not divide the block
+    ("uniform256", 9 << 20, 3 << 20),               # k = 256
+    ("const41", (4 << 20) - 1, 2 << 20),            # one-symbol blocks; the last block one byte short
+    ("zipf255", (4 << 20) - 1, 0),                  # ONE block just below the 64-bit tree's threshold
 ])
 def test_big_blocks_are_chunked_bit_exact(torch_mod, codec, oracle, kind, n, bs):
-    """Blocks of 4 MiB and more are cut into 256 KiB chunks (one workgroup each) by the encoder and
+    """Blocks of 2 MiB and more are cut into 256 KiB chunks (one workgroup each) by the encoder and
     into 64 KiB chunks by the sub-index decoder; the stream is the oracle's, byte for byte."""
     torch = torch_mod
     data = datagen.GENERATORS[kind](n)

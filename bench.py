@@ -156,6 +156,49 @@ def measured_traffic(workload: str, kernel: str, n: int, bs: int):
         return None
 
 
+def live_traffic(workload: str, kernel: str, timeout: float = 180.0):
+    """HBM bytes per launch of `kernel` counted in THIS run: two child passes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domain mixed in; FETCH_SIZE
+    doubled: the gfx950 correction of MI355X_MICROARCH.md; KiB -> bytes).  None when rocprofv3 is not there, this
+    process is itself being profiled, or a pass fails or takes too long - the stamp of profiles/traffic.json
+    (same kernel sources) stays in the line then."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or any(k in os.environ for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES")) \
+            or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(d, ctr), "-o", "p", "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--workload", workload,
+                       "--secondary", "none", "--no-cpu-baseline", "--no-other-decode", "--no-index-free",
+                       "--no-python-layer", "--no-verify", "--no-live-traffic"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
+                if r.returncode != 0:
+                    return None
+                files = glob.glob(os.path.join(d, ctr, "**", "*counter_collection.csv"), recursive=True)
+                if not files:
+                    return None
+                total, launches = 0.0, set()
+                with open(files[0]) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == ctr and kernel in row["Kernel_Name"]:
+                            total += float(row["Counter_Value"])
+                            launches.add(row["Dispatch_Id"])
+                if not launches:
+                    return None
+                got[ctr] = total / len(launches)
+        return round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    except Exception:
+        return None
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD process (this
     process has not touched a GPU and never will) and relay rank 0's JSON line."""
@@ -514,6 +557,8 @@ def main() -> None:
     ap.add_argument("--no-other-decode", action="store_true")
     ap.add_argument("--no-index-free", action="store_true", help="skip the timed loop with the block index alone")
     ap.add_argument("--no-python-layer", action="store_true", help="skip the huffmanfile (configs[4] shape) figure")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not count the longest kernel's HBM bytes with two rocprofv3 --pmc child passes (the stamp of profiles/traffic.json stays)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -610,6 +655,14 @@ def main() -> None:
             result["root_placement"] = root_rec
         if py_rec is not None:
             result["secondary"]["logtext_huffmanfile"] = py_rec
+        result["roofline"]["traffic_source"] = ("profiles/traffic.json: TCC counters of this command, collected for exactly these kernel sources"
+                                                if result["roofline"].get("traffic") is not None else None)
+        if world == 1 and not args.no_live_traffic:
+            lt = live_traffic(args.workload, result["roofline"]["kernel"])
+            if lt:
+                result["roofline"]["traffic"] = lt
+                result["roofline"]["traffic_source"] = ("counted in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes "
+                                                        "of this command (FETCH_SIZE doubled: gfx950)")
         result["roofline"]["copy_ceiling_GBps"] = round(copy_gbs, 1)
         result["roofline"]["frac_of_copy_ceiling"] = round(result["roofline"]["achieved"] / copy_gbs, 4)
         if world > 1:

@@ -830,7 +830,7 @@ def test_bench_runs_over_rccl_with_one_rank(torch_mod):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1",
-                          "--bytes-per-gpu", str(64 << 20), "--secondary", "const41", "--no-cpu-baseline"],
+                          "--bytes-per-gpu", str(64 << 20), "--secondary", "const41", "--no-cpu-baseline", "--no-live-traffic"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -840,6 +840,27 @@ def test_bench_runs_over_rccl_with_one_rank(torch_mod):
     rp = d["root_placement"]
     assert "error" not in rp, rp
     assert rp["bit_exact_roundtrip"] is True and rp["value"] > 0
+
+
+def test_bench_counts_the_longest_kernels_traffic_in_its_own_run(torch_mod):
+    """roofline.traffic of the default bench line is counted in the run itself (two rocprofv3 --pmc child passes of
+    the same command), not taken from a table: between the algorithmic bytes and 1.3 times them for the kernels the
+    step is made of."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("rocprofv3"):
+        pytest.skip("no rocprofv3 here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--secondary", "none",
+                          "--no-cpu-baseline", "--no-index-free", "--no-python-layer", "--no-other-decode"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    rf = d["roofline"]
+    assert rf["traffic_source"].startswith("counted in this run"), rf
+    assert rf["alg_bytes_per_launch"] <= rf["traffic"] <= 1.3 * rf["alg_bytes_per_launch"], rf
 
 
 @pytest.mark.parametrize("top", [17, 24])

@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp
-COMMON="--secondary none --no-cpu-baseline --no-other-decode --no-index-free --no-python-layer"
+COMMON="--secondary none --no-cpu-baseline --no-other-decode --no-index-free --no-python-layer --no-live-traffic"
 for WL in $WLS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$WL -o run -- python3 $ROOT/bench.py --steps 20 --warmup 5 --workload $WL $COMMON > $OUT/${TAG}_${WL}_bench.json 2> $OUT/kt_$WL.err
   cp $(find $OUT/kt_$WL -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${WL}_kernel_stats.csv

@@ -156,7 +156,7 @@ def measured_traffic(workload: str, kernel: str, n: int, bs: int):
         return None
 
 
-def live_traffic(workload: str, kernel: str, timeout: float = 180.0):
+def live_traffic(workload: str, kernel: str, passthrough=(), timeout: float = 120.0):
     """HBM bytes per launch of `kernel` counted in THIS run: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domain mixed in; FETCH_SIZE
     doubled: the gfx950 correction of MI355X_MICROARCH.md; KiB -> bytes).  None when rocprofv3 is not there, this
@@ -178,7 +178,7 @@ def live_traffic(workload: str, kernel: str, timeout: float = 180.0):
                 cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(d, ctr), "-o", "p", "--",
                        sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--workload", workload,
                        "--secondary", "none", "--no-cpu-baseline", "--no-other-decode", "--no-index-free",
-                       "--no-python-layer", "--no-verify", "--no-live-traffic"]
+                       "--no-python-layer", "--no-verify", "--no-live-traffic"] + list(passthrough)
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
                 if r.returncode != 0:
                     return None
@@ -658,7 +658,10 @@ def main() -> None:
         result["roofline"]["traffic_source"] = ("profiles/traffic.json: TCC counters of this command, collected for exactly these kernel sources"
                                                 if result["roofline"].get("traffic") is not None else None)
         if world == 1 and not args.no_live_traffic:
-            lt = live_traffic(args.workload, result["roofline"]["kernel"])
+            same = ["--bytes-per-gpu", str(args.bytes_per_gpu), "--decode", args.decode]
+            if args.blocksize is not None:
+                same += ["--blocksize", str(args.blocksize)]
+            lt = live_traffic(args.workload, result["roofline"]["kernel"], same)
             if lt:
                 result["roofline"]["traffic"] = lt
                 result["roofline"]["traffic_source"] = ("counted in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes "

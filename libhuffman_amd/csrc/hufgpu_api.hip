@@ -1031,7 +1031,7 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
         DISC_TRACE("probe done");
         link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
         DISC_TRACE("link done");
-        walk_kernel<<<dim3(1), dim3(64), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
+        walk_kernel<<<dim3(1), dim3(WALK_THREADS), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
         DISC_TRACE("walk done");
         HIP_OK(ctx, hipGetLastError());
         HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));

@@ -399,12 +399,28 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         /* a lane whose share lies behind the payload holds nothing and ends where its share ends (the block's last
          * segment is a quarter full on average: its other lanes scanned what follows the block, and passed every
          * change of their neighbour's on) */
-        const bool dead = hi - DFAST_SUB_BITS >= pay_rel;
+        bool dead = hi - DFAST_SUB_BITS >= pay_rel;
         uint32_t end = hi, cnt = 0;
         if (__ballot(!dead)) {
             if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
             else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
             if (dead) { end = hi; cnt = 0; }
+        }
+        /* A caller that does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the
+         * stream) has no dead lanes by the test above, and the lanes behind the block's last symbol scan the next
+         * block's header and payload, round after round.  The speculative counts say where the block ends, a few
+         * symbols either way: a lane in front of which they already hold the rest of the block and a margin is taken
+         * for dead.  If that was wrong the segment ends short of the block, and the block goes to the exact decoder. */
+        bool assumed = false;
+        if (end_bits) {
+            uint32_t spec_total;
+            const uint32_t exs = block_excl_scan_u32<THREADS>(cnt, sh.part, spec_total);
+            if (!dead && (uint64_t)exs >= (block_len - produced) + 128u + ((uint32_t)tid >> 2)) {
+                dead = true;
+                assumed = true;
+                end = hi;
+                cnt = 0;
+            }
         }
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
@@ -444,7 +460,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             quota = take - ex;
             if (quota > cnt) quota = cnt;
         }
-        bool lane_ok = true;
+        bool lane_ok = !(assumed && (uint64_t)seg_total < remaining);        /* (the block does not end where the counts said) */
         if (quota) {
             const uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok);
 #ifdef DFAST_DEBUG

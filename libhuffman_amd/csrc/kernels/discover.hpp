@@ -277,7 +277,10 @@ __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *_
  * per GiB); any other link is followed one step at a time.  Every loop-control value is the
  * same in all lanes (ballots), so no flag is ever polled in memory. */
 #define WALK_CHUNK 8192
-__global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ cand,
+#define WALK_THREADS 1024
+/* (Round 3: the candidates of a chunk come into LDS with their links, loaded by sixteen waves - the one wave that
+ * walks read cand[] from memory inside its loop, one round trip per step of 64: 115 us per GiB of 64 KiB blocks.) */
+__global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const uint64_t *__restrict__ cand,
                                                   const uint64_t *__restrict__ cand_end,
                                                   const uint32_t *__restrict__ nxt, uint64_t ncand,
                                                   uint64_t *__restrict__ block_offsets,
@@ -285,41 +288,61 @@ __global__ __launch_bounds__(64) void walk_kernel(const uint64_t *__restrict__ c
                                                   const uint64_t *__restrict__ spec_off, uint64_t out_cap)
 {
     __shared__ uint32_t s_nxt[WALK_CHUNK];
-    const int lane = (int)threadIdx.x;
+    __shared__ uint64_t s_cand[WALK_CHUNK];
+    __shared__ uint64_t s_cur;
+    __shared__ int s_stop;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const bool walker = tid < 64;                      /* the first wave */
     uint64_t cur = 0, m = 0, resume = 0, consumed = 0;
     int complete = 0;
     bool contiguous = true;       /* validated block j is candidate j, for every j so far */
     bool stop = (ncand == 0) || (cand[0] != 0);       /* the stream must start with a header */
-    while (!stop) {
+    while (!stop) {                                    /* (cur and stop: the same in every thread) */
         const uint64_t base = cur - (cur % WALK_CHUNK);
         const uint64_t top = dmin<uint64_t>(base + WALK_CHUNK, ncand);      /* candidates [base, top) are in LDS */
-        for (uint64_t i = (uint64_t)lane; base + i < top; i += 64) s_nxt[i] = nxt[base + i];
-        __syncthreads();
-        uint64_t c = cur;
-        while (c < top) {
-            /* the run of plain links that starts at c */
-            const uint64_t idx = c + (uint64_t)lane;
-            const bool plain = idx < top && s_nxt[idx - base] == (uint32_t)(idx + 1);
-            const unsigned long long mask = __ballot(plain);
-            const uint32_t run = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);
-            if ((uint32_t)lane < run) block_offsets[m + (uint64_t)lane] = cand[idx];
-            if (run && c != m) contiguous = false;
-            m += run;
-            c += run;
-            if (run == 64u || c >= top) continue;
-            /* one link of another kind */
-            const uint32_t nx = s_nxt[c - base];
-            if (nx == LINK_BAD) { resume = cand[c]; stop = true; break; }
-            if (lane == 0) block_offsets[m] = cand[c];
-            if (c != m) contiguous = false;
-            m++;
-            if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
-            if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
-            c = nx;                                    /* nx > c: the chain only moves forward */
+#pragma unroll
+        for (int k = 0; k < WALK_CHUNK / WALK_THREADS; k++) {
+            const uint64_t i = (uint64_t)(tid + k * WALK_THREADS);
+            if (base + i < top) {
+                s_nxt[i] = nxt[base + i];
+                s_cand[i] = cand[base + i];
+            }
         }
-        cur = c;
-        __syncthreads();                               /* before s_nxt is reused */
+        __syncthreads();
+        if (walker) {
+            uint64_t c = cur;
+            while (c < top) {
+                /* the run of plain links that starts at c */
+                const uint64_t idx = c + (uint64_t)lane;
+                const bool plain = idx < top && s_nxt[idx - base] == (uint32_t)(idx + 1);
+                const unsigned long long mask = __ballot(plain);
+                const uint32_t run = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);
+                if ((uint32_t)lane < run) block_offsets[m + (uint64_t)lane] = s_cand[idx - base];
+                if (run && c != m) contiguous = false;
+                m += run;
+                c += run;
+                if (run == 64u || c >= top) continue;
+                /* one link of another kind */
+                const uint32_t nx = s_nxt[c - base];
+                if (nx == LINK_BAD) { resume = s_cand[c - base]; stop = true; break; }
+                if (lane == 0) block_offsets[m] = s_cand[c - base];
+                if (c != m) contiguous = false;
+                m++;
+                if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
+                if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
+                c = nx;                                    /* nx > c: the chain only moves forward */
+            }
+            if (lane == 0) {
+                s_cur = c;
+                s_stop = stop ? 1 : 0;
+            }
+        }
+        __syncthreads();                               /* the walker is done with this chunk; where it stands */
+        cur = s_cur;
+        stop = s_stop != 0;
     }
+    if (!walker) return;
     if (lane == 0) {
         result[0] = m;
         result[1] = resume;

@@ -355,6 +355,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     }
     uint64_t true_start = 0, produced = 0;
     bool ok = true;
+    bool trust = true;                                                 /* (uniform) guesses at the block's end are allowed */
     while (produced < block_len) {
         if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }             /* input exhausted: the exact decoder says how */
         const uint64_t seg0 = true_start & ~31ull;
@@ -400,27 +401,38 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
          * segment is a quarter full on average: its other lanes scanned what follows the block, and passed every
          * change of their neighbour's on) */
         bool dead = hi - DFAST_SUB_BITS >= pay_rel;
+        const uint64_t remaining = block_len - produced;
+        /* A caller that does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the
+         * stream) has no dead lanes by the test above, and the lanes behind the block's last symbol scan the next
+         * block's header and payload, round after round.  Two guesses at where the block ends, both checked by the
+         * symbol count of the segment (a segment that ends short of the block although lanes were taken for dead is
+         * done again without guessing):
+         *  - before the first scan: the bits per symbol of the block so far, a sixteenth more, and 1 024 bits; */
+        bool guessed = false;                                          /* (uniform) lanes may have been taken for dead */
+        if (end_bits && trust && produced != 0) {
+            const float est = (float)remaining * ((float)true_start / (float)produced);
+            const float lim_f = (float)first + est * 1.0625f + 1024.0f;
+            const uint32_t bound = lim_f < 4.0e9f ? (uint32_t)lim_f : 0xffffffffu;
+            if (!dead && hi - DFAST_SUB_BITS >= bound) dead = true;
+            guessed = (uint32_t)(THREADS - 1) * DFAST_SUB_BITS >= bound;
+        }
         uint32_t end = hi, cnt = 0;
         if (__ballot(!dead)) {
             if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
             else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
             if (dead) { end = hi; cnt = 0; }
         }
-        /* A caller that does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the
-         * stream) has no dead lanes by the test above, and the lanes behind the block's last symbol scan the next
-         * block's header and payload, round after round.  The speculative counts say where the block ends, a few
-         * symbols either way: a lane in front of which they already hold the rest of the block and a margin is taken
-         * for dead.  If that was wrong the segment ends short of the block, and the block goes to the exact decoder. */
-        bool assumed = false;
-        if (end_bits) {
+        /*  - after it: the speculative counts are right to a few symbols either way; a lane in front of which they
+         *    already hold the rest of the block and a margin is taken for dead. */
+        if (end_bits && trust) {
             uint32_t spec_total;
             const uint32_t exs = block_excl_scan_u32<THREADS>(cnt, sh.part, spec_total);
-            if (!dead && (uint64_t)exs >= (block_len - produced) + 128u + ((uint32_t)tid >> 2)) {
+            if (!dead && (uint64_t)exs >= remaining + 128u + ((uint32_t)tid >> 2)) {
                 dead = true;
-                assumed = true;
                 end = hi;
                 cnt = 0;
             }
+            guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
         }
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
@@ -453,14 +465,20 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         uint32_t seg_total;
         const uint32_t ex = block_excl_scan_u32<THREADS>(cnt, sh.part, seg_total);
         seg_total = uni32(seg_total);
-        const uint64_t remaining = block_len - produced;
+        if (guessed) DFAST_DBG(12, 1);
+        if (guessed && (uint64_t)seg_total < remaining) {             /* a guess that did not hold: the segment again, without */
+            DFAST_DBG(13, 1);
+            trust = false;
+            continue;
+        }
+        trust = true;
         const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
         uint32_t quota = 0;
         if (ex < take) {
             quota = take - ex;
             if (quota > cnt) quota = cnt;
         }
-        bool lane_ok = !(assumed && (uint64_t)seg_total < remaining);        /* (the block does not end where the counts said) */
+        bool lane_ok = true;
         if (quota) {
             const uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok);
 #ifdef DFAST_DEBUG

@@ -394,3 +394,40 @@ def test_runs_of_one_byte_inside_a_big_block(torch_mod, codec, run_kib, limit_ms
     print(f"\n  40 MiB block with runs of {run_kib} KiB: {ms:.2f} ms")
     if limit_ms is not None:
         assert ms < limit_ms, ms
+
+
+@pytest.mark.parametrize("blocksize", [64 << 10, 256 << 10, 1 << 20])
+def test_raw_stream_of_blocks_whose_bit_rate_changes(torch_mod, codec, blocksize):
+    """The raw-stream probe guesses where a block's payload ends from the bits per symbol of the block so far
+    (decode_fast.hpp): blocks that begin with cheap symbols and end with dear ones, and the other way round, and
+    blocks that end in a run - the guess fails or overshoots there, and the result must not depend on it."""
+    torch = torch_mod
+    nb = 96
+    n = nb * blocksize - 777
+    rng = np.random.default_rng(blocksize)
+    data = np.empty(n, np.uint8)
+    for b in range(nb):
+        lo, hi = b * blocksize, min((b + 1) * blocksize, n)
+        m = hi - lo
+        cut = int(m * rng.choice([0.3, 0.5, 0.75, 0.9]))
+        cheap = np.where(rng.random(m) < 0.93, 7, rng.integers(0, 256, m)).astype(np.uint8)
+        dear = rng.integers(0, 255, m).astype(np.uint8)
+        kind = b % 4
+        if kind == 0:
+            blk = np.concatenate([cheap[:cut], dear[cut:]])
+        elif kind == 1:
+            blk = np.concatenate([dear[:cut], cheap[cut:]])
+        elif kind == 2:
+            blk = np.concatenate([dear[:cut], np.full(m - cut, 7, np.uint8)])
+            blk[::97] = dear[::97]                       # (keep the tree an ordinary one)
+        else:
+            blk = np.concatenate([cheap[:cut // 2], dear[cut // 2:cut], cheap[cut:]])
+        data[lo:hi] = blk
+    d = dev(torch, data)
+    stream, offs, length = codec.encode(d, blocksize)
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    assert codec.decode_stream(stream, length, length, out, relaxed=True) == (0, n, length)
+    assert torch.equal(out[:n], d)
+    ref = torch.zeros_like(out)
+    assert codec.decode_stream(stream, length, length, ref, relaxed=True, sequential=True) == (0, n, length)
+    assert torch.equal(ref, out)

@@ -4,14 +4,30 @@ import torch
 from libhuffman_amd.codec import GpuCodec
 n, bs = 1 << 28, 65536
 c = GpuCodec(0)
-for wl in sys.argv[1:] or ["zipf255", "uniform256"]:
-    data = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(data, wl)
+raw = "--raw" in sys.argv          # through the raw-stream probe (decode_stream) instead of the indexed kernel
+for wl in [a for a in sys.argv[1:] if a != "--raw"] or ["zipf255", "uniform256"]:
+    if wl == "logtext":
+        from libhuffman_amd import datagen
+        tile = torch.from_numpy(datagen.logtext(16 << 20)).cuda()
+        data = tile.repeat(n // tile.numel())[:n].contiguous()
+    elif wl == "ratechange":        # every block: cheap symbols, then dear ones (or the other way round)
+        import numpy as np
+        rng = np.random.default_rng(1)
+        cheap = np.where(rng.random(n) < 0.93, 7, rng.integers(0, 256, n)).astype(np.uint8)
+        dear = rng.integers(0, 255, n).astype(np.uint8)
+        pos = np.arange(n) % bs
+        first = (np.arange(n) // bs) % 2 == 0
+        data = torch.from_numpy(np.where((pos < bs // 2) == first, cheap, dear)).cuda()
+    else:
+        data = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(data, wl)
     out, offs, length = c.encode(data, bs)
     back = torch.empty(n, dtype=torch.uint8, device="cuda"); nb = c.block_count(n, bs)
     arr = (C.c_ulonglong * 16)()
     c.lib.hufgpu_debug_dfast(arr, 1)
-    c.decode(out, length, offs, nb, back, relaxed=True)
+    if raw: c.decode_stream(out, length, length, back, relaxed=True)
+    else: c.decode(out, length, offs, nb, back, relaxed=True)
     c.lib.hufgpu_debug_dfast(arr, 0)
     a = list(arr)
     print(wl, "blocks", nb, "fail: exhausted", a[0], "rounds", a[1], "lane_ok", a[2], "take0", a[3], "| lanes !ok", a[4], "lanes exh", a[5],
-          "| scan calls/blk %.1f iters/call %.1f rounds/blk %.2f segments/blk %.2f" % (a[8] / nb, a[9] / max(a[8], 1), a[10] / nb, a[11] / nb), "equal", torch.equal(back, data))
+          "| scan calls/blk %.1f iters/call %.1f rounds/blk %.2f segments/blk %.2f" % (a[8] / nb, a[9] / max(a[8], 1), a[10] / nb, a[11] / nb),
+          "| segments with a guessed end", a[12], "done again", a[13], "equal", torch.equal(back, data))

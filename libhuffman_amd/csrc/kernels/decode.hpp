@@ -14,10 +14,9 @@ namespace hufgpu {
  * ==================================================================================== */
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p)
 {
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) v |= (uint64_t)p[k] << (8 * k);
-    return v;
+    /* (one 8-byte load: global loads need no alignment on gfx950, and the stream is little-endian like the device) */
+    typedef uint64_t __attribute__((aligned(1))) unaligned_u64;
+    return *reinterpret_cast<const unaligned_u64 *>(p);
 }
 
 /* first 10 bytes of a block header at stream + o0, by aligned 32-bit loads (the words that hold

@@ -111,10 +111,18 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
             /* almost no offset survives "the upper half of block_len is zero": that test is done
              * for all 16 offsets without a branch, everything else only for the survivors */
             uint32_t maybe = 0;
+            /* (four zero bytes in a row hold an aligned zero halfword, wherever they begin: bytes 4..22 of the
+             * window, words 1..5 - in a compressed stream one halfword in 65 536 is zero, and the sixteen tests
+             * below were most of the kernel's instructions) */
+            uint32_t zh = 0;
 #pragma unroll
-            for (int k = 0; k < DISC_PER; k++) {
-                const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
-                maybe |= (hi == 0u ? 1u : 0u) << k;                              /* block_len < 2^32 */
+            for (int d = 1; d <= 5; d++) zh |= (w[d] - 0x00010001u) & ~w[d] & 0x80008000u;
+            if (zh) {
+#pragma unroll
+                for (int k = 0; k < DISC_PER; k++) {
+                    const uint32_t hi = __funnelshift_r(w[(k + 4) >> 2], w[((k + 4) >> 2) + 1], 8 * ((k + 4) & 3));
+                    maybe |= (hi == 0u ? 1u : 0u) << k;                          /* block_len < 2^32 */
+                }
             }
             if (maybe) {                                    /* runs of zero bytes pass the first test everywhere: */
                 uint32_t nz = 0;                            /* block_len != 0, again for all offsets at once */

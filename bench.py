@@ -360,6 +360,21 @@ class Bench:
             codec.set_profiling(False)
             other_ms = p["decode"] / max(c, 1)
 
+        # ... and with no index at all (what huf_decode() gets: block discovery + probes), wall clock
+        # of the call, outside the timed region; reported with the index-free record only
+        raw_ms = None
+        if rank == 0 and not use_sub and not a.no_other_decode:
+            codec.decode_stream(out, comp_len, comp_len, back, relaxed=relaxed)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                raw_res = codec.decode_stream(out, comp_len, comp_len, back, relaxed=relaxed)
+            torch.cuda.synchronize()
+            raw_ms = (time.perf_counter() - t0) / 3 * 1e3
+            assert tuple(raw_res) == (0, n, comp_len), f"raw-stream decode returned {raw_res}"
+            if not a.no_verify:
+                assert torch.equal(back, data), "raw-stream decode differs from the input"
+
         rec = None
         if rank == 0:
             K = steps
@@ -423,6 +438,10 @@ class Bench:
                 "gpu_ms_per_step_rank0": round(gpu_ms, 4),
                 "profiled_steps": max(enc_calls, dec_calls),
             }
+            if raw_ms is not None:
+                rec["raw_stream_decode"] = {"ms": round(raw_ms, 4), "GiBps": round(n / GIB / (raw_ms / 1e3), 1),
+                                            "note": "no index at all (huf_decode's input): discovery + probes, wall clock of "
+                                                    "the call, outside the timed region"}
         del data, out, offs, back, sub
         torch.cuda.empty_cache()
         return rec
@@ -649,7 +668,8 @@ def main() -> None:
                 "roofline": {"kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
                              "achieved": r["roofline"]["achieved"], "traffic": r["roofline"]["traffic"],
                              "pipeline_frac": r["roofline"]["pipeline_frac"]},
-                "kernels": {k: v["avg_ms"] for k, v in r["kernels"].items()}}
+                "kernels": {k: v["avg_ms"] for k, v in r["kernels"].items()},
+                **({"raw_stream_decode": r["raw_stream_decode"]} if "raw_stream_decode" in r else {})}
             for w, r in sec_recs.items()}
         if root_rec is not None:
             result["root_placement"] = root_rec

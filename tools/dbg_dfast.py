@@ -1,3 +1,7 @@
+"""Counters of decode_fast.hpp's lean decoder (scan calls, rounds, segments, blocks handed to the exact decoder, guessed
+block ends in the raw-stream probe and how many of them had to be done again).  Needs a library built with the
+counters in:  HUF_LIB_PATH=$PWD/tools/_ablate/lib_dfastdbg.so HUF_EXTRA_FLAGS=-DDFAST_DEBUG python -m libhuffman_amd.build
+then          HUF_LIB_PATH=$PWD/tools/_ablate/lib_dfastdbg.so python tools/dbg_dfast.py [--raw] [zipf255 uniform256 logtext ratechange]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

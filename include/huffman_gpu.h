@@ -122,6 +122,12 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
                       const void *d_sub_index, void *d_out, uint64_t out_cap, uint32_t flags,
                       uint64_t *raw_len, void *stream);
 
+/* Of the last enqueued hufgpu_decode() / hufgpu_decode_sub(): blocks that went through a slower decoder -
+ * counters[0] = decoded again by the exact in-order-equivalent decoder (a damaged block, an unusual tree, a stale
+ * sub-index), counters[1] = handed on by the one-pass decoder of index-only streams (starts that did not settle).
+ * Results never depend on these; they say what a slow decode was slow for.  Synchronises the stream. */
+int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters);
+
 /* Synchronise and report the outcome of the last enqueued hufgpu_decode() / hufgpu_decode_sub(). */
 int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
 

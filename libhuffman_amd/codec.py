@@ -135,6 +135,12 @@ class GpuCodec:
         self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data", raw=int(raw.value))
         return int(raw.value)
 
+    def decode_counters(self):
+        """(blocks the exact decoder took, blocks the one-pass index-only decoder handed on) of the last decode."""
+        c = (C.c_uint32 * 2)()
+        self._check(self.lib.hufgpu_decode_counters(self._ctx, c), "counter readout failed")
+        return int(c[0]), int(c[1])
+
     def decode_stream(self, stream: torch.Tensor, avail: int, length: int, out: torch.Tensor,
                       relaxed: bool = False, sequential: bool = False):
         """Raw-stream decode (no index). Returns (err, bytes written, bytes consumed).

@@ -57,6 +57,7 @@ struct hufgpu_ctx {
     uint32_t *d_fix_count;        /* decode_sub_kernel: blocks its sub-index could not verify */
     uint32_t *d_fix_blocks;
     uint32_t *d_fix_flag;
+    uint32_t *d_lean_blocks;      /* decode_lean_kernel: blocks it leaves to decode_fast_list_kernel (their count: d_fix_count[1]) */
 
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
@@ -243,8 +244,8 @@ static void free_decode_ws(hufgpu_ctx *c)
     (void)hipFree(c->d_dmeta);
     (void)hipFree(c->d_out_offsets);
     (void)hipFree(c->d_status);
-    (void)hipFree(c->d_fix_count); (void)hipFree(c->d_fix_blocks); (void)hipFree(c->d_fix_flag);
-    c->d_fix_count = NULL; c->d_fix_blocks = NULL; c->d_fix_flag = NULL;
+    (void)hipFree(c->d_fix_count); (void)hipFree(c->d_fix_blocks); (void)hipFree(c->d_fix_flag); (void)hipFree(c->d_lean_blocks);
+    c->d_fix_count = NULL; c->d_fix_blocks = NULL; c->d_fix_flag = NULL; c->d_lean_blocks = NULL;
     c->d_dmeta = NULL; c->d_out_offsets = NULL; c->d_status = NULL;
     c->dws_blocks = 0;
 }
@@ -336,10 +337,11 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipMalloc((void **)&c->d_dmeta, cap * sizeof(HufDecodeMeta)));
     HIP_OK(c, hipMalloc((void **)&c->d_out_offsets, (cap + 1) * sizeof(uint64_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
-    HIP_OK(c, hipMalloc((void **)&c->d_fix_count, sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_fix_count, 2 * sizeof(uint32_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_fix_blocks, cap * sizeof(uint32_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_fix_flag, cap * sizeof(uint32_t)));
-    HIP_OK(c, hipMemset(c->d_fix_count, 0, sizeof(uint32_t)));
+    HIP_OK(c, hipMalloc((void **)&c->d_lean_blocks, cap * sizeof(uint32_t)));
+    HIP_OK(c, hipMemset(c->d_fix_count, 0, 2 * sizeof(uint32_t)));
     HIP_OK(c, hipMemset(c->d_fix_flag, 0, cap * sizeof(uint32_t)));
     int rc2 = alloc_two_level(c, &c->dec_lens, cap, true);
     if (rc2) return rc2;
@@ -643,6 +645,29 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     return err;
 }
 
+/* How many blocks of the last enqueued decode were handed on: counters[0] = to the exact decoder
+ * (decode_fix_kernel), counters[1] = by decode_lean_kernel to round 3's decoder.  Synchronises. */
+extern "C" int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters)
+{
+    if (!ctx || !counters) return HUFE_ARGUMENT;
+    counters[0] = counters[1] = 0;
+    if (!ctx->d_fix_count) return HUFE_OK;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_stream || ctx->decode_pending) HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
+    HIP_OK(ctx, hipMemcpy(counters, ctx->d_fix_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HUFE_OK;
+}
+
+/* (tooling) the first `cap` block numbers decode_lean_kernel handed on in the last decode */
+extern "C" int hufgpu_debug_lean_blocks(hufgpu_ctx_t *ctx, uint32_t *out, uint32_t cap)
+{
+    if (!ctx || !out || !ctx->d_lean_blocks) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipDeviceSynchronize());
+    HIP_OK(ctx, hipMemcpy(out, ctx->d_lean_blocks, cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HUFE_OK;
+}
+
 static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
                        const uint64_t *d_block_offsets, uint64_t nblocks, const HufSubIndex *sub, uint64_t blocksize,
                        void *d_out, uint64_t out_cap, uint32_t flags, uint64_t *raw_len, void *stream)
@@ -694,8 +719,20 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
             fix.count = ctx->d_fix_count;
             fix.blocks = ctx->d_fix_blocks;
             fix.flag = ctx->d_fix_flag;
-            decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
+            /* HUF_GPU_LEAN_DECODE=1: the one-pass decoder of kernels/decode_lean.hpp first (round 4's experiment: every
+             * symbol decoded once after a speculative run-in; bit-exact, but 2.1 ms per GiB where this path takes 1.6 -
+             * DESIGN.md 3.4 says why - so it is not the default) */
+            static const bool lean = getenv("HUF_GPU_LEAN_DECODE") && atoi(getenv("HUF_GPU_LEAN_DECODE")) != 0;
             const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+            if (lean) {
+                /* every symbol once (kernels/decode_lean.hpp); what that cannot settle goes through round 3's decoder */
+                LeanTodo todo;
+                todo.count = ctx->d_fix_count + 1;
+                todo.blocks = ctx->d_lean_blocks;
+                decode_lean_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, todo);
+                decode_fast_list_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix, todo.count, todo.blocks);
+            } else
+            decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
             decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
         }
     }
@@ -1192,6 +1229,18 @@ extern "C" int hufgpu_synchronize(hufgpu_ctx_t *ctx)
 }
 
 #ifdef DEC_PHASE_PROF
+/* diagnostic builds only: why decode_lean_kernel handed blocks on (kernels/decode_lean.hpp, LEAN_FAIL) */
+extern "C" int hufgpu_debug_lean_fail(hufgpu_ctx_t *ctx, unsigned long long *out16, int reset)
+{
+    if (!ctx || !out16) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipDeviceSynchronize());
+    HIP_OK(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(hufgpu::g_lean_fail), (reset & 2 ? 80 : 16) * sizeof(unsigned long long)));
+    if (reset & 1) {
+        unsigned long long z[80] = {0};
+        HIP_OK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(hufgpu::g_lean_fail), z, sizeof(z)));
+    }
+    return HUFE_OK;
+}
 /* diagnostic builds only: cycle sums of the decode phases (thread 0 of every workgroup) */
 extern "C" int hufgpu_debug_phase_cycles(hufgpu_ctx_t *ctx, unsigned long long *out16, int reset)
 {

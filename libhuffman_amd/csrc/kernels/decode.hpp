@@ -67,7 +67,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
     __shared__ uint64_t s_part[SCAN_GROUP / 64];
     __shared__ unsigned long long s_bad;
     if (threadIdx.x == 0) s_bad = ~0ull;
-    if (fix_count && blockIdx.x == 0 && threadIdx.x == 0) *fix_count = 0;   /* decode_sub_kernel's work list starts empty */
+    if (fix_count && blockIdx.x == 0 && threadIdx.x == 0) { fix_count[0] = 0; fix_count[1] = 0; }   /* the work lists of decode_sub / decode_lean start empty */
     const uint64_t b = (uint64_t)blockIdx.x * SCAN_GROUP + threadIdx.x;
     HufDecodeMeta m;
     m.block_len = 0;
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
 
 #ifdef DEC_PHASE_PROF
 __device__ unsigned long long g_dec_prof[16];
+__device__ unsigned long long g_lean_fail[16 + 64];     /* decode_lean_kernel: blocks handed on, by reason */
 #define DPROF_T() (__builtin_readcyclecounter())
 #define DPROF_ADD(slot, t0) do { if (threadIdx.x == 0) atomicAdd(&g_dec_prof[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
 #else
@@ -712,8 +713,8 @@ __device__ __forceinline__ void fill_bytes(uint8_t *dst, uint64_t n, uint32_t sy
  * waits for the other.  Only a payload with a set bit is read again for the bit's position; what
  * the fill wrote behind it is unspecified, as everywhere behind the end of a failed decode.
  * Aligned 16-byte loads: the chunks that hold a payload byte are readable (never across a page). */
-template <int THREADS, bool STORE>
-__device__ int decode_single_leaf(DecShared<THREADS> &sh, uint32_t symv, const uint8_t *pay, uint64_t block_len,
+template <int THREADS, bool STORE, class SH>
+__device__ int decode_single_leaf(SH &sh, uint32_t symv, const uint8_t *pay, uint64_t block_len,
                                   uint64_t pay_bytes, uint8_t *gout, uint64_t *end_bits, uint64_t *produced_out)
 {
     const int tid = (int)threadIdx.x;

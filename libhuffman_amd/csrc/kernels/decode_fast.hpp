@@ -499,20 +499,15 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     return ok;
 }
 
+/* One indexed block (the body of decode_fast_kernel and of decode_fast_list_kernel). */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kernel(
+__device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64_t blk,
     const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
     const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
     uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
     unsigned long long *__restrict__ result, DecFixList fix)
 {
-    __shared__ DecShared<THREADS> sh;
-#ifdef DFAST_LDS_PAD            /* (occupancy experiments: fewer workgroups per CU) */
-    __shared__ uint32_t lds_pad[DFAST_LDS_PAD / 4];
-    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
-#endif
     const int tid = (int)threadIdx.x;
-    const uint64_t blk = blockIdx.x;
     HufDecodeMeta m = dmeta[blk];
     m.block_len = uni64(m.block_len);
     m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
@@ -547,6 +542,38 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kerne
     }
     if (!good && tid == 0) {
         if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kernel(
+    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
+    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
+    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
+    unsigned long long *__restrict__ result, DecFixList fix)
+{
+    __shared__ DecShared<THREADS> sh;
+#ifdef DFAST_LDS_PAD            /* (occupancy experiments: fewer workgroups per CU) */
+    __shared__ uint32_t lds_pad[DFAST_LDS_PAD / 4];
+    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
+#endif
+    decode_fast_block<THREADS>(sh, blockIdx.x, stream, stream_len, offsets, dmeta, out_offsets, lens, out, out_cap, status, result, fix);
+}
+
+/* The blocks decode_lean_kernel (decode_lean.hpp) could not vouch for, with the decoder above: runs of one byte
+ * value, codes that never fall into step inside a run-in, trees that are not an encoder's. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_list_kernel(
+    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
+    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
+    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
+    unsigned long long *__restrict__ result, DecFixList fix, const uint32_t *__restrict__ todo_count, const uint32_t *__restrict__ todo_blocks)
+{
+    __shared__ DecShared<THREADS> sh;
+    const uint32_t n = uni32(*todo_count);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();                                               /* the previous block's readers of sh are done */
+        decode_fast_block<THREADS>(sh, (uint64_t)uni32(todo_blocks[i]), stream, stream_len, offsets, dmeta, out_offsets, lens, out, out_cap, status, result, fix);
     }
 }
 

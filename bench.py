@@ -99,25 +99,15 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
         t2 = time.perf_counter()
         assert err == 0 and back.size == sample_bytes
         t_enc, t_dec = t1 - t0, t2 - t1
-    # the same library on every host core: blocks are independent, so the sample is cut into one
-    # block-aligned slice per core and the slices are encoded / decoded concurrently (ctypes
-    # releases the GIL).  Reported beside the 1-thread figure, which stays the baseline `value`.
+    # the same library on every host core: one PROCESS per core (a child interpreter that never touches the GPU starts
+    # them), each with its own 8 MiB of the workload, all released together - see cpu_all_cores_child().
     all_cores = None
     if kind == "reference":
         try:
-            from concurrent.futures import ThreadPoolExecutor
-            ncpu = os.cpu_count() or 1
-            per = max(blocksize, (sample_bytes // ncpu) // blocksize * blocksize)
-            parts = [data[i:i + per] for i in range(0, sample_bytes, per)]
-            with ThreadPoolExecutor(ncpu) as ex:
-                t0 = time.perf_counter()
-                encs = list(ex.map(lambda part: ref.encode(part, blocksize), parts))
-                t1 = time.perf_counter()
-                backs = list(ex.map(lambda e: ref.decode(e, raw_hint=per + 64), encs))
-                t2 = time.perf_counter()
-            assert all(err == 0 for err, _ in backs) and sum(b.size for _, b in backs) == sample_bytes
-            all_cores = {"value": round(sample_bytes / GIB / (t2 - t0), 5), "unit": "GiB/s", "cores": ncpu,
-                         "threads": min(ncpu, len(parts))}
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores-child", workload, str(blocksize)],
+                               capture_output=True, text=True, timeout=180, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            all_cores = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:                                  # never fail the bench over the extra figure
             all_cores = {"error": repr(e)}
     return {"value": round(sample_bytes / GIB / (t_enc + t_dec), 5), "unit": "GiB/s", "cores": 1,
@@ -126,6 +116,63 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
                       f"encode {t_enc:.2f}s + decode {t_dec:.2f}s, memstreams, 1 thread",
             "encode_GiBps": round(sample_bytes / GIB / t_enc, 5),
             "decode_GiBps": round(sample_bytes / GIB / t_dec, 5)}
+
+
+def _all_cores_worker(workload, blocksize, per, idx, barrier, q):
+    """One core's share of the all-cores baseline: its own `per` bytes of the workload (seeded by the worker's number),
+    generated before the barrier; the reference's encode + decode timed behind it."""
+    try:
+        from libhuffman_amd import datagen
+        from oracle.oracle import Reference
+        gen = {"zipf255": lambda n: datagen.zipf255(n, 3 + idx), "uniform255": lambda n: datagen.uniform255(n, 2 + idx),
+               "uniform256": lambda n: datagen.uniform256(n, 1 + idx)}.get(workload, datagen.GENERATORS[workload])
+        data = gen(per)
+        ref = Reference()
+        ref.encode(data[:blocksize], blocksize)               # (library loaded, pages touched)
+        barrier.wait(timeout=120)
+        t0 = time.perf_counter()
+        enc = ref.encode(data, blocksize)
+        t1 = time.perf_counter()
+        ok = True
+        if workload != "uniform256":                          # (the reference cannot decode k = 256 blocks)
+            err, back = ref.decode(enc, raw_hint=per + 64)
+            ok = err == 0 and back.size == per
+        t2 = time.perf_counter()
+        q.put((idx, t0, t1, t2, ok))
+    except Exception as e:
+        q.put((idx, 0.0, 0.0, 0.0, repr(e)))
+
+
+def cpu_all_cores_child(workload: str, blocksize: int) -> None:
+    """`bench.py --cpu-all-cores-child W B` (started by cpu_baseline): the unmodified reference on EVERY host core at
+    once, one process per core, 8 MiB of the workload each (blocks are independent: what a host-side caller
+    with that many cores could do with libhuffman today).  Prints one JSON object: aggregate GiB/s = all bytes /
+    (last finish - first start)."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    per = max(blocksize, (8 << 20) // blocksize * blocksize)
+    ctx = mp.get_context("fork")
+    barrier, q = ctx.Barrier(ncpu), ctx.Queue()
+    procs = [ctx.Process(target=_all_cores_worker, args=(workload, blocksize, per, i, barrier, q)) for i in range(ncpu)]
+    for p_ in procs:
+        p_.start()
+    got = [q.get(timeout=170) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=10)
+    bad = [g for g in got if g[4] is not True]
+    if bad:
+        print(json.dumps({"error": "worker failed: %r" % (bad[0][4],)}))
+        return
+    start, mid, end = min(g[1] for g in got), max(g[2] for g in got), max(g[3] for g in got)
+    total = per * ncpu
+    print(json.dumps({"value": round(total / GIB / (end - start), 5), "unit": "GiB/s", "cores": ncpu, "processes": ncpu,
+                      "encode_GiBps": round(total / GIB / (mid - start), 5),
+                      "sample": f"{per >> 20} MiB of {workload} per process ({total >> 20} MiB), {blocksize >> 10} KiB blocks, "
+                                f"encode + decode {end - start:.2f}s, all processes released together"}))
+
+
+STAMP_SOURCE = ("profiles/traffic.json: TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled) "
+                "of this command, stamped for exactly these kernel sources by tools/gpu_round_profile.sh - not counted in this run")
 
 
 def kernel_source_digest() -> str:
@@ -156,8 +203,8 @@ def measured_traffic(workload: str, kernel: str, n: int, bs: int):
         return None
 
 
-def live_traffic(workload: str, kernel: str, passthrough=(), timeout: float = 120.0):
-    """HBM bytes per launch of `kernel` counted in THIS run: two child passes of this script under
+def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0):
+    """HBM bytes per launch of every kernel named in `kernels` counted in THIS run: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domain mixed in; FETCH_SIZE
     doubled: the gfx950 correction of MI355X_MICROARCH.md; KiB -> bytes).  None when rocprofv3 is not there, this
     process is itself being profiled, or a pass fails or takes too long - the stamp of profiles/traffic.json
@@ -185,16 +232,19 @@ def live_traffic(workload: str, kernel: str, passthrough=(), timeout: float = 12
                 files = glob.glob(os.path.join(d, ctr, "**", "*counter_collection.csv"), recursive=True)
                 if not files:
                     return None
-                total, launches = 0.0, set()
+                total, launches = {k: 0.0 for k in kernels}, {k: set() for k in kernels}
                 with open(files[0]) as f:
                     for row in csv.DictReader(f):
-                        if row["Counter_Name"] == ctr and kernel in row["Kernel_Name"]:
-                            total += float(row["Counter_Value"])
-                            launches.add(row["Dispatch_Id"])
-                if not launches:
-                    return None
-                got[ctr] = total / len(launches)
-        return round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+                        if row["Counter_Name"] != ctr:
+                            continue
+                        for k in kernels:
+                            if k in row["Kernel_Name"]:
+                                total[k] += float(row["Counter_Value"])
+                                launches[k].add(row["Dispatch_Id"])
+                got[ctr] = {k: total[k] / len(launches[k]) for k in kernels if launches[k]}
+        out = {k: round(got["FETCH_SIZE"][k] * 1024 * 2 + got["WRITE_SIZE"][k] * 1024)
+               for k in kernels if k in got["FETCH_SIZE"] and k in got["WRITE_SIZE"]}
+        return out or None
     except Exception:
         return None
 
@@ -236,25 +286,40 @@ class Bench:
         self.codec.fill(data, workload, first=first)
         return data
 
-    def copy_ceiling(self, n: int) -> float:
-        """GB/s of a plain device copy of n bytes (read n + write n) on this GPU, HIP events on the
-        current stream: the measured ceiling SURVEY 8d asks to be reported beside the 8 TB/s spec."""
+    def ceilings(self, n: int) -> dict:
+        """GB/s of the hand-written byte movers of kernels/fill.hpp (16 bytes per lane and access; hufgpu_calib_bandwidth)
+        over n bytes on this GPU: copy = read n + write n, read = n, write (fill) = n; the best workgroup shape / cache
+        policy of each, HIP events on the current stream.  What a kernel that only moves bytes reaches here - the
+        measured ceilings SURVEY 8d asks to be reported beside the 8 TB/s of the data sheet.  (torch's copy_ is timed
+        too: it is what rounds 1-3 called the copy ceiling.)"""
         torch = self.torch
         a = torch.empty(n, dtype=torch.uint8, device=self.dev)
         b = torch.empty(n, dtype=torch.uint8, device=self.dev)
         a.fill_(7)
-        for _ in range(2):
-            b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        reps = 5
-        for _ in range(reps):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
+
+        def timed(fn, reps=5):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 1e3 / reps
+
+        out = {}
+        for kind, moved in (("copy", 2.0 * n), ("read", 1.0 * n), ("fill", 1.0 * n)):
+            best, which = 0.0, -1
+            for v in range(self.codec.CALIB_VARIANTS):
+                gbs = moved / 1e9 / timed(lambda: self.codec.calib_bandwidth(kind, v, a, b, n))
+                if gbs > best:
+                    best, which = gbs, v
+            out[kind] = (best, which)
+        out["torch_copy"] = (2.0 * n / 1e9 / timed(lambda: b.copy_(a)), -1)
         del a, b
         torch.cuda.empty_cache()
-        return 2.0 * n * reps / 1e9 / (e0.elapsed_time(e1) / 1e3)
+        return out
 
     def run(self, workload: str, steps: int, warmup: int, decode: str = None, bytes_per_gpu: int = None,
             other_decode: bool = True) -> dict:
@@ -334,10 +399,22 @@ class Bench:
         dec_prof, dec_calls = codec.profile("decode")
         codec.set_profiling(False)
 
+        per_rank_ms, allgather_ms = None, None
         if self.use_dist:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            # every rank's own clock over the K steps (the value uses the slowest), and what the step's one collective -
+            # the all-gather of the compressed sizes - costs on its own (K of them back to back, after the timed region)
+            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank_ms = [round(float(t.item()) / steps * 1e3, 4) for t in every]
+            elapsed = max(float(t.item()) for t in every)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                dist.all_gather_into_tensor(sizes[0], snaps[0])
+            torch.cuda.synchronize()
+            allgather_ms = round((time.perf_counter() - t1) / steps * 1e3, 4)
 
         comp_len = int(offs[nb].item())
         bit_exact = None
@@ -438,6 +515,9 @@ class Bench:
                 "gpu_ms_per_step_rank0": round(gpu_ms, 4),
                 "profiled_steps": max(enc_calls, dec_calls),
             }
+            if per_rank_ms is not None:
+                rec["per_rank_ms_per_step"] = per_rank_ms
+                rec["size_allgather_ms"] = allgather_ms
             if raw_ms is not None:
                 rec["raw_stream_decode"] = {"ms": round(raw_ms, 4), "GiBps": round(n / GIB / (raw_ms / 1e3), 1),
                                             "note": "no index at all (huf_decode's input): discovery + probes, wall clock of "
@@ -513,6 +593,8 @@ class Bench:
             torch.cuda.synchronize()
             dist.barrier()
             total += time.perf_counter() - t0
+        legs_all = [None] * world
+        dist.all_gather_object(legs_all, {k: round(v / max(steps, 1) * 1e3, 3) for k, v in legs.items()})
         tmax = torch.tensor([total], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ok = True
@@ -524,6 +606,7 @@ class Bench:
         return {"value": round(n_total / GIB / sec, 3), "unit": "GiB/s", "ms_per_step": round(sec * 1e3, 3),
                 "steps": steps, "bit_exact_roundtrip": ok, "stream_bytes": int(sum(csizes)),
                 "legs_ms_rank0": {key: round(v / steps * 1e3, 3) for key, v in legs.items()},
+                "legs_ms_per_rank": legs_all,
                 "note": "input and output live on rank 0; every leg is synchronised (no overlap between legs)"}
 
 
@@ -578,6 +661,9 @@ def main() -> None:
     ap.add_argument("--no-python-layer", action="store_true", help="skip the huffmanfile (configs[4] shape) figure")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not count the longest kernel's HBM bytes with two rocprofv3 --pmc child passes (the stamp of profiles/traffic.json stays)")
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-all-cores-child":
+        cpu_all_cores_child(sys.argv[2], int(sys.argv[3]))
+        return
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -627,7 +713,8 @@ def main() -> None:
         if rank == 0:
             sec_recs["uniform256_16GiB"]["config"]["workload"] = \
                 "configs[3]: 16 GiB uniform-random bytes (uniform256 seed 1), blocksize=64KiB, sharded across 8 MI355X"
-    copy_gbs = bench.copy_ceiling(1 << 30) if rank == 0 else None
+    ceil = bench.ceilings(1 << 30) if rank == 0 else None
+    copy_gbs = ceil["copy"][0] if ceil else None
     # The scatter/gather form is an extra figure.  Every movement in it is waited for with a deadline
     # (BENCH_LEG_TIMEOUT), so a rank that fails alone shows as an exception here, not as a hang: the line is
     # then printed without the figure and the ranks leave without the final barrier.
@@ -667,6 +754,7 @@ def main() -> None:
                 "ratio": r["config"]["ratio"], "bit_exact_roundtrip": r["config"]["bit_exact_roundtrip"],
                 "roofline": {"kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
                              "achieved": r["roofline"]["achieved"], "traffic": r["roofline"]["traffic"],
+                             "traffic_source": (STAMP_SOURCE if r["roofline"]["traffic"] is not None else None),
                              "pipeline_frac": r["roofline"]["pipeline_frac"]},
                 "kernels": {k: v["avg_ms"] for k, v in r["kernels"].items()},
                 **({"raw_stream_decode": r["raw_stream_decode"]} if "raw_stream_decode" in r else {})}
@@ -675,18 +763,33 @@ def main() -> None:
             result["root_placement"] = root_rec
         if py_rec is not None:
             result["secondary"]["logtext_huffmanfile"] = py_rec
-        result["roofline"]["traffic_source"] = ("profiles/traffic.json: TCC counters of this command, collected for exactly these kernel sources"
-                                                if result["roofline"].get("traffic") is not None else None)
+        result["roofline"]["traffic_source"] = STAMP_SOURCE if result["roofline"].get("traffic") is not None else None
         if world == 1 and not args.no_live_traffic:
             same = ["--bytes-per-gpu", str(args.bytes_per_gpu), "--decode", args.decode]
             if args.blocksize is not None:
                 same += ["--blocksize", str(args.blocksize)]
-            lt = live_traffic(args.workload, result["roofline"]["kernel"], same)
+            live_src = ("counted in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes "
+                        "of this command (FETCH_SIZE doubled: gfx950)")
+            want = sorted({result["roofline"]["kernel"], "pack_kernel", "hist_lanes_kernel", "tree_wave_kernel"})
+            lt = live_traffic(args.workload, want, same)
+            if lt and result["roofline"]["kernel"] in lt:
+                result["roofline"]["traffic"] = lt[result["roofline"]["kernel"]]
+                result["roofline"]["traffic_source"] = live_src
             if lt:
-                result["roofline"]["traffic"] = lt
-                result["roofline"]["traffic_source"] = ("counted in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes "
-                                                        "of this command (FETCH_SIZE doubled: gfx950)")
+                result["kernel_traffic"] = {"bytes_per_launch": lt, "source": live_src}
+            # the index-alone decoder's kernel: one more pair of passes of the same command with --decode selfsync
+            if (args.workload + "_index_free") in sec_recs and args.decode == "sub":
+                same_idx = [x if x != args.decode else "selfsync" for x in same]
+                li = live_traffic(args.workload, ["decode_fast_kernel"], same_idx)
+                if li:
+                    result.setdefault("kernel_traffic", {"bytes_per_launch": {}, "source": live_src})["bytes_per_launch"].update(li)
         result["roofline"]["copy_ceiling_GBps"] = round(copy_gbs, 1)
+        result["roofline"]["read_ceiling_GBps"] = round(ceil["read"][0], 1)
+        result["roofline"]["write_ceiling_GBps"] = round(ceil["fill"][0], 1)
+        result["roofline"]["torch_copy_GBps"] = round(ceil["torch_copy"][0], 1)
+        result["roofline"]["ceiling_source"] = ("hufgpu_calib_bandwidth: hand-written 16-byte-per-lane copy / read / fill kernels "
+                                                "(kernels/fill.hpp), best of %d shapes each over 1 GiB: variants %d / %d / %d"
+                                                % (bench.codec.CALIB_VARIANTS, ceil["copy"][1], ceil["read"][1], ceil["fill"][1]))
         result["roofline"]["frac_of_copy_ceiling"] = round(result["roofline"]["achieved"] / copy_gbs, 4)
         if world > 1:
             result["multi_gpu_note"] = ("ranks are block-sharded; value = all ranks' bytes over the slowest rank's time; "
@@ -705,7 +808,7 @@ def main() -> None:
         # barrier and no teardown (both would wait for the missing ones)
         if rank == 0:
             print(json.dumps(result), flush=True)
-        os._exit(0)
+        os._exit(1)                                  # (the line is there, with the error inside root_placement; the job did not run clean)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -128,7 +128,10 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
  * Results never depend on these; they say what a slow decode was slow for.  Synchronises the stream. */
 int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters);
 
-/* Synchronise and report the outcome of the last enqueued hufgpu_decode() / hufgpu_decode_sub(). */
+/* Synchronise and report the outcome of the last enqueued hufgpu_decode() / hufgpu_decode_sub().
+ * LIFETIME: d_stream, d_block_offsets and d_out of the enqueued call must stay valid until this returns - when a block
+ * failed, this call reads the stream and the index once more and WRITES the failing block's symbols in front of the
+ * failure to d_out (what src/decoder.c:69-91 delivers).  After it has returned the library holds none of them. */
 int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len);
 
 /*
@@ -175,6 +178,13 @@ int hufgpu_memcpy_h2d(hufgpu_ctx_t *ctx, void *d_dst, const void *h_src, uint64_
 int hufgpu_memcpy_d2h(hufgpu_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int hufgpu_memcpy_d2d(hufgpu_ctx_t *ctx, void *d_dst, const void *d_src, uint64_t bytes);
 int hufgpu_synchronize(hufgpu_ctx_t *ctx);
+
+/* Bandwidth calibration: ONE launch of a hand-written kernel that only moves bytes, 16 bytes per lane and access
+ * (kernels/fill.hpp) - kind 0: copy d_a -> d_b, 1: read d_a, 2: fill d_b; variant 0 .. HUFGPU_CALIB_VARIANTS - 1 =
+ * workgroup shape and cache policy.  bytes: a multiple of 64 KiB; pointers 16-byte aligned.  bench.py times these
+ * for the ceilings it prints beside the roofline (what a kernel that reads N and writes N can reach on this part). */
+#define HUFGPU_CALIB_VARIANTS 8
+int hufgpu_calib_bandwidth(hufgpu_ctx_t *ctx, int kind, int variant, const void *d_a, void *d_b, uint64_t bytes, void *stream);
 
 /* Per-kernel timing. While enabled, every hufgpu_encode/hufgpu_decode call records HIP
  * events around each of its kernels on the stream it launches on (up to 256 calls are kept).

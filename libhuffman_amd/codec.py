@@ -40,6 +40,7 @@ class GpuCodec:
             raise HuffmanGpuError(err, "Failed to create the GPU codec context",
                                   self.lib.hufgpu_last_error(None).decode())
         self.tdev = torch.device("cuda", device)
+        self._pending_decode = None
 
     def close(self):
         if self._ctx:
@@ -127,13 +128,28 @@ class GpuCodec:
             err = self.lib.hufgpu_decode(self._ctx, stream.data_ptr(), stream_len, offsets.data_ptr(),
                                          nblocks, out.data_ptr(), out.numel(), flags,
                                          C.byref(raw) if sync else None, self._stream())
+        # an enqueued decode's buffers are read - and, after a failed block, written - by hufgpu_decode_result():
+        # they stay referenced until then (include/huffman_gpu.h)
+        self._pending_decode = None if sync else (stream, offsets, out, sub_index)
         self._check(err, "Failed to decode the data", raw=int(raw.value) if sync else None)
         return int(raw.value) if sync else None
 
     def decode_result(self) -> int:
         raw = C.c_uint64(0)
-        self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data", raw=int(raw.value))
+        try:
+            self._check(self.lib.hufgpu_decode_result(self._ctx, C.byref(raw)), "Failed to decode the data", raw=int(raw.value))
+        finally:
+            self._pending_decode = None
         return int(raw.value)
+
+    CALIB_VARIANTS = 8
+
+    def calib_bandwidth(self, kind: str, variant: int, a: torch.Tensor | None, b: torch.Tensor | None, nbytes: int):
+        """One launch of the bandwidth calibration kernel (kind: "copy" a -> b, "read" a, "fill" b)."""
+        k = {"copy": 0, "read": 1, "fill": 2}[kind]
+        self._check(self.lib.hufgpu_calib_bandwidth(self._ctx, k, variant, a.data_ptr() if a is not None else None,
+                                                    b.data_ptr() if b is not None else None, nbytes, self._stream()),
+                    "calibration launch failed")
 
     def decode_counters(self):
         """(blocks the exact decoder took, blocks the one-pass index-only decoder handed on) of the last decode."""

@@ -613,6 +613,8 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
     ctx->decode_pending = 0;
+    const uint8_t *last_st = ctx->last_st;
+    ctx->last_st = NULL;                           /* the caller's buffers are not looked at again after this call */
     const uint64_t failing = ctx->h_result[2];
     if (failing == ~0ull) {                        /* every block decoded */
         if (raw_len) *raw_len = ctx->h_result[1];
@@ -624,7 +626,7 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     HIP_OK(ctx, hipMemcpyAsync(&err, ctx->d_status + failing, sizeof(err), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipMemcpyAsync(&before, ctx->d_out_offsets + failing, sizeof(before), hipMemcpyDeviceToHost, ctx->last_stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
-    if ((err == HUFE_RW || err == HUFE_CORRUPTED) && ctx->last_st && failing < ctx->last_nblocks && before <= ctx->last_out_cap) {
+    if ((err == HUFE_RW || err == HUFE_CORRUPTED) && last_st && failing < ctx->last_nblocks && before <= ctx->last_out_cap) {
         /* src/decoder.c:69-91 delivers the symbols in front of the failure: the failing block once more by the
          * exact in-order decoder, its record [o0, o1) as the whole input (a walk that needs more fails like the
          * reference's reader at the end of its input) */
@@ -634,7 +636,7 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
         if (o[1] > ctx->last_stream_len) o[1] = ctx->last_stream_len;
         if (o[0] < o[1]) {
             uint64_t raw = 0, used = 0, gu = 0, gr = 0;
-            const int rc = decode_chain(ctx, ctx->last_st + o[0], o[1] - o[0], 1, ctx->last_out + before, ctx->last_out_cap - before,
+            const int rc = decode_chain(ctx, last_st + o[0], o[1] - o[0], 1, ctx->last_out + before, ctx->last_out_cap - before,
                                         ctx->last_max_tree, ctx->last_stream, &raw, &used, &gu, &gr);
             if (rc == err) before += raw;
         }
@@ -656,6 +658,39 @@ extern "C" int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters)
     if (ctx->last_stream || ctx->decode_pending) HIP_OK(ctx, hipStreamSynchronize(ctx->last_stream));
     HIP_OK(ctx, hipMemcpy(counters, ctx->d_fix_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return HUFE_OK;
+}
+
+/* Bandwidth calibration (include/huffman_gpu.h): one launch of a kernel that only moves bytes. */
+template <int KIND>
+static int calib_launch(int variant, const uint8_t *a, uint8_t *b, uint64_t bytes, uint32_t *flag, hipStream_t s)
+{
+#define CALIB_CASE(V, T, P, NTL, NTS) case V: calib_bw_kernel<T, P, KIND, NTL, NTS><<<dim3((unsigned)(bytes / P)), dim3(T), 0, s>>>(a, b, flag); return P;
+    switch (variant) {
+        CALIB_CASE(0, 256, 16384, true, true)
+        CALIB_CASE(1, 256, 16384, true, false)
+        CALIB_CASE(2, 256, 16384, false, false)
+        CALIB_CASE(3, 512, 65536, true, true)
+        CALIB_CASE(4, 512, 65536, true, false)
+        CALIB_CASE(5, 256, 4096, true, true)
+        CALIB_CASE(6, 256, 4096, false, false)
+        CALIB_CASE(7, 1024, 65536, true, true)
+    }
+#undef CALIB_CASE
+    return 0;
+}
+extern "C" int hufgpu_calib_bandwidth(hufgpu_ctx_t *ctx, int kind, int variant, const void *d_a, void *d_b, uint64_t bytes, void *stream)
+{
+    if (!ctx || kind < 0 || kind > 2 || variant < 0 || variant >= HUFGPU_CALIB_VARIANTS) return HUFE_ARGUMENT;
+    if ((kind != 2 && !d_a) || (kind != 1 && !d_b) || bytes == 0 || (bytes & 65535u) || (((uintptr_t)d_a | (uintptr_t)d_b) & 15u)) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    uint32_t *flag = (uint32_t *)ctx->d_result;          /* (a word nobody reads: the read-only kernel's "result") */
+    int per = 0;
+    if (kind == 0) per = calib_launch<0>(variant, (const uint8_t *)d_a, (uint8_t *)d_b, bytes, flag + 6, s);
+    else if (kind == 1) per = calib_launch<1>(variant, (const uint8_t *)d_a, (uint8_t *)d_b, bytes, flag + 6, s);
+    else per = calib_launch<2>(variant, (const uint8_t *)d_a, (uint8_t *)d_b, bytes, flag + 6, s);
+    HIP_OK(ctx, hipGetLastError());
+    return per ? HUFE_OK : HUFE_ARGUMENT;
 }
 
 /* (tooling) the first `cap` block numbers decode_lean_kernel handed on in the last decode */

@@ -43,6 +43,9 @@ namespace hufgpu {
                                                        rescans as long as its slowest lane - zipf255 1.87 -> 2.12 ms; codes of one length,
                                                        uniform bytes, never fall into step at all) */
 #define DFAST_MAX_ROUNDS 64
+#ifndef DFAST_PRE
+#define DFAST_PRE 0u                                 /* bits in front of a share its lane walks before the first scan (0: none) */
+#endif
 
 template <int THREADS>
 struct DfastLds {
@@ -417,6 +420,21 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             guessed = (uint32_t)(THREADS - 1) * DFAST_SUB_BITS >= bound;
         }
         uint32_t end = hi, cnt = 0;
+#if DFAST_PRE
+        /* Round 4: the speculation begins DFAST_PRE bits in FRONT of the share (its left neighbour's last bits): a lane
+         * that walks those first stands on a codeword start of the real track when it reaches its own share in 99 % of
+         * all cases (tools/sim/sim_sync.py), where the share's own first bit is one in 13 %; the second scan below - a
+         * whole scan for every wave that holds ONE lane whose start moved - is then the exception. */
+        if (__ballot(!dead && tid != 0)) {
+            const uint32_t lo = hi - DFAST_SUB_BITS;
+            const uint32_t from = (lo >= first + DFAST_PRE) ? lo - DFAST_PRE : first;
+            const bool walk = !dead && tid != 0;
+            uint32_t e0 = lo, c0 = 0;
+            if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, walk ? from : lo, lo, lim, &e0, &c0);
+            else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, walk ? from : lo, lo, lim, &e0, &c0);
+            if (walk && e0 < hi) start = e0;
+        }
+#endif
         if (__ballot(!dead)) {
             if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
             else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);

@@ -43,4 +43,36 @@ __global__ void fill_kernel(uint8_t *__restrict__ out, uint64_t n, int kind, uin
     }
 }
 
+/* ======================================================================================
+ * Bandwidth calibration (bench.py's ceilings; tools/calib): what a kernel that does nothing but move bytes reaches
+ * on this part - 16 bytes per lane and access, every workgroup a contiguous piece, grid = bytes / PER_WG.
+ * KIND 0: copy (read a, write b), 1: read a only (the OR of everything decides one store nobody takes), 2: fill b.
+ * NTL / NTS: non-temporal loads / stores.
+ * ==================================================================================== */
+template <int THREADS, int PER_WG, int KIND, bool NTL, bool NTS>
+__global__ __launch_bounds__(THREADS) void calib_bw_kernel(const uint8_t *__restrict__ a, uint8_t *__restrict__ b, uint32_t *__restrict__ flag)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr int ITERS = PER_WG / 16 / THREADS;
+    const v4u *src = reinterpret_cast<const v4u *>(a + (uint64_t)blockIdx.x * PER_WG) + threadIdx.x;
+    v4u *dst = reinterpret_cast<v4u *>(b + (uint64_t)blockIdx.x * PER_WG) + threadIdx.x;
+    v4u acc = {0, 0, 0, 0};
+    v4u v[ITERS > 8 ? 8 : ITERS];
+#pragma unroll 1
+    for (int i0 = 0; i0 < ITERS; i0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8 && i0 + i < ITERS; i++) {
+            if (KIND == 2) v[i] = v4u{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+            else v[i] = NTL ? __builtin_nontemporal_load(src + (i0 + i) * THREADS) : src[(i0 + i) * THREADS];
+        }
+#pragma unroll
+        for (int i = 0; i < 8 && i0 + i < ITERS; i++) {
+            if (KIND == 1) acc |= v[i];
+            else if (NTS) __builtin_nontemporal_store(v[i], dst + (i0 + i) * THREADS);
+            else dst[(i0 + i) * THREADS] = v[i];
+        }
+    }
+    if (KIND == 1 && (acc.x | acc.y | acc.z | acc.w) == 0x12345678u) flag[0] = 1;
+}
+
 }  // namespace hufgpu

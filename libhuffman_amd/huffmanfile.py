@@ -217,8 +217,9 @@ class HuffmanCompressor:
             # straight into the result: header + tree are at most 2 060 bytes a block, a code at most 9 bits on
             # average (8 + the wrap root's) - the bound the device path allocates by, and then some
             nblocks = (n + self._blocksize - 1) // self._blocksize
-            src, sink = _WrappedBytes(data), _BytesSink(n + n // 8 + 2064 * nblocks + 4096)
+            src, sink = _WrappedBytes(data), None
             try:
+                sink = _BytesSink(n + n // 8 + 2064 * nblocks + 4096)       # (inside the try: a MemoryError here must not leak src)
                 cfg = N.Config(n, self._blocksize, 0, 0, src.handle, sink.handle)
                 err = self._lib.huf_encode(C.byref(cfg))
                 if err == N.HUF_ERROR_SUCCESS:
@@ -227,7 +228,8 @@ class HuffmanCompressor:
                     _check(err, "Failed to encode the data")
             finally:
                 src.close()
-                sink.close()
+                if sink is not None:
+                    sink.close()
         src, dst = _WrappedBytes(data), _MemStream(n + n // 8 + 4096)
         try:
             cfg = N.Config(n, self._blocksize, 0, 0, src.handle, dst.handle)
@@ -287,8 +289,11 @@ class HuffmanDecompressor:
             # byte - does not fit, and the growable stream below takes the call)
             # (a stream that begins with a one-symbol block - tree_len 5: one bit a symbol - may be all of them)
             room = 9 * n + 4096 if n >= 10 and view[8] == 5 and view[9] == 0 else 4 * n
-            src, sink = _WrappedBytes(view), _BytesSink(max(self._memlimit, room))
+            # (a stream that expands more than that is decoded a SECOND time below, through the growable stream: the
+            #  price of a result that is written in place when it fits)
+            src, sink = _WrappedBytes(view), None
             try:
+                sink = _BytesSink(max(self._memlimit, room))
                 cfg = N.Config(n, 0, 0, 0, src.handle, sink.handle)
                 err = self._lib.huf_decode(C.byref(cfg))
                 if err == N.HUF_ERROR_SUCCESS:
@@ -297,7 +302,8 @@ class HuffmanDecompressor:
                     _check(err, "Failed to decode the data")
             finally:
                 src.close()
-                sink.close()
+                if sink is not None:
+                    sink.close()
         src, dst = _WrappedBytes(view), _MemStream(max(self._memlimit, 4 * n))
         try:
             cfg = N.Config(n, 0, 0, 0, src.handle, dst.handle)
@@ -423,6 +429,7 @@ class HuffmanFile(io.BufferedIOBase):
 
     # -- I/O --------------------------------------------------------------------------------
     READ_PIECE = 32 << 20          # compressed bytes taken from the file per round
+    MAX_READ = 64 << 20            # ... and at most per read, whatever a block header claims
 
     def _fill(self, want: int) -> None:
         """Decode rounds of READ_PIECE compressed bytes until `want` plain bytes are buffered (want <
@@ -458,7 +465,9 @@ class HuffmanFile(io.BufferedIOBase):
             if need > len(buf):
                 # the first block cannot be complete yet: no decode attempt, read on
                 self._rest = bytes(buf)
-                next_read = max(self.READ_PIECE, need - len(buf), len(buf))
+                # (`need` comes from the block's header, which nobody has checked yet: a damaged length field must not
+                #  become one read - and one allocation - of that size; the reads grow geometrically instead)
+                next_read = max(self.READ_PIECE, min(need - len(buf), self.MAX_READ), min(len(buf), self.MAX_READ))
                 continue
             try:
                 plain, used = self._decompressor.decompress_blocks(buf)

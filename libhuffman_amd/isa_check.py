@@ -59,6 +59,9 @@ def kernel_resources(asm: str) -> dict:
             "sgprs": field("next_free_sgpr"),
             "lds": field("group_segment_fixed_size"),
             "scratch": field("private_segment_fixed_size"),
+            # gfx90a and later: architectural VGPRs in front of the AGPRs of the unified file (a multiple of 4;
+            # equal to the VGPR count, rounded up, when the kernel has no AGPRs)
+            "accum_offset": field("accum_offset", 0),
         }
     return res
 
@@ -71,13 +74,22 @@ def last_vgpr_shift_hazards(asm: str) -> list:
     callee_lines = [ln for name, body in funcs.items() if name not in kernels for ln in body]
     out = []
     for name, r in kernels.items():
-        if r["vgprs"] == 0 or r["vgprs"] != r["allocated"]:
-            continue                        # at least one allocated register above the highest used one
-        top = r["allocated"] - 1
-        pat = re.compile(r"^\s*(%s)(_e64)?\s+v\[\d+:\d+\],\s*v%d\s*," % ("|".join(SHIFT64), top))
-        hits = [ln.strip() for ln in funcs.get(name, []) + callee_lines if pat.match(ln)]
-        if hits:
-            out.append((name, "v%d" % top, hits))
+        if r["vgprs"] == 0:
+            continue
+        tops = []
+        if r["vgprs"] == r["allocated"]:
+            tops.append(r["allocated"] - 1)     # (otherwise: at least one allocated register above the highest used one)
+        # A kernel with AGPRs (accum_offset < next_free_vgpr): the probe was run on kernels without them, so which
+        # register the hardware takes for "the last one" there is not known - the top ARCHITECTURAL register is
+        # checked as well.
+        acc = r.get("accum_offset", 0)
+        if acc and acc < r["vgprs"] and acc - 1 not in tops:
+            tops.append(acc - 1)
+        for top in tops:
+            pat = re.compile(r"^\s*(%s)(_e64)?\s+v\[\d+:\d+\],\s*v%d\s*," % ("|".join(SHIFT64), top))
+            hits = [ln.strip() for ln in funcs.get(name, []) + callee_lines if pat.match(ln)]
+            if hits:
+                out.append((name, "v%d" % top, hits))
     return out
 
 

@@ -28,8 +28,10 @@ def _all_to_all(out, inp, out_split, in_split, group, timeout: Optional[float]):
         return
     work = dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=group,
                                   async_op=True)
-    if work.wait(timeout=timedelta(seconds=timeout)) is False:
-        raise TimeoutError("variable-size all-to-all did not complete in %.0f s" % timeout)
+    try:
+        work.wait(timeout=timedelta(seconds=timeout))          # (the backends raise when the time is up; they do not return False)
+    except RuntimeError as e:                                  # torch.distributed.DistBackendError is a RuntimeError
+        raise TimeoutError("variable-size all-to-all did not complete in %.0f s: %s" % (timeout, e)) from e
 
 
 def shard_range(n_total: int, blocksize: int, rank: int, world: int) -> Tuple[int, int]:

@@ -58,11 +58,11 @@ def test_the_digest_covers_every_kernel_source():
 
 def test_no_counter_passes_without_a_profiler_or_under_one(clean_env, tmp_path):
     clean_env.setenv("PATH", str(tmp_path))                       # no rocprofv3 there
-    assert bench.live_traffic("zipf255", "decode_sub_kernel") is None
+    assert bench.live_traffic("zipf255", ["decode_sub_kernel"]) is None
     clean_env.setenv("PATH", fake_profiler(tmp_path, "sys.exit(3)\n") + os.pathsep + os.environ["PATH"])
-    assert bench.live_traffic("zipf255", "decode_sub_kernel") is None             # a pass that fails
+    assert bench.live_traffic("zipf255", ["decode_sub_kernel"]) is None           # a pass that fails
     clean_env.setenv("ROCP_TOOL_LIBRARIES", "librocprofiler-sdk-tool.so")
-    assert bench.live_traffic("zipf255", "decode_sub_kernel") is None             # this process is being profiled
+    assert bench.live_traffic("zipf255", ["decode_sub_kernel"]) is None           # this process is being profiled
 
 
 def test_counter_passes_are_read_per_launch_of_the_named_kernel(clean_env, tmp_path):
@@ -79,6 +79,9 @@ def test_counter_passes_are_read_per_launch_of_the_named_kernel(clean_env, tmp_p
         "rows.append('11,\"void hufgpu::pack_kernel<256, true>(unsigned char const*)\",%s,99999' % ctr)\n"
         "open(os.path.join(out, name + '_counter_collection.csv'), 'w').write('\\n'.join(rows) + '\\n')\n")
     clean_env.setenv("PATH", fake_profiler(tmp_path, body) + os.pathsep + os.environ["PATH"])
-    got = bench.live_traffic("zipf255", "decode_sub_kernel", ["--bytes-per-gpu", str(1 << 28)])
-    assert got == 1000 * 1024 * 2 + 500 * 1024
-    assert bench.live_traffic("zipf255", "no_such_kernel") is None
+    got = bench.live_traffic("zipf255", ["decode_sub_kernel"], ["--bytes-per-gpu", str(1 << 28)])
+    assert got == {"decode_sub_kernel": 1000 * 1024 * 2 + 500 * 1024}
+    # several kernels out of the same two passes (round 4: pack_kernel and decode_fast_kernel are counted too)
+    got = bench.live_traffic("zipf255", ["decode_sub_kernel", "pack_kernel", "no_such_kernel"], ["--bytes-per-gpu", str(1 << 28)])
+    assert got == {"decode_sub_kernel": 1000 * 1024 * 2 + 500 * 1024, "pack_kernel": 99999 * 1024 * 3}
+    assert bench.live_traffic("zipf255", ["no_such_kernel"]) is None

@@ -2,7 +2,8 @@
 blocks of many MiB - the reference's default blocksize = 0 makes the whole input ONE block
 (src/encoder.c:163-165).  The library builds a sub-index for such a block on the device
 (kernels/spec_index.hpp) and decodes it chunk by chunk; every result is compared with the input, the
-error cases with the in-order decoder of the same library (which the other tests pin to the oracle)."""
+error cases with the CPU oracle (error code, bytes delivered, the bytes themselves) and with the in-order
+decoder of the same library."""
 import time
 
 import numpy as np
@@ -100,7 +101,20 @@ def test_several_big_blocks_then_small(torch_mod, codec):
     assert torch.equal(out[:2 * bs], d[:2 * bs])
 
 
-def test_damaged_big_blocks_match_the_in_order_decoder(torch_mod, codec):
+def oracle_agrees(oracle, stream_dev, avail, ln, got, out_dev, relaxed=False):
+    """(err, raw, used) and the delivered bytes of a decode_stream() call against oracle.decode() on the same bytes
+    (src/decoder.c:34-96, 201-287 restated on the CPU): the error code, the number of bytes delivered, the bytes."""
+    host = stream_dev[:avail].cpu().numpy()
+    oerr, oout, oused = oracle.decode(host, out_dev.numel(), 1025 if relaxed else 1024, length=ln)
+    assert oerr != 1, "the oracle's buffer is as large as the device's"
+    assert got[0] == oerr, (got, oerr, oout.size, oused)
+    assert got[1] == oout.size, (got, oerr, oout.size, oused)
+    assert np.array_equal(out_dev[:got[1]].cpu().numpy(), oout)
+    if oerr == 0:
+        assert got[2] == oused, (got, oused)
+
+
+def test_damaged_big_blocks_match_the_in_order_decoder(torch_mod, codec, oracle):
     torch = torch_mod
     bs = 5 << 20
     data = dev(torch, np.concatenate([datagen.zipf255(bs), datagen.zipf255(bs)[::-1], datagen.zipf255(bs // 2)]))
@@ -116,6 +130,7 @@ def test_damaged_big_blocks_match_the_in_order_decoder(torch_mod, codec):
         assert a == b, (a, b)
         n = a[1]
         assert torch.equal(out[:n], ref_out[:n])
+        oracle_agrees(oracle, s, avail, ln, a, out)             # ... and both are the reference's outcome
         return a
 
     # payload damage in the middle of the second block: zipf255's tree is full, so the bits still
@@ -247,7 +262,7 @@ def test_one_block_of_3_5_gib(torch_mod, codec):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_fuzz_big_blocks_against_the_in_order_decoder(torch_mod, codec, seed):
+def test_fuzz_big_blocks_against_the_in_order_decoder(torch_mod, codec, oracle, seed):
     """random alphabets, skews and block sizes around 4-7 MiB; each stream also with random damage
     (bit flips anywhere, truncation): the parallel path (device-built sub-index) and the in-order
     decoder must agree on the error, the bytes written, the bytes consumed and the output"""
@@ -287,6 +302,8 @@ def test_fuzz_big_blocks_against_the_in_order_decoder(torch_mod, codec, seed):
             b = codec.decode_stream(bad, avail, avail, ref.zero_(), relaxed=True, sequential=True)
             assert a == b, (seed, case, trial, kind, k, skew, bs, a, b)
             assert torch.equal(out[:a[1]], ref[:a[1]]), (seed, case, trial, kind)
+            if trial < 2:                                   # (the CPU oracle takes a second per stream: two of the four)
+                oracle_agrees(oracle, bad, avail, avail, a, out, relaxed=True)
 
 
 def test_blocks_beyond_4_gib(torch_mod, codec):
@@ -363,6 +380,29 @@ def test_one_call_fans_out_over_free_sessions(torch_mod, bs):
     import re
     m = re.search(r"fanout_encodes=(\d+) fanout_decodes=(\d+)", r.stdout)
     assert m and int(m.group(1)) == 4 and int(m.group(2)) == 4, r.stdout
+
+
+def test_huffmanfile_over_several_sessions(torch_mod):
+    """BASELINE configs[4]'s route on what one box has: 160 MiB of log text in 1 MiB blocks through
+    huffmanfile.compress() / decompress() (the reference's huffmanfile.py:294-342, 385-417) with three device sessions
+    configured - ONE call of either is dealt out over them.  Stream = the oracle's, round trip = the input, and
+    huf_gpu_fanouts() counts both directions."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HUF_GPU_DEVICES"] = "0,0,0"
+    env["HUF_GPU_BATCH_MB"] = "16"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fanout_huffmanfile_child.py"), root, "160"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    print("\n  " + r.stdout.strip().replace("\n", "\n  "))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sessions live=3 configured=3" in r.stdout, r.stdout
+    assert "stream_is_oracles=True roundtrip=True" in r.stdout and "incremental_equals_one_shot=True" in r.stdout, r.stdout
+    m = re.search(r"fanout_encodes=(\d+) fanout_decodes=(\d+)", r.stdout)
+    assert m and int(m.group(1)) >= 1 and int(m.group(2)) >= 1, r.stdout
 
 
 @pytest.mark.parametrize("run_kib,limit_ms", [(2, 10.0), (24, 25.0), (300, 200.0), (2048, 4000.0)])

@@ -55,7 +55,19 @@ def test_a_called_function_counts_for_the_kernel():
 
 def test_resources_are_read_from_the_kernel_descriptor():
     r = isa_check.kernel_resources(kernel_asm("k", 75, ""))["k"]
-    assert r == {"vgprs": 75, "allocated": 80, "sgprs": 20, "lds": 1024, "scratch": 0}
+    assert r == {"vgprs": 75, "allocated": 80, "sgprs": 20, "lds": 1024, "scratch": 0, "accum_offset": 0}
+
+
+def test_a_kernel_with_agprs_has_its_top_architectural_register_checked():
+    """with AGPRs behind the architectural registers (accum_offset < next_free_vgpr) the guard must
+    not depend on next_free_vgpr alone"""
+    shift = "\tv_lshlrev_b64 v[24:25], v63, v[24:25]"
+    with_agprs = kernel_asm("ka", 75, shift).replace(".amdhsa_next_free_sgpr 20", ".amdhsa_next_free_sgpr 20\n\t\t.amdhsa_accum_offset 64")
+    (name, top, hits), = isa_check.last_vgpr_shift_hazards(with_agprs)
+    assert (name, top) == ("ka", "v63")
+    # no AGPRs (accum_offset at or above the VGPR count): only the last allocated register counts
+    without = kernel_asm("kb", 75, shift).replace(".amdhsa_next_free_sgpr 20", ".amdhsa_next_free_sgpr 20\n\t\t.amdhsa_accum_offset 76")
+    assert not isa_check.last_vgpr_shift_hazards(without)
 
 
 @pytest.fixture(scope="module")

@@ -610,6 +610,67 @@ class Bench:
                 "note": "input and output live on rank 0; every leg is synchronised (no overlap between legs)"}
 
 
+C_API_SIZES = (10, 4 << 10, 64 << 10, 1 << 20, 64 << 20, 1 << 30)
+
+
+def c_api_by_size(lib, sizes, blocksize: int, budget_s: float = 6.0, relaxed_setter=None) -> dict:
+    """huf_encode() + huf_decode() on huf_memopen streams (the drop-in boundary itself: host bytes in, host bytes out,
+    PCIe included) for inputs of `sizes` bytes of zipf255 - microseconds per call and GiB/s of the pair.  `lib` is any
+    library with libhuffman's ABI (include/huffman.h): this build's, or - in the cpu_baseline leg - the unmodified
+    reference's (oracle/_ref), which is why the streams are driven through ctypes here and not through a wrapper."""
+    import ctypes as C
+    import numpy as np
+    from libhuffman_amd import _native as N, datagen
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    lib.huf_memopen.argtypes = [C.POINTER(C.POINTER(N.ReadWriter)), C.POINTER(C.c_void_p), C.c_size_t]
+    lib.huf_memclose.argtypes = [C.POINTER(C.POINTER(N.ReadWriter))]
+    lib.huf_memlen.argtypes = [C.POINTER(N.ReadWriter), C.POINTER(C.c_size_t)]
+    lib.huf_encode.argtypes = [C.POINTER(N.Config)]
+    lib.huf_decode.argtypes = [C.POINTER(N.Config)]
+    tile = datagen.zipf255(min(max(sizes), 16 << 20))
+    out = {}
+    for n in sizes:
+        data = tile[:n] if n <= tile.size else np.tile(tile, (n + tile.size - 1) // tile.size)[:n]
+        data = np.ascontiguousarray(data)
+        t_enc = t_dec = 0.0
+        calls, ok = 0, True
+        while calls < 3 or (t_enc + t_dec < budget_s / len(sizes) and calls < 2000):
+            rin, rout, rback = C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)()
+            bin_, bout, bback = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            assert lib.huf_memopen(C.byref(rin), C.byref(bin_), max(n, 1)) == 0
+            assert lib.huf_memopen(C.byref(rout), C.byref(bout), max(n + n // 4, 4096)) == 0
+            assert lib.huf_memopen(C.byref(rback), C.byref(bback), max(n, 1)) == 0
+            assert rin.contents.write(rin.contents.stream, data.ctypes.data_as(C.c_void_p), n) == 0
+            cfg = N.Config(n, blocksize, 0, 0, rin, rout)
+            t0 = time.perf_counter()
+            e1 = lib.huf_encode(C.byref(cfg))
+            t1 = time.perf_counter()
+            m = C.c_size_t()
+            lib.huf_memlen(rout, C.byref(m))
+            dcfg = N.Config(m.value, 0, 0, 0, rout, rback)
+            t2 = time.perf_counter()
+            e2 = lib.huf_decode(C.byref(dcfg))
+            t3 = time.perf_counter()
+            lib.huf_memlen(rback, C.byref(m))
+            good = e1 == 0 and e2 == 0 and m.value == n and C.string_at(bback.value, min(n, 4096)) == data[:4096].tobytes()
+            for r in (rin, rout, rback):
+                lib.huf_memclose(C.byref(r))
+            for b in (bin_, bout, bback):
+                libc.free(b)
+            if calls >= 1 or n >= (64 << 20):          # (the first call of a size warms buffers and pages: not counted below 64 MiB)
+                t_enc += t1 - t0
+                t_dec += t3 - t2
+            ok = ok and good
+            calls += 1
+            if n >= (64 << 20) and calls >= 2:
+                break
+        timed = calls if n >= (64 << 20) else calls - 1
+        out[str(n)] = {"encode_us": round(t_enc / timed * 1e6, 1), "decode_us": round(t_dec / timed * 1e6, 1),
+                       "GiBps": round(n * timed / GIB / (t_enc + t_dec), 5), "calls": timed, "roundtrip_ok": bool(ok)}
+    return out
+
+
 def huffmanfile_layer(n: int, blocksize: int, reps: int = 2) -> dict:
     """BASELINE.json configs[4]'s shape on this GPU: synthetic log text through the Python layer
     (libhuffman_amd.huffmanfile.compress / decompress = huf_encode / huf_decode behind memstreams), host
@@ -724,12 +785,40 @@ def main() -> None:
             root_rec = bench.root_placement(args.workload, max(2, min(args.steps, 5)))
         except Exception as e:                      # the extra figure never takes the headline down with it
             root_rec, root_ok = {"error": repr(e)}, False
-    py_rec = None
-    if rank == 0 and not args.no_python_layer:
+    def host_legs():
+        """the two figures through the host API (rank 0 only): the Python layer on configs[4]'s shape and the C API by
+        input size.  With more than one rank they run AFTER the other ranks have left, over every GPU of the node
+        (HUF_GPU_DEVICES=all: one huffmanfile call dealt out over the sessions - configs[4]'s stated route)."""
+        py, capi = None, None
+        if args.no_python_layer:
+            return py, capi
         try:
-            py_rec = huffmanfile_layer(1 << 30, 1 << 20)
+            n_py = 1 << 30
+            if world > 1:
+                os.environ["HUF_GPU_DEVICES"] = "all"        # (read when the host API opens its first session: not before this)
+                n_py = min(world, 4) << 30
+            py = huffmanfile_layer(n_py, 1 << 20)
+            if world > 1:
+                import ctypes as C
+                from libhuffman_amd import _native as N
+                fe, fd, conf = C.c_int(0), C.c_int(0), C.c_int(0)
+                N.load().huf_gpu_fanouts(C.byref(fe), C.byref(fd))
+                live = N.load().huf_gpu_sessions(C.byref(conf))
+                py["sessions"] = {"configured": conf.value, "live": live, "fanout_encodes": fe.value, "fanout_decodes": fd.value}
         except Exception as e:
-            py_rec = {"error": repr(e)}
+            py = {"error": repr(e)}
+        try:
+            from libhuffman_amd import _native as N
+            capi = {"what": "huf_encode + huf_decode on huf_memopen streams, zipf255, blocksize 64 KiB: host bytes in and out "
+                            "(PCIe and every launch included); microseconds per call",
+                    "by_bytes": c_api_by_size(N.load(), C_API_SIZES, 65536)}
+        except Exception as e:
+            capi = {"error": repr(e)}
+        return py, capi
+
+    py_rec, capi_rec = (None, None)
+    if rank == 0 and world == 1:
+        py_rec, capi_rec = host_legs()
 
     result = None
     if rank == 0:
@@ -763,6 +852,8 @@ def main() -> None:
             result["root_placement"] = root_rec
         if py_rec is not None:
             result["secondary"]["logtext_huffmanfile"] = py_rec
+        if capi_rec is not None:
+            result["secondary"]["c_api_memstream"] = capi_rec
         result["roofline"]["traffic_source"] = STAMP_SOURCE if result["roofline"].get("traffic") is not None else None
         if world == 1 and not args.no_live_traffic:
             same = ["--bytes-per-gpu", str(args.bytes_per_gpu), "--decode", args.decode]
@@ -796,6 +887,14 @@ def main() -> None:
                                         "cpu_baseline is rank 0's host")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, bs)
+            try:                                         # the reference on the sizes of secondary.c_api_memstream (bounded: up to 64 MiB)
+                import ctypes
+                from oracle.oracle import REF_SO, Reference
+                if Reference.available():
+                    result["cpu_baseline"]["c_api_by_bytes"] = c_api_by_size(ctypes.CDLL(REF_SO), [z for z in C_API_SIZES if z <= (64 << 20)],
+                                                                                65536, budget_s=4.0)
+            except Exception as e:
+                result["cpu_baseline"]["c_api_by_bytes"] = {"error": repr(e)}
 
     # RCCL writes its version banner through C stdio, which a pipe only sees when a process exits:
     # every rank pushes its buffer out before the last barrier, so that rank 0's JSON line is the
@@ -813,6 +912,12 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if world > 1:
+            py_rec, capi_rec = host_legs()
+            if py_rec is not None:
+                result["secondary"]["logtext_huffmanfile"] = py_rec
+            if capi_rec is not None:
+                result["secondary"]["c_api_memstream"] = capi_rec
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(result), flush=True)
 

@@ -741,11 +741,16 @@ huf_error_t huf_tree_deserialize(huf_tree_t *self, const int16_t *buf, size_t le
  * concurrent calls - disjoint configs on different threads are legal and parallel in the
  * reference, which has no global state (src/encoder.c:379-392) - run side by side, each on the
  * first session that is free: a multi-threaded C caller uses every listed GPU. */
+#define LANE_MAX 8             /* copy lanes (threads) of a large host <-> device transfer */
 typedef struct {
     void *h_a, *h_b;           /* pinned staging */
     size_t h_a_cap, h_b_cap;
     void *d_a, *d_b, *d_c;     /* device staging (d_c: one round of a descriptor-fed decode) */
     size_t d_a_cap, d_b_cap, d_c_cap;
+    void *lane_pin;            /* LANE_MAX x 2 pinned slots of LANE_SLOT bytes (lane_copy) */
+    hipStream_t lane_stream[LANE_MAX];
+    hipEvent_t lane_ev[LANE_MAX][2];
+    int lanes_ready;
 } staging_t;
 
 #define HUF_MAX_SESSIONS 32
@@ -947,14 +952,142 @@ static void prefault_end(prefault_job_t *j)
     j->started = 0;
 }
 
+/* Large transfers between PAGEABLE host memory (a caller's buffer, a memory stream) and the device.
+ * hipMemcpy from or to pageable memory runs at 10-18 GB/s here (the runtime pins or stages piece by piece on one
+ * thread), a fifth of what the link carries.  lane_copy() cuts the transfer into pieces of LANE_SLOT bytes and gives
+ * them to a few threads (lanes); every lane owns two pinned slots and a stream: memcpy into a slot, asynchronous copy
+ * from it - while that runs, memcpy into the other slot (and the other way round for device -> host, where the
+ * destination's pages are populated piece by piece by the lane that is about to fill them: no populate of the whole
+ * buffer in front of the copy).  Returns when everything has arrived. */
+#define LANE_SLOT ((size_t)8 << 20)
+#define LANE_MIN ((size_t)32 << 20)        /* below this one hipMemcpy is as good */
+typedef struct {
+    staging_t *st;
+    int device, lane, nlanes, to_device;
+    char *host;
+    char *dev;
+    size_t n;
+    int err;
+} lane_job_t;
+
+static int lane_count(void)
+{
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("HUF_GPU_COPY_LANES");
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        n = e ? atoi(e) : (int)(cpus >= 16 ? 6 : (cpus >= 8 ? 4 : (cpus >= 4 ? 2 : 1)));     /* (1 GiB of log text through huffmanfile: 0 lanes 5.2, 2: 5.3, 4: 5.7, 6: 6.0, 8: 4.7 GiB/s) */
+        if (n < 0) n = 0;
+        if (n > LANE_MAX) n = LANE_MAX;
+    }
+    return n;
+}
+
+static void *lane_main(void *arg)
+{
+    lane_job_t *j = (lane_job_t *)arg;
+    staging_t *st = j->st;
+    if (hipSetDevice(j->device) != hipSuccess) { j->err = 1; return NULL; }
+    hipStream_t s = st->lane_stream[j->lane];
+    char *slot[2] = {(char *)st->lane_pin + (size_t)(2 * j->lane) * LANE_SLOT, (char *)st->lane_pin + (size_t)(2 * j->lane + 1) * LANE_SLOT};
+    const size_t pieces = (j->n + LANE_SLOT - 1) / LANE_SLOT;
+    int k = 0;                                   /* this lane's pieces, in order: lane, lane + nlanes, ... */
+    if (j->to_device) {
+        for (size_t p = (size_t)j->lane; p < pieces; p += (size_t)j->nlanes, k++) {
+            const size_t off = p * LANE_SLOT, len = (j->n - off < LANE_SLOT) ? j->n - off : LANE_SLOT;
+            if (k >= 2 && hipEventSynchronize(st->lane_ev[j->lane][k & 1]) != hipSuccess) { j->err = 1; break; }
+            memcpy(slot[k & 1], j->host + off, len);
+            if (hipMemcpyAsync(j->dev + off, slot[k & 1], len, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipEventRecord(st->lane_ev[j->lane][k & 1], s) != hipSuccess) { j->err = 1; break; }
+        }
+    } else {
+        /* device -> host: the copy of piece k + 1 is in flight while piece k goes from its slot to the destination */
+        size_t p = (size_t)j->lane;
+        size_t off = p * LANE_SLOT, len = 0;
+        if (p < pieces) {
+            len = (j->n - off < LANE_SLOT) ? j->n - off : LANE_SLOT;
+            if (hipMemcpyAsync(slot[0], j->dev + off, len, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipEventRecord(st->lane_ev[j->lane][0], s) != hipSuccess) j->err = 1;
+        }
+        for (; p < pieces && !j->err; p += (size_t)j->nlanes, k++) {
+            const size_t pn = p + (size_t)j->nlanes;
+            size_t offn = 0, lenn = 0;
+            if (pn < pieces) {
+                offn = pn * LANE_SLOT;
+                lenn = (j->n - offn < LANE_SLOT) ? j->n - offn : LANE_SLOT;
+                if (hipMemcpyAsync(slot[(k + 1) & 1], j->dev + offn, lenn, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipEventRecord(st->lane_ev[j->lane][(k + 1) & 1], s) != hipSuccess) { j->err = 1; break; }
+            }
+            prefault_t w = {j->host + off, len};
+            prefault_main(&w);                       /* (contents untouched; pages that are there already cost nothing) */
+            if (hipEventSynchronize(st->lane_ev[j->lane][k & 1]) != hipSuccess) { j->err = 1; break; }
+            memcpy(j->host + off, slot[k & 1], len);
+            off = offn;
+            len = lenn;
+        }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) j->err = 1;
+    return NULL;
+}
+
+/* host <-> device, n bytes; falls back to one plain copy for small transfers or when the lanes cannot be set up */
+static huf_error_t lane_copy(int to_device, void *dev, void *host, size_t n)
+{
+    staging_t *st = &g_stage;
+    const int nl = lane_count();
+    if (n < LANE_MIN || nl <= 0) goto plain;
+    (void)hipSetDevice(t_session->device);
+    if (!st->lanes_ready) {
+        if (st->lanes_ready < 0) goto plain;
+        st->lanes_ready = -1;
+        if (hipHostMalloc(&st->lane_pin, (size_t)2 * LANE_MAX * LANE_SLOT, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); st->lane_pin = NULL; goto plain; }
+        for (int i = 0; i < LANE_MAX; i++) {
+            if (hipStreamCreateWithFlags(&st->lane_stream[i], hipStreamNonBlocking) != hipSuccess) goto plain;
+            for (int e = 0; e < 2; e++)
+                if (hipEventCreateWithFlags(&st->lane_ev[i][e], hipEventDisableTiming) != hipSuccess) goto plain;
+        }
+        st->lanes_ready = 1;
+    }
+    {
+        (void)hipDeviceSynchronize();                /* what the device buffer is read from or written by has finished (the lanes' streams do not wait for others) */
+        lane_job_t job[LANE_MAX];
+        pthread_t th[LANE_MAX];
+        int started = 0, bad = 0;
+        if (!to_device) {
+            const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+            const uintptr_t lo = ((uintptr_t)host + page - 1) & ~(page - 1), hi = ((uintptr_t)host + n) & ~(page - 1);
+            if (hi > lo) (void)madvise((void *)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+        }
+        for (int i = 0; i < nl; i++) {
+            job[i].st = st; job[i].device = t_session->device; job[i].lane = i; job[i].nlanes = nl; job[i].to_device = to_device;
+            job[i].host = (char *)host; job[i].dev = (char *)dev; job[i].n = n; job[i].err = 0;
+            if (i == 0) continue;                        /* lane 0 is the calling thread's */
+            if (pthread_create(&th[i], NULL, lane_main, &job[i]) == 0) started |= 1 << i;
+            else lane_main(&job[i]);
+        }
+        lane_main(&job[0]);
+        for (int i = 1; i < nl; i++)
+            if (started & (1 << i)) pthread_join(th[i], NULL);
+        for (int i = 0; i < nl; i++) bad |= job[i].err;
+        if (bad) { (void)hipGetLastError(); return HUF_ERROR_FATAL; }
+        return HUF_ERROR_SUCCESS;
+    }
+plain:
+    return (huf_error_t)(to_device ? hufgpu_memcpy_h2d(g_ctx, dev, host, n) : hufgpu_memcpy_d2h(g_ctx, host, dev, n));
+}
+
 static huf_error_t d2h_to_memstream(membuf_t *wmem, const void *d_src, size_t n)
 {
     TRY(mem_reserve(wmem, n));
     char *dst = (char *)*wmem->buf + wmem->len;
-    prefault_job_t job;
-    prefault_begin(&job, dst, n, 1);
-    prefault_end(&job);
-    TRY(hufgpu_memcpy_d2h(g_ctx, dst, d_src, n));
+    if (n >= LANE_MIN && lane_count() > 0) {
+        TRY(lane_copy(0, (void *)d_src, dst, n));       /* (populates the pages piece by piece, beside the copies) */
+    } else {
+        prefault_job_t job;
+        prefault_begin(&job, dst, n, 1);
+        prefault_end(&job);
+        TRY(hufgpu_memcpy_d2h(g_ctx, dst, d_src, n));
+    }
     wmem->len += n;
     return HUF_ERROR_SUCCESS;
 }
@@ -1221,7 +1354,7 @@ static huf_error_t encode_rounds(huf_encoder_t *enc, uint64_t batch, membuf_t *r
                 rmem->off = rmem->len;                          /* what a failed read would have consumed */
                 rc = HUF_ERROR_READ_WRITE;
             } else {
-                rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, (const char *)*rmem->buf + rmem->off, take);
+                rc = lane_copy(1, g_stage.d_a, (char *)*rmem->buf + rmem->off, take);
                 if (rc == HUF_ERROR_SUCCESS) rmem->off += take;
             }
         } else if (rd->started) {
@@ -1885,7 +2018,7 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
         TRY(grow_dev(&g_stage.d_a, &g_stage.d_a_cap, avail + 16));
         TRY(grow_dev(&g_stage.d_b, &g_stage.d_b_cap, out_cap));
         uint64_t raw = 0, used = 0;
-        int rc = hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, rmem ? (const void *)in_ptr : (const void *)g_stage.h_a, avail);
+        int rc = rmem ? (int)lane_copy(1, g_stage.d_a, (void *)in_ptr, avail) : hufgpu_memcpy_h2d(g_ctx, g_stage.d_a, g_stage.h_a, avail);
         if (rc == HUF_ERROR_SUCCESS)
             rc = hufgpu_decode_stream(g_ctx, g_stage.d_a, avail, length, g_stage.d_b, g_stage.d_b_cap, flags, &raw, &used, NULL);
         if (rc == HUF_ERROR_FATAL) return (huf_error_t)rc;

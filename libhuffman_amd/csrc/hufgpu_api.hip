@@ -1133,7 +1133,9 @@ static int decode_stream_general(hufgpu_ctx_t *ctx, const void *d_stream, uint64
     uint64_t prefix_raw = 0, resume = 0;
     bool complete = false;
     const uint64_t scan_len = length < avail ? length : avail;
-    const bool try_parallel = (((uintptr_t)st & 15u) == 0) && scan_len >= 4096 && !(flags & HUFGPU_SEQUENTIAL);
+    /* (below 64 KiB of stream the in-order chain is the faster of the two: one launch, 50-60 us a call where the discovery's
+     *  launches and its two host round trips take 100-130 - tools/time_stream_small.py) */
+    const bool try_parallel = (((uintptr_t)st & 15u) == 0) && scan_len >= 65536 && !(flags & HUFGPU_SEQUENTIAL);
     if (try_parallel) {
         uint64_t m = 0, in_place = ~0ull;
         const int drc = discover_chain(ctx, st, avail, length, scan_len, max_tree, out, out_cap, s, &m, &resume, &complete, &in_place);

@@ -842,6 +842,26 @@ def test_bench_runs_over_rccl_with_one_rank(torch_mod):
     assert rp["bit_exact_roundtrip"] is True and rp["value"] > 0
 
 
+def test_bench_configs3_share_over_rccl_with_one_rank(torch_mod):
+    """BASELINE configs[3] is 16 GiB of uniform bytes over 8 GPUs = 2 GiB per rank: that share - its allocations (2 GiB
+    in, 2.3 GiB of stream bound, the sub-index, 2 GiB out), 32 768 blocks of k = 256 in relaxed-tree mode - over RCCL with
+    the one rank this box has, per-rank times and the size all-gather's cost in the record."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "uniform256",
+                          "--bytes-per-gpu", str(2 << 30), "--secondary", "none", "--no-cpu-baseline", "--no-live-traffic",
+                          "--no-index-free", "--no-python-layer", "--no-other-decode", "--placement", "resident"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["bytes_per_gpu"] == 2 << 30 and d["config"]["blocks_per_gpu"] == 32768
+    assert d["config"]["bit_exact_roundtrip"] is True and d["config"]["generator"] == "uniform256"
+    assert len(d["per_rank_ms_per_step"]) == 1 and d["size_allgather_ms"] >= 0
+
+
 def test_bench_counts_the_longest_kernels_traffic_in_its_own_run(torch_mod):
     """roofline.traffic of the default bench line is counted in the run itself (two rocprofv3 --pmc child passes of
     the same command), not taken from a table: between the algorithmic bytes and 1.3 times them for the kernels the

@@ -149,7 +149,23 @@ def cpu_all_cores_child(workload: str, blocksize: int) -> None:
     with that many cores could do with libhuffman today).  Prints one JSON object: aggregate GiB/s = all bytes /
     (last finish - first start)."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))                  # (a container may be given fewer cores than the machine has)
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    # ... or less CPU TIME than cores: a cgroup quota (cpu.max "quota period").  The GPU boxes of this pool show 256
+    # hardware threads and grant 16 cores' worth of time; 256 processes then measure the throttle, not the machine
+    # (8 processes 0.14, 32: 0.26, 64: 0.24, 128: 0.21, 256: 0.16 GiB/s).  Twice the quota's cores is what ran fastest.
+    quota_cores = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max":
+            quota_cores = max(1, int(int(q) / int(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    cores = min(usable, quota_cores) if quota_cores else usable
+    ncpu = int(os.environ.get("BENCH_CPU_PROCESSES", "0")) or (min(usable, 2 * cores) if quota_cores and quota_cores < usable else cores)
     per = max(blocksize, (8 << 20) // blocksize * blocksize)
     ctx = mp.get_context("fork")
     barrier, q = ctx.Barrier(ncpu), ctx.Queue()
@@ -165,7 +181,8 @@ def cpu_all_cores_child(workload: str, blocksize: int) -> None:
         return
     start, mid, end = min(g[1] for g in got), max(g[2] for g in got), max(g[3] for g in got)
     total = per * ncpu
-    print(json.dumps({"value": round(total / GIB / (end - start), 5), "unit": "GiB/s", "cores": ncpu, "processes": ncpu,
+    print(json.dumps({"value": round(total / GIB / (end - start), 5), "unit": "GiB/s", "cores": cores, "processes": ncpu,
+                      "hardware_threads": os.cpu_count(), "cgroup_quota_cores": quota_cores,
                       "encode_GiBps": round(total / GIB / (mid - start), 5),
                       "sample": f"{per >> 20} MiB of {workload} per process ({total >> 20} MiB), {blocksize >> 10} KiB blocks, "
                                 f"encode + decode {end - start:.2f}s, all processes released together"}))

@@ -44,7 +44,14 @@ namespace hufgpu {
                                                        uniform bytes, never fall into step at all) */
 #define DFAST_MAX_ROUNDS 64
 #ifndef DFAST_PRE
-#define DFAST_PRE 0u                                 /* bits in front of a share its lane walks before the first scan (0: none) */
+#define DFAST_PRE 0u                                 /* bits in front of a share its lane walks before the first scan (0: round 3's form, the default:
+                                                       96 / 128 / 192 bits alone 1.72 -> 1.74 / 1.71 / 1.66 ms per GiB on zipf255, uniform bytes worse) */
+#endif
+#ifndef DFAST_COMPACT_ROUNDS
+#define DFAST_COMPACT_ROUNDS 0                       /* rounds of compacted rescans in front of the round loop (needs DFAST_PRE; 0: none, the default.
+                                                       Measured with DFAST_PRE = 64 / 96 / 128 and 3 rounds: 1.91 / 1.81 / 1.77 ms per GiB on zipf255 against 1.73
+                                                       without, uniform255 1.43 -> 1.60-2.02: ONE wave's scan takes as long as all eight waves' - what compaction
+                                                       saves is instruction issue, and what this kernel waits for is the latency of a scan and its barriers) */
 #endif
 
 template <int THREADS>
@@ -308,7 +315,11 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
             acc = __builtin_amdgcn_alignbit(e2, acc, 8);
             Q += l1 + ((e2 >> 8) & 31u);
         }
+#ifdef DFAST_ABLATE_STORE       /* (timing experiment: what the scattered 32-bit stores of the write pass cost) */
+        if (acc == 0x12345678u) gw[k] = acc;
+#else
         gw[k] = acc;
+#endif
     }
     uint32_t p1 = Q + 1u - qbase;
     if (__builtin_expect(__ballot((special & 0xC000u) != 0u) != 0ull, 0)) {
@@ -359,6 +370,16 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     uint64_t true_start = 0, produced = 0;
     bool ok = true;
     bool trust = true;                                                 /* (uniform) guesses at the block's end are allowed */
+#if DFAST_PRE
+    uint32_t pre = DFAST_PRE;
+    if (!end_bits && block_len != 0) {
+        /* whole bits per symbol (up to the last byte's padding), and that many dividing the share: codes of one length */
+        const uint64_t per = pay_bits / block_len;
+        if (per != 0 && pay_bits - per * block_len < 8u && DFAST_SUB_BITS % (uint32_t)per == 0u) pre = 0;
+    }
+    if (end_bits) pre = 0;                                             /* (the raw-stream probe keeps round 3's form) */
+    pre = uni32(pre);
+#endif
     while (produced < block_len) {
         if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }             /* input exhausted: the exact decoder says how */
         const uint64_t seg0 = true_start & ~31ull;
@@ -422,12 +443,14 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         uint32_t end = hi, cnt = 0;
 #if DFAST_PRE
         /* Round 4: the speculation begins DFAST_PRE bits in FRONT of the share (its left neighbour's last bits): a lane
-         * that walks those first stands on a codeword start of the real track when it reaches its own share in 99 % of
-         * all cases (tools/sim/sim_sync.py), where the share's own first bit is one in 13 %; the second scan below - a
-         * whole scan for every wave that holds ONE lane whose start moved - is then the exception. */
-        if (__ballot(!dead && tid != 0)) {
+         * that walks those first stands on a codeword start of the real track when it reaches its own share in 97-99 % of
+         * all cases (tools/sim/sim_sync.py), where the share's own first bit is one in 13 %.  On its own that buys little
+         * (nearly every WAVE still holds a lane whose start moves, and scans again as a whole: 1.72 -> 1.66 ms per GiB);
+         * with the compacted rescans below it does.  Not for codes of ONE length that divides the share (uniform bytes:
+         * 32 codes of 9 bits): there every share's first bit IS a codeword start. */
+        if (pre != 0u && __ballot(!dead && tid != 0)) {
             const uint32_t lo = hi - DFAST_SUB_BITS;
-            const uint32_t from = (lo >= first + DFAST_PRE) ? lo - DFAST_PRE : first;
+            const uint32_t from = (lo >= first + pre) ? lo - pre : first;
             const bool walk = !dead && tid != 0;
             uint32_t e0 = lo, c0 = 0;
             if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, walk ? from : lo, lo, lim, &e0, &c0);
@@ -452,6 +475,63 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             }
             guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
         }
+#if DFAST_COMPACT_ROUNDS && DFAST_PRE
+        /* Round 4: the lanes whose start has to move are few once the speculation begins in front of the share (2-3 %);
+         * left to their waves they cost a whole scan of every wave that holds one.  COMPACTED into the first lanes of the
+         * workgroup they cost one wave's scan: ends, starts and counts pass through LDS (the area behind the stage).
+         * Only a lane whose LEFT neighbour's start stands is taken (its new start then is final unless something further
+         * left still moves); what has not settled after DFAST_COMPACT_ROUNDS rounds - runs of one byte value, codes
+         * that fall into step slowly - is the loop's below, which also has the last word on "nothing moves any more". */
+        if (!end_bits && pre != 0u) {
+            uint32_t *cE = stage + L::STAGE_WORDS + 4u;                /* [THREADS] a lane's end */
+            uint32_t *cS = cE + THREADS;                               /* [THREADS] start << 10 | count of a lane scanned again */
+            uint16_t *clist = reinterpret_cast<uint16_t *>(cS + THREADS);
+            static_assert(L::STAGE_WORDS + 4u + 2u * THREADS + THREADS / 2u <= L::AREA_WORDS, "the compaction's arrays fit behind the stage");
+            cE[tid] = end;
+            if (tid == 0) sh.firstone = 0;
+            __syncthreads();
+            for (int cr = 0; cr < DFAST_COMPACT_ROUNDS; cr++) {
+                const uint32_t ns = tid ? cE[tid - 1] : first;
+                const bool bad = !dead && ns != start;
+                const unsigned long long bm = __ballot(bad);
+                if (lane == 63) sh.part[wave] = (uint32_t)(bm >> 63);
+                if (!__syncthreads_or(bad ? 1 : 0)) break;
+                const bool left_bad = lane ? ((bm >> (lane - 1)) & 1ull) != 0ull : (tid != 0 && sh.part[wave - 1] != 0u);
+                const bool fixme = bad && !left_bad;
+                {
+                    const unsigned long long m = __ballot(fixme);
+                    uint32_t base = 0;
+                    if (lane == 0 && m) base = atomicAdd(&sh.firstone, (uint32_t)__popcll(m));
+                    base = wave_lane_u32(base, 0);
+                    if (fixme) clist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+                }
+                __syncthreads();
+                const uint32_t n = uni32(sh.firstone);
+                if ((uint32_t)tid < ((n + 63u) & ~63u)) {              /* (whole waves) */
+                    const bool mine = (uint32_t)tid < n;
+                    const uint32_t li = mine ? clist[tid] : 0u;
+                    const uint32_t hi_li = (li + 1u) * DFAST_SUB_BITS;
+                    const uint32_t st = li ? cE[li - 1u] : first;
+                    uint32_t e2 = hi_li, c2 = 0;
+                    if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, mine ? st : hi_li, hi_li, lim, &e2, &c2);
+                    else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, mine ? st : hi_li, hi_li, lim, &e2, &c2);
+                    if (mine) {
+                        cS[li] = (st << 10) | (c2 & 1023u);
+                        cE[li] = e2;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) sh.firstone = 0;
+                if (fixme) {
+                    const uint32_t v = cS[tid];
+                    start = v >> 10;
+                    cnt = v & 1023u;
+                    end = cE[tid];
+                }
+            }
+            __syncthreads();                                           /* (sh.part is the sums' again below) */
+        }
+#endif
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
         int rounds = 0;

@@ -42,7 +42,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void chunk_hist_kernel(const uint8_t *__restrict__ in, ChunkGeom geo,
                                                              uint32_t *__restrict__ chunk_hist)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HUF_NSYM * 64 * 4];
+    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HL_LDS_BYTES];
     uint64_t base, len;
     if (!geo.locate(blockIdx.x, base, len)) {            /* (a chunk behind the stream's last, short block) */
         for (int b = (int)threadIdx.x; b < HUF_NSYM; b += THREADS) chunk_hist[(uint64_t)blockIdx.x * HUF_NSYM + b] = 0;

@@ -30,22 +30,59 @@ namespace hufgpu {
  * ==================================================================================== */
 #define HL_THREADS 512
 #define HL_MIN_BLOCK 32768u       /* below this the 64 KiB of counters cost more to zero and sum than the block to count: the fused kernel */
+/* Round 4: 16-bit counters.  Lanes l and l + 32 of a wave share a word (low and high half); an LDS instruction serves
+ * lanes 0-31 and 32-63 in different cycles anyway, so the 32 lanes of a half still meet 32 different banks - two passes
+ * per ds_add as before - and the array is 32 KiB: four workgroups per CU instead of two, half as much to zero and to
+ * sum.  A counter sees lane l of all eight waves: 1 024 bytes of a 64 KiB block, 32 768 of the largest block that
+ * comes here (below 2 MiB; chunks of 256 KiB above that) - 16 bits hold it.  The address is byte << 7 | (lane & 31) << 2:
+ * the v_perm puts the byte over twice the column, one shift halves both. */
+#ifndef HL_COUNTER16
+#define HL_COUNTER16 1
+#endif
+#ifndef HL_AHEAD
+#define HL_AHEAD 8                /* 16-byte vectors a thread requests before it counts the first */
+#endif
+#ifndef HL_WAVES_PER_SIMD
+#define HL_WAVES_PER_SIMD 4       /* (8 waves a workgroup: 4 = two workgroups per CU, what 97 registers allow) */
+#endif
+#define HL_LDS_BYTES (HL_COUNTER16 ? HUF_NSYM * 32 * 4 : HUF_NSYM * 64 * 4)
+#define HL_MAX_PER_COUNTER 65535u
 
-__device__ __forceinline__ void hl_add_dword(uint8_t *hl_lds, uint32_t w, uint32_t col)
+#if HL_COUNTER16
+/* col = (lane & 31) << 3 (twice the column's byte offset), one = 1 or 1 << 16 (the lane's half of the word) */
+__device__ __forceinline__ void hl_add_dword(uint8_t *hl_lds, uint32_t w, uint32_t col, uint32_t one)
+{
+    /* D.byte0 = col.byte0, D.byte1 = w.byte k, D.byte2 = D.byte3 = 0; >> 1: byte << 7 | (lane & 31) << 2 */
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (__builtin_amdgcn_perm(w, col, 0x0c0c0400u) >> 1)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (__builtin_amdgcn_perm(w, col, 0x0c0c0500u) >> 1)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (__builtin_amdgcn_perm(w, col, 0x0c0c0600u) >> 1)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (__builtin_amdgcn_perm(w, col, 0x0c0c0700u) >> 1)), one);
+}
+__device__ __forceinline__ void hl_add_byte(uint8_t *hl_lds, uint32_t byte, uint32_t col, uint32_t one)
+{
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (((byte << 8) | col) >> 1)), one);
+}
+#else
+__device__ __forceinline__ void hl_add_dword(uint8_t *hl_lds, uint32_t w, uint32_t col, uint32_t one)
 {
     /* D.byte0 = col.byte0 (lane << 2), D.byte1 = w.byte k, D.byte2 = D.byte3 = 0 */
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0400u)), 1u);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0500u)), 1u);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0600u)), 1u);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0700u)), 1u);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0400u)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0500u)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0600u)), one);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0700u)), one);
 }
-
-__device__ __forceinline__ void hl_add_vec(uint8_t *hl_lds, uint4 v, uint32_t col)
+__device__ __forceinline__ void hl_add_byte(uint8_t *hl_lds, uint32_t byte, uint32_t col, uint32_t one)
 {
-    hl_add_dword(hl_lds, v.x, col);
-    hl_add_dword(hl_lds, v.y, col);
-    hl_add_dword(hl_lds, v.z, col);
-    hl_add_dword(hl_lds, v.w, col);
+    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + ((byte << 8) | col)), one);
+}
+#endif
+
+__device__ __forceinline__ void hl_add_vec(uint8_t *hl_lds, uint4 v, uint32_t col, uint32_t one)
+{
+    hl_add_dword(hl_lds, v.x, col, one);
+    hl_add_dword(hl_lds, v.y, col, one);
+    hl_add_dword(hl_lds, v.z, col, one);
+    hl_add_dword(hl_lds, v.w, col, one);
 }
 
 /* the 256 counts of `len` bytes at `p` -> out[256] (the whole workgroup; hl_lds = its 64 KiB) */
@@ -53,48 +90,68 @@ template <int THREADS>
 __device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restrict__ p, uint64_t len, uint32_t *__restrict__ out)
 {
     const int tid = (int)threadIdx.x;
+#if HL_COUNTER16
+    const uint32_t col = (uint32_t)(tid & 31) << 3;
+    const uint32_t one = (tid & 32) ? 0x10000u : 1u;
+#else
     const uint32_t col = (uint32_t)(tid & 63) << 2;
+    const uint32_t one = 1u;
+#endif
 
     {
         uint4 *z = reinterpret_cast<uint4 *>(hl_lds);
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int i = 0; i < (HUF_NSYM * 64 * 4) / 16 / THREADS; i++) z[i * THREADS + tid] = zero;
+        for (int i = 0; i < HL_LDS_BYTES / 16 / THREADS; i++) z[i * THREADS + tid] = zero;
     }
     const uint64_t head = dmin<uint64_t>(len, (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
     const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
     const uint64_t nvec = (len - head) >> 4;
     /* the first eight vectors of every thread are requested before the zeroed array is waited for */
-    uint4 v[8];
+    uint4 v[HL_AHEAD];
     uint64_t i = (uint64_t)tid;
-    const bool full8 = i + 7 * THREADS < nvec;
+    const bool full8 = i + (HL_AHEAD - 1) * THREADS < nvec;
     if (full8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = load_stream16(q + i + (uint64_t)k * THREADS);
+        for (int k = 0; k < HL_AHEAD; k++) v[k] = load_stream16(q + i + (uint64_t)k * THREADS);
     }
     __syncthreads();
-    if ((uint64_t)tid < head) atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (((uint32_t)p[tid] << 8) | col)), 1u);
+    if ((uint64_t)tid < head) hl_add_byte(hl_lds, (uint32_t)p[tid], col, one);
     if (full8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) hl_add_vec(hl_lds, v[k], col);
-        i += 8 * THREADS;
+        for (int k = 0; k < HL_AHEAD; k++) hl_add_vec(hl_lds, v[k], col, one);
+        i += HL_AHEAD * THREADS;
     }
     for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {
         const uint4 a = load_stream16(q + i), b = load_stream16(q + i + THREADS), c = load_stream16(q + i + 2 * THREADS),
                     d = load_stream16(q + i + 3 * THREADS);
-        hl_add_vec(hl_lds, a, col);
-        hl_add_vec(hl_lds, b, col);
-        hl_add_vec(hl_lds, c, col);
-        hl_add_vec(hl_lds, d, col);
+        hl_add_vec(hl_lds, a, col, one);
+        hl_add_vec(hl_lds, b, col, one);
+        hl_add_vec(hl_lds, c, col, one);
+        hl_add_vec(hl_lds, d, col, one);
     }
-    for (; i < nvec; i += THREADS) hl_add_vec(hl_lds, load_stream16(q + i), col);
+    for (; i < nvec; i += THREADS) hl_add_vec(hl_lds, load_stream16(q + i), col, one);
     const uint64_t tail0 = head + (nvec << 4);
-    if (tail0 + (uint64_t)tid < len) atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (((uint32_t)p[tail0 + tid] << 8) | col)), 1u);
+    if (tail0 + (uint64_t)tid < len) hl_add_byte(hl_lds, (uint32_t)p[tail0 + tid], col, one);
     __syncthreads();
     /* row sums: a wave takes four rows per step - lane l reads words 4 (l % 16) .. + 3 of row (l / 16) - adds its
      * four words and then the sixteen lanes of the row (DPP row_shr 1, 2, 4, 8: the sum ends in the row's lane 15) */
     constexpr int WAVES = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
+#if HL_COUNTER16
+    /* a row is 32 words of two 16-bit counters: lane l reads words 2 (l % 16), + 1 of row (l / 16) - a wave four rows a step */
+#pragma unroll
+    for (int it = 0; it < HUF_NSYM / (4 * WAVES); it++) {
+        const int row = (it * WAVES + wave) * 4 + (lane >> 4);
+        const uint2 x = *reinterpret_cast<const uint2 *>(hl_lds + row * 128 + (lane & 15) * 8);
+        uint32_t s = (x.x & 0xffffu) + (x.x >> 16) + (x.y & 0xffffu) + (x.y >> 16);
+        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
+        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
+        if ((lane & 15) == 15) out[row] = s;
+    }
+#else
 #pragma unroll
     for (int it = 0; it < HUF_NSYM / (4 * WAVES); it++) {
         const int row = (it * WAVES + wave) * 4 + (lane >> 4);
@@ -106,13 +163,14 @@ __device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restr
         s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
         if ((lane & 15) == 15) out[row] = s;
     }
+#endif
 }
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void hist_lanes_kernel(const uint8_t *__restrict__ in, uint64_t n, uint64_t blocksize,
+__global__ __launch_bounds__(THREADS, HL_WAVES_PER_SIMD) void hist_lanes_kernel(const uint8_t *__restrict__ in, uint64_t n, uint64_t blocksize,
                                                              uint32_t *__restrict__ hist)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HUF_NSYM * 64 * 4];      /* uint32 [256 byte values][64 lanes] */
+    __shared__ __attribute__((aligned(16))) uint8_t hl_lds[HL_LDS_BYTES];      /* [256 byte values][32 columns] words of two 16-bit counters (round 3: [256][64] uint32) */
     const uint64_t blk = blockIdx.x;
     const uint64_t base = blk * blocksize;
     const uint64_t len = dmin<uint64_t>(blocksize, n - base);

@@ -122,6 +122,12 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
                       const void *d_sub_index, void *d_out, uint64_t out_cap, uint32_t flags,
                       uint64_t *raw_len, void *stream);
 
+/* A small encode with one synchronisation instead of three: h_in_pinned (n bytes, pinned host memory) -> d_in ->
+ * encode -> h_out_pinned: the stream's first hufgpu_encode_bound(n, blocksize) bytes and, 8-byte aligned behind them,
+ * its length (h_out_cap >= bound rounded up to 8, + 8).  What huf_encode() uses for memory streams of up to 32 KiB. */
+int hufgpu_encode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t n, uint64_t blocksize, void *d_in,
+                        void *d_out, uint64_t out_cap, void *h_out_pinned, uint64_t h_out_cap, uint64_t *out_len);
+
 /* Of the last enqueued hufgpu_decode() / hufgpu_decode_sub(): blocks that went through a slower decoder -
  * counters[0] = decoded again by the exact in-order-equivalent decoder (a damaged block, an unusual tree, a stale
  * sub-index), counters[1] = handed on by the one-pass decoder of index-only streams (starts that did not settle).

@@ -647,6 +647,29 @@ extern "C" int hufgpu_decode_result(hufgpu_ctx_t *ctx, uint64_t *raw_len)
     return err;
 }
 
+/* One small encode with ONE synchronisation (include/huffman_gpu.h): input from pinned host memory, the stream and its
+ * length back into pinned host memory.  A call through the general entry points waits three times (input up, the length,
+ * the stream back); for inputs of a few KiB those waits are most of the call. */
+extern "C" int hufgpu_encode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t n, uint64_t blocksize, void *d_in,
+                                   void *d_out, uint64_t out_cap, void *h_out_pinned, uint64_t h_out_cap, uint64_t *out_len)
+{
+    if (!ctx || !h_in_pinned || !d_in || !d_out || !h_out_pinned || !out_len || n == 0) return HUFE_ARGUMENT;
+    const uint64_t bound = hufgpu_encode_bound(n, blocksize);
+    const uint64_t len_at = (bound + 7u) & ~7ull;
+    if (h_out_cap < len_at + 8u || out_cap < bound) return HUFE_ARGUMENT;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIP_OK(ctx, hipMemcpyAsync(d_in, h_in_pinned, n, hipMemcpyHostToDevice, s));
+    const int rc = encode_impl(ctx, d_in, n, blocksize, d_out, out_cap, NULL, NULL, NULL, (void *)s);
+    if (rc != HUFE_OK) return rc;
+    const uint64_t nb = hufgpu_block_count(n, blocksize ? blocksize : n);
+    HIP_OK(ctx, hipMemcpyAsync(h_out_pinned, d_out, bound, hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipMemcpyAsync((char *)h_out_pinned + len_at, ctx->d_offsets + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipStreamSynchronize(s));
+    *out_len = *(const uint64_t *)((const char *)h_out_pinned + len_at);
+    return (*out_len <= bound) ? HUFE_OK : HUFE_FATAL;
+}
+
 /* How many blocks of the last enqueued decode were handed on: counters[0] = to the exact decoder
  * (decode_fix_kernel), counters[1] = by decode_lean_kernel to round 3's decoder.  Synchronises. */
 extern "C" int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters)

@@ -597,6 +597,205 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     return ok;
 }
 
+/* ======================================================================================
+ * Round 4: the table of an ENCODER-MADE tree without walking it.  dec_build_tables finds every node's right child by a
+ * search and walks the tree twelve levels deep for each of the 4 096 entries - about 1 150 vector instructions per thread
+ * and block, a seventh of this kernel's.  For the trees an encoder writes (4K + 1 entries, K leaves, a root with a left
+ * child only, every other node two children) the depths follow from two facts (decode_lean.hpp has the long form): in
+ * preorder a leaf's depth is (left turns on its path) + (right turns), the left turns are a prefix sum over the entries
+ * (+1 node, -1 marker), the right turns are the one bits of the leaf's code, and code(k + 1) = code(k) + 2^-depth(k) -
+ * one chain of four scalar instructions per leaf, walked by ONE wave; the claimed depths are then checked against the
+ * entries' positions exactly as dsub_fast_tables (decode_sub.hpp) checks the sub-index's, and the table is filled eight
+ * consecutive entries per thread.  Entries are dec_build_tables' (decode.hpp).  Returns false - nothing of the tables
+ * is to be used then, the caller walks the tree - for any other shape of tree and for blocks with codes of more than
+ * DEC_LUT_BITS bits (their `long` entries need the child links only the walk builds).
+ * ==================================================================================== */
+template <int THREADS, bool SPEC>
+__device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len)
+{
+    typedef DsubFastLds<THREADS> F;
+    constexpr int WAVES = THREADS / 64;
+    static_assert(THREADS * 2 >= HUF_TREE_MAX - 1 && THREADS >= 256 && WAVES <= 8, "two entries per thread");
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t K = (uint32_t)(tree_len - 1) >> 2;
+    if (tree_len < 9 || tree_len > HUF_TREE_MAX || ((tree_len - 1) & 3) != 0) return false;     /* uniform */
+    __syncthreads();                                                            /* the previous user of sh is done */
+    uint16_t *s_pos = reinterpret_cast<uint16_t *>(sh.pay);                     /* [256] entry index of the k-th leaf */
+    uint8_t *s_left = reinterpret_cast<uint8_t *>(sh.pay + 128);                /* [256] left turns on the way to the k-th leaf */
+    uint32_t *s_cpart = sh.wtile;
+    static_assert(sizeof(sh.wtile) >= 3 * WAVES * sizeof(uint32_t), "partials of the code scan");
+    bool ok = true;
+    /* the three aligned dwords that hold entries 2t .. 2t + 3 */
+    uint32_t d0, d1, d2, mis;
+    {
+        const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
+        mis = (uint32_t)(a & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(a - mis);
+        const uint32_t nbytes = mis + 2u * (uint32_t)tree_len;
+        const uint32_t t4 = 4u * (uint32_t)tid;
+        d0 = (t4 < nbytes) ? q[tid] : 0u;
+        d1 = (t4 + 4u < nbytes) ? q[tid + 1] : 0u;
+        d2 = (t4 + 8u < nbytes) ? q[tid + 2] : 0u;
+    }
+    if (tid == 0) { sh.efflen = tree_len; sh.badsym = DEC_NO_BAD; sh.firstone = DEC_NO_BAD; sh.qend = 0; }     /* (what dec_build_tables sets) */
+    bool l0, l1;
+    int e0, e1;
+    {
+        if (tid < 64) reinterpret_cast<uint32_t *>(s_left)[tid] = 0x3f3f3f3fu;
+        const uint32_t two01 = mis ? __builtin_amdgcn_alignbit(d1, d0, 8u * mis) : d0;
+        const uint32_t two23 = mis ? __builtin_amdgcn_alignbit(d2, d1, 8u * mis) : d1;
+        const int i0 = 2 * tid;
+        e0 = (i0 < tree_len) ? (int)(int16_t)(two01 & 0xffffu) : -1;
+        e1 = (i0 + 1 < tree_len) ? (int)(int16_t)(two01 >> 16) : -1;
+        const int e2 = (i0 + 2 < tree_len) ? (int)(int16_t)(two23 & 0xffffu) : -1;
+        const int e3 = (i0 + 3 < tree_len) ? (int)(int16_t)(two23 >> 16) : -1;
+        const bool n0 = e0 != -1, n1 = e1 != -1;
+        l0 = n0 && e1 == -1 && e2 == -1 && i0 + 2 < tree_len;
+        l1 = n1 && e2 == -1 && e3 == -1 && i0 + 3 < tree_len;
+        if (tid == 0 && !n0) ok = false;                                        /* the root */
+        if ((i0 == tree_len - 1 && n0) || (i0 + 1 == tree_len - 1 && n1)) ok = false;      /* the last entry is a marker */
+        if (tid == THREADS - 1 && i0 + 2 == tree_len - 1 && e2 != -1) ok = false;          /* (entry 1024 has no thread of its own) */
+        const uint32_t mine = (uint32_t)l0 + (uint32_t)l1 + (((uint32_t)n0 + (uint32_t)n1) << 16);
+        const uint32_t inc = wave_incl_scan_u32(mine);
+        if (lane == 63) sh.part[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const uint32_t x = sh.part[i];
+            if (i < wave) base += x;
+            tot += x;
+        }
+        if ((tot & 0xffffu) != K || (tot >> 16) != 2u * K) ok = false;
+        const uint32_t before = base + inc - mine;
+        uint32_t k = before & 0xffffu;
+        const uint32_t nb = before >> 16;                                       /* nodes in front of entry i0 */
+        if (l0 && k < 256u) {
+            s_pos[k] = (uint16_t)i0;
+            F::sym(sh)[k] = (uint8_t)e0;
+            s_left[k] = (uint8_t)dmin<uint32_t>(2u * nb - (uint32_t)i0, 63u);
+            k++;
+        }
+        if (l1 && k < 256u) {
+            s_pos[k] = (uint16_t)(i0 + 1);
+            F::sym(sh)[k] = (uint8_t)e1;
+            s_left[k] = (uint8_t)dmin<uint32_t>(2u * (nb + (uint32_t)n0) - (uint32_t)(i0 + 1), 63u);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                                            /* the chain (scalar: every value the same in all lanes) */
+        const uint32_t vl4 = 0xa0a0a0a0u - reinterpret_cast<const uint32_t *>(s_left)[lane];
+        uint32_t vd = 0;
+        uint32_t code = 0;
+        const uint32_t nl = uni32((K + 3u) >> 2);
+#pragma unroll 1
+        for (uint32_t l = 0; l < nl; l++) {
+            const uint32_t four = wave_lane_u32(vl4, l);
+            uint32_t pack = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t lneg = ((four >> (8u * j)) & 0xffu) - 128u;
+                const uint32_t sft = lneg - (uint32_t)__builtin_popcount(code);     /* 32 - depth */
+                code += 1u << (sft & 31u);
+                pack |= (sft & 0xffu) << (8u * j);
+            }
+            vd = ((uint32_t)lane == l) ? pack : vd;
+        }
+        uint32_t dd = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t shb = (vd >> (8u * j)) & 0xffu;
+            dd |= (shb <= 30u ? 32u - shb : 33u) << (8u * j);
+        }
+        reinterpret_cast<uint32_t *>(F::len(sh))[lane] = dd;
+    }
+    __syncthreads();
+    uint32_t d = 2;
+    bool anylong;
+    {
+        uint32_t whi = 0, wlo = 0;
+        if ((uint32_t)tid < K) {
+            d = F::len(sh)[tid];
+            if (d < 2u || d > 32u) { ok = false; d = 2; }
+            else if (d >= 16u) wlo = 1u << (32u - d);
+            else whi = 1u << (16u - d);
+        }
+        const uint32_t ihi = wave_incl_scan_u32(whi), ilo = wave_incl_scan_u32(wlo);
+        const unsigned long long lg = __ballot(d > (uint32_t)DEC_LUT_BITS);
+        if (lane == 63) {
+            s_cpart[wave] = ihi;
+            s_cpart[WAVES + wave] = ilo;
+            s_cpart[2 * WAVES + wave] = lg != 0ull;
+        }
+        __syncthreads();
+        uint64_t base = 0, tot = 0;
+        uint32_t lf = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const uint64_t x = ((uint64_t)s_cpart[i] << 16) + s_cpart[WAVES + i];
+            if (i < wave) base += x;
+            tot += x;
+            lf |= s_cpart[2 * WAVES + i];
+        }
+        anylong = uni32(lf) != 0u;
+        if (tot != (1ull << 31)) ok = false;
+        if ((uint32_t)tid < K) F::code(sh)[tid] = (uint32_t)(base + (((uint64_t)(ihi - whi)) << 16) + (ilo - wlo));
+    }
+    __syncthreads();
+    if ((uint32_t)tid < K) {                                                    /* the entry positions the depths imply are the stream's */
+        const uint32_t k = (uint32_t)tid;
+        const uint32_t bits = F::code(sh)[k] >> (32u - d);
+        const uint32_t t = (uint32_t)__builtin_ctz(~bits);
+        const uint32_t pos = s_pos[k];
+        if (k == 0 && pos != d) ok = false;
+        if (k + 1 < K) {
+            const uint32_t dn = F::len(sh)[k + 1];
+            if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
+        } else if (pos + 4u != (uint32_t)tree_len) ok = false;
+    }
+    if (anylong) ok = false;                                                    /* (uniform: codes beyond the table take the walk's child links) */
+    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    {
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
+        const uint32_t *code = F::code(sh);
+        const uint32_t x0 = (uint32_t)tid * 8u;
+        uint32_t k = dsub_leaf_of(code, K, x0 << (32 - DEC_LUT_BITS));
+        uint32_t e[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t idx = x0 + j;
+            const uint32_t v = idx << (32 - DEC_LUT_BITS);
+            if (v >> 31) {
+                /* the first bit leaves the tree (bits = 1), and so does every one bit that follows it at once (skip) */
+                const uint32_t skip = dmin<uint32_t>((uint32_t)__clz((int)~v), (uint32_t)DEC_LUT_BITS);
+                e[j] = DEC_E_BAD | DEC_E_NOCW | (skip << 8) | 1u;
+            } else {
+                while (k + 1u < K && code[k + 1u] <= v) k++;
+                e[j] = ((uint32_t)F::len(sh)[k] << 8) | (uint32_t)F::sym(sh)[k];
+            }
+        }
+        *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        __syncthreads();
+        if (SPEC) {
+            /* a failing run and the codeword behind it in ONE entry when both fit the window (dec_build_tables) */
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t ej = e[j];
+                if (ej >= DEC_E_BAD && ej < DEC_E_LONG && (ej & 0x7fu) == 1u) {
+                    const uint32_t run = dec_e_adv(ej);
+                    const uint32_t idx = x0 + j;
+                    const uint32_t e2 = sh.lut[(idx << run) & ((1u << DEC_LUT_BITS) - 1u)];
+                    if (run < (uint32_t)DEC_LUT_BITS && e2 < DEC_E_BAD && run + (e2 >> 8) <= (uint32_t)DEC_LUT_BITS)
+                        sh.lut[idx] = (uint16_t)(DEC_E_BAD | ((run + (e2 >> 8)) << 8) | 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 /* One indexed block (the body of decode_fast_kernel and of decode_fast_list_kernel). */
 template <int THREADS>
 __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64_t blk,
@@ -628,7 +827,15 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     const uint8_t *pay = tree + 2 * (int)m.tree_len;
     int leaf = m.leaf;
     int rc = HUFE_OK;
-    if (leaf < 0) rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+#ifndef DFAST_WALKED_TABLES      /* (-DDFAST_WALKED_TABLES: round 3's tables for every block, for measurements) */
+    /* (from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide next to a long
+     *  payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05, log text
+     *  1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
+    if (leaf < 0 && !(m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, tree, m.tree_len)))
+#else
+    if (leaf < 0)
+#endif
+        rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
     bool good;
     if (rc != HUFE_OK) {
         good = false;

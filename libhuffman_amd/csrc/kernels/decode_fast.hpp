@@ -169,6 +169,48 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
     const uint32_t hiQ = hi - 1u + qbase;
     uint32_t c = 0;
     DFAST_DBGW(8, 1);
+#ifndef DFAST_CHECKED_SCAN
+    if (!LONGS) {
+        /* Round 4: blocks without `long` entries (most).  The loop above asks of EVERY look-up whether it still belongs to
+         * the lane (24 vector instructions per window of two); this one only notes where the last window began that
+         * started in front of `hi` and how many did (17 per window), and that one window is then looked at again, look-up
+         * by look-up, for the end and the count.  A lane that is done walks on until its wave is (what lies there is
+         * read and ignored; the slack behind the stage and the fields behind that are LDS of this workgroup). */
+        uint32_t Qg = Q, ng = 0;
+        for (;;) {
+            const bool act = Q < hiQ;
+            if (!__any(act)) break;
+            DFAST_DBGW(9, 1);
+            Qg = act ? Q : Qg;
+            ng += act ? 1u : 0u;
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
+            const uint32_t l1 = (e1 >> 8) & 31u;
+            const uint32_t d2 = d1 << l1;
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
+            /* (a leaf or `bad` entry advances by at most DEC_LUT_BITS: the second look-up always has its whole index) */
+            Q += l1 + ((e2 >> 8) & 31u);
+        }
+        if (ng != 0u) {
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg >> 3) & ~3u);
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Qg);
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
+            const uint32_t l1 = (e1 >> 8) & 31u;
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + (((d1 << l1) >> 19) & 0x1ffeu));
+            const uint32_t l2 = (e2 >> 8) & 31u;
+            const uint32_t t1 = Qg + l1;
+            const bool take2 = t1 < hiQ && l2 != 0u;
+            c = 2u * (ng - 1u) + 1u + (take2 ? 1u : 0u);
+            Q = t1 + (take2 ? l2 : 0u);
+        } else {
+            Q = start - 1u + qbase;
+        }
+        *end = Q + 1u - qbase;
+        *cnt = c;
+        return;
+    }
+#endif
     for (;;) {
         const bool act = Q < hiQ;
         if (!__any(act)) break;

@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t dfast_run_at(uint32_t qbase, uint32_t lut_ad
  * and a stretch of any length inside the wave settles in this round.  A guess that does not hold is found out like
  * any wrong start: by the neighbour's end in the next round.  Returns (start, end, count, moved) of the lane.
  * (Out of line: it runs in the rounds after the second only, and its registers are its own.) */
-__device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, bool changed, bool dead, uint32_t hi, uint32_t pay_rel,
+__device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, bool changed, bool dead, uint32_t hi, uint32_t sb, uint32_t pay_rel,
                                              uint32_t start, uint32_t end, uint32_t cnt0)
 {
     const uint32_t lane = (uint32_t)lane_id();
@@ -301,7 +301,7 @@ __device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, 
     uint32_t cand = 0;
     if (src >= 0 && src < (int)lane && !dead && !changed) {
         /* the first codeword start at or behind my first bit: P plus a multiple of L */
-        const uint32_t lo = hi - DFAST_SUB_BITS;
+        const uint32_t lo = hi - sb;
         const uint32_t back = (lo - P) % L;
         cand = lo + (back ? L - back : 0u);
         pass = cand >= hi || (cand < pay_rel && dfast_run_at(qbase, lut_addr, cand, hi) == L);
@@ -322,9 +322,13 @@ __device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, 
 
 /* Write pass of a lane: its first `quota` symbols, from `start`, to g[0 .. quota).  Returns the position behind
  * the last one; *ok is cleared when a look-up was not a codeword (a walk out of the tree, bits past `lim`). */
+/* Round 4: `whole` = the lane may store its last, partly filled word WHOLE: the symbols behind its own are the next
+ * lane's first (the same values from whoever stores them), and they stay inside the block's output.  Its symbols then
+ * need no step-by-step tail (up to three look-ups with a bit buffer and byte stores: a third of this pass); the position
+ * behind its last symbol is the end its scan found, and the return value is not used. */
 template <int THREADS>
 __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
-                                                uint32_t start, uint32_t quota, uint32_t lim, uint8_t *g, bool *ok_out)
+                                                uint32_t start, uint32_t quota, uint32_t lim, uint8_t *g, bool *ok_out, bool whole = false)
 {
     bool ok = true;
     LinReader rd;
@@ -337,7 +341,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
     const uint32_t p0 = start;
     typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
     unaligned_u32 *gw = reinterpret_cast<unaligned_u32 *>(g + head);
-    const uint32_t words = (quota - head) >> 2;
+    const uint32_t words = whole ? (quota - head + 3u) >> 2 : (quota - head) >> 2;
     /* whole words: four table entries folded into one register, two per window, no branch; an entry that is
      * not a leaf advances like one and is only remembered */
     uint32_t Q = p0 - 1u + qbase;
@@ -375,13 +379,18 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
             p1 = rd.pos();
         }
     }
-    rd.load(p1);
-    for (uint32_t c = head + 4u * words; c < quota; c++) {
-        g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
-        if (rd.avail <= 32) rd.refill();
+    if (__ballot(!whole)) {
+        if (!whole) {
+            rd.load(p1);
+            for (uint32_t c = head + 4u * words; c < quota; c++) {
+                g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
+                if (rd.avail <= 32) rd.refill();
+            }
+            p1 = rd.pos();
+        }
     }
     *ok_out = ok;
-    return rd.pos();
+    return p1;
 }
 
 /* A block's payload (tables in sh, built by dec_build_tables<THREADS, true>).  Returns true (workgroup-uniform)
@@ -425,12 +434,30 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     while (produced < block_len) {
         if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }             /* input exhausted: the exact decoder says how */
         const uint64_t seg0 = true_start & ~31ull;
+        /* Round 4: the payload left is cut into EQUAL shares (the block index says where it ends): the last segment of a block
+         * is as full as the others instead of a quarter full on average, and every scan is that much shorter (zipf255 at
+         * 64 KiB: 3.2 segments of 288-bit shares -> 4 of 232).  The raw-stream probe does not know the end: 288 as before. */
+        uint32_t sb = DFAST_SUB_BITS;
+#ifndef DFAST_FIXED_SHARES
+        if (!end_bits) {
+            const uint64_t rem = pay_bits - seg0;
+            const uint64_t nseg = (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
+            const uint64_t even = (rem + nseg * THREADS - 1u) / (nseg * THREADS);
+            sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), DFAST_SUB_BITS);
+        }
+        sb = uni32(sb);
+#endif
+        const uint32_t need_words = uni32(dmin<uint32_t>(((uint32_t)THREADS * sb + 31u) / 32u + DFAST_SLACK_WORDS, L::STAGE_WORDS));
         __syncthreads();                                               /* the previous segment's readers are done */
+        unsigned long long pt = DPROF_T();
         {
             /* four words per thread and step from 20 bytes at a 4-byte aligned address, as decode_sub stages */
             struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
             const uint64_t byte0 = seg0 >> 3;
             constexpr uint32_t STEPS = (L::STAGE_WORDS + 4u * THREADS - 1u) / (4u * THREADS);
+#ifdef DFAST_ABLATE_STAGE
+            if (produced != 0) { } else
+#endif
             if (byte0 + 4ull * (4ull * THREADS * STEPS) + 24ull <= readable) {
                 const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));
                 const uint32_t m = (uint32_t)(a & 3u);
@@ -440,33 +467,34 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
                 uint32_t x[STEPS];
 #pragma unroll
                 for (uint32_t k = 0; k < STEPS; k++) {
-                    const uint32_t i4 = 4u * ((uint32_t)tid + (uint32_t)THREADS * k);
+                    const uint32_t i4 = dmin<uint32_t>(4u * ((uint32_t)tid + (uint32_t)THREADS * k), (need_words - 1u) & ~3u);   /* (nothing past the words the shares need) */
                     v[k] = *reinterpret_cast<const Q4 *>(qw + i4);
                     x[k] = qw[i4 + 4];
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < STEPS; k++) {
                     const uint32_t i4 = 4u * ((uint32_t)tid + (uint32_t)THREADS * k);
-                    if (i4 < L::STAGE_WORDS)
+                    if (i4 < need_words)
                         *reinterpret_cast<uint4 *>(stage + i4) =
                             make_uint4(__builtin_amdgcn_perm(v[k].y, v[k].x, sel), __builtin_amdgcn_perm(v[k].z, v[k].y, sel),
                                        __builtin_amdgcn_perm(v[k].w, v[k].z, sel), __builtin_amdgcn_perm(x[k], v[k].w, sel));
                 }
             } else {
-                for (uint32_t i = (uint32_t)tid; i < L::STAGE_WORDS; i += THREADS) stage[i] = load_be32(pay, byte0 + 4ull * i, readable);
+                for (uint32_t i = (uint32_t)tid; i < need_words; i += THREADS) stage[i] = load_be32(pay, byte0 + 4ull * i, readable);
             }
         }
         __syncthreads();
+        DPROF_ADD(1, pt); pt = DPROF_T();
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);   /* payload bits from seg0 on */
         const uint32_t first = (uint32_t)(true_start - seg0);
-        const uint32_t hi = ((uint32_t)tid + 1u) * DFAST_SUB_BITS;
+        const uint32_t hi = ((uint32_t)tid + 1u) * sb;
         /* speculation: every lane but the first starts at its own first bit - a decoder that starts anywhere falls
          * into step within a few codewords, and a lane that has not is found out below */
-        uint32_t start = tid == 0 ? first : hi - DFAST_RUNIN;
+        uint32_t start = tid == 0 ? first : hi - sb;
         /* a lane whose share lies behind the payload holds nothing and ends where its share ends (the block's last
          * segment is a quarter full on average: its other lanes scanned what follows the block, and passed every
          * change of their neighbour's on) */
-        bool dead = hi - DFAST_SUB_BITS >= pay_rel;
+        bool dead = hi - sb >= pay_rel;
         const uint64_t remaining = block_len - produced;
         /* A caller that does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the
          * stream) has no dead lanes by the test above, and the lanes behind the block's last symbol scan the next
@@ -479,8 +507,8 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             const float est = (float)remaining * ((float)true_start / (float)produced);
             const float lim_f = (float)first + est * 1.0625f + 1024.0f;
             const uint32_t bound = lim_f < 4.0e9f ? (uint32_t)lim_f : 0xffffffffu;
-            if (!dead && hi - DFAST_SUB_BITS >= bound) dead = true;
-            guessed = (uint32_t)(THREADS - 1) * DFAST_SUB_BITS >= bound;
+            if (!dead && hi - sb >= bound) dead = true;
+            guessed = (uint32_t)(THREADS - 1) * sb >= bound;
         }
         uint32_t end = hi, cnt = 0;
 #if DFAST_PRE
@@ -491,7 +519,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
          * with the compacted rescans below it does.  Not for codes of ONE length that divides the share (uniform bytes:
          * 32 codes of 9 bits): there every share's first bit IS a codeword start. */
         if (pre != 0u && __ballot(!dead && tid != 0)) {
-            const uint32_t lo = hi - DFAST_SUB_BITS;
+            const uint32_t lo = hi - sb;
             const uint32_t from = (lo >= first + pre) ? lo - pre : first;
             const bool walk = !dead && tid != 0;
             uint32_t e0 = lo, c0 = 0;
@@ -552,7 +580,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
                 if ((uint32_t)tid < ((n + 63u) & ~63u)) {              /* (whole waves) */
                     const bool mine = (uint32_t)tid < n;
                     const uint32_t li = mine ? clist[tid] : 0u;
-                    const uint32_t hi_li = (li + 1u) * DFAST_SUB_BITS;
+                    const uint32_t hi_li = (li + 1u) * sb;
                     const uint32_t st = li ? cE[li - 1u] : first;
                     uint32_t e2 = hi_li, c2 = 0;
                     if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, mine ? st : hi_li, hi_li, lim, &e2, &c2);
@@ -576,6 +604,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
 #endif
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
+        DPROF_ADD(2, pt); pt = DPROF_T();
         int rounds = 0;
         for (;;) {
             /* left neighbour's end: a DPP move inside the wave, LDS across the wave seams */
@@ -593,7 +622,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             /* ---- runs of one byte value (only when the starts have not settled in two rounds): dfast_run_jump ---- */
             int jumped = 0;
             if (rounds >= 1 && __ballot(changed != 0)) {
-                const uint4 r = dfast_run_jump(qbase, lut_addr, changed != 0, dead, hi, pay_rel, start, end, cnt);
+                const uint4 r = dfast_run_jump(qbase, lut_addr, changed != 0, dead, hi, sb, pay_rel, start, end, cnt);
                 start = r.x; end = r.y; cnt = r.z; jumped = (int)r.w;
             }
             if (lane == 63) sh.wend[wave] = end;
@@ -602,6 +631,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             if (++rounds > DFAST_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }    /* (uniform: every thread counts the same rounds) */
         }
         if (!ok) break;
+        DPROF_ADD(3, pt); pt = DPROF_T();
         uint32_t seg_total;
         const uint32_t ex = block_excl_scan_u32<THREADS>(cnt, sh.part, seg_total);
         seg_total = uni32(seg_total);
@@ -618,9 +648,21 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             quota = take - ex;
             if (quota > cnt) quota = cnt;
         }
+        DPROF_ADD(4, pt); pt = DPROF_T();
         bool lane_ok = true;
+#ifdef DFAST_ABLATE_WRITE          /* (timing experiments: no write pass; the output is wrong) */
+        if (false) {
+#else
         if (quota) {
-            const uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok);
+#endif
+#ifndef DFAST_EXACT_TAILS
+            /* (all of the lane's symbols, and the whole last word still inside this block's output) */
+            const bool whole = quota == cnt && produced + ex + ((quota + 3u) & ~3u) <= block_len;
+#else
+            const bool whole = false;
+#endif
+            uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok, whole);
+            if (whole) qe = end;
 #ifdef DFAST_DEBUG
             if (!lane_ok) atomicAdd(&g_dfast_dbg[4], 1ull);
             if (qe > pay_rel) atomicAdd(&g_dfast_dbg[5], 1ull);
@@ -630,6 +672,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         }
         const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
         if (!__syncthreads_and(lane_ok ? 1 : 0)) { ok = false; DFAST_DBG(2, 1); break; }
+        DPROF_ADD(5, pt);
         DFAST_DBG(11, 1);
         produced += take;
         if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }                          /* (no progress: cannot happen on a track that holds codewords) */
@@ -869,6 +912,7 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     const uint8_t *pay = tree + 2 * (int)m.tree_len;
     int leaf = m.leaf;
     int rc = HUFE_OK;
+    unsigned long long kt = DPROF_T();
 #ifndef DFAST_WALKED_TABLES      /* (-DDFAST_WALKED_TABLES: round 3's tables for every block, for measurements) */
     /* (from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide next to a long
      *  payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05, log text
@@ -878,6 +922,7 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     if (leaf < 0)
 #endif
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+    DPROF_ADD(6, kt);
     bool good;
     if (rc != HUFE_OK) {
         good = false;
@@ -887,6 +932,9 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     } else {
         good = decode_payload_fast<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase);
     }
+#if defined(DFAST_ABLATE_WRITE) || defined(DFAST_ABLATE_STAGE) || defined(DFAST_ABLATE_SCANS)
+    good = true;
+#endif
     if (!good && tid == 0) {
         if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
     }

@@ -169,12 +169,13 @@ template <int THREADS>
 struct DecShared {
     static constexpr int ENT = HUF_TREE_MAX + 1;
     static constexpr int COLS = THREADS + DEC_XCOLS;
-    int16_t ent[ENT];
     uint32_t lr[ENT];                    /* children of entry i: left in the low half, right in the high half, DEC_NULL = none */
     uint16_t lut[1 << DEC_LUT_BITS];
     __attribute__((aligned(16))) uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
                                             (a padded linear layout has a cheaper address but costs 2 KiB = one workgroup per CU) */
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
+    int16_t ent[ENT];                    /* the tree's entries (behind the marks: decode_fast_kernel's table of pairs runs on into it when the
+                                            block has no codes that need the entries, decode_fast.hpp) */
     uint32_t wend[THREADS / 64];         /* end position of the last lane of each wave (neighbours use shuffles) */
     uint32_t part[THREADS / 64];
     uint32_t wtile[32];                  /* decode_sub: payload bits of the chunk's wave tiles */

@@ -43,16 +43,15 @@ namespace hufgpu {
                                                        rescans as long as its slowest lane - zipf255 1.87 -> 2.12 ms; codes of one length,
                                                        uniform bytes, never fall into step at all) */
 #define DFAST_MAX_ROUNDS 64
-#ifndef DFAST_PRE
-#define DFAST_PRE 0u                                 /* bits in front of a share its lane walks before the first scan (0: round 3's form, the default:
-                                                       96 / 128 / 192 bits alone 1.72 -> 1.74 / 1.71 / 1.66 ms per GiB on zipf255, uniform bytes worse) */
+#ifndef DFAST_PAIRS_FROM
+#define DFAST_PAIRS_FROM 32768u                      /* symbols of a block from which its scans read the table of pairs (dfast_pair_table) */
 #endif
-#ifndef DFAST_COMPACT_ROUNDS
-#define DFAST_COMPACT_ROUNDS 0                       /* rounds of compacted rescans in front of the round loop (needs DFAST_PRE; 0: none, the default.
-                                                       Measured with DFAST_PRE = 64 / 96 / 128 and 3 rounds: 1.91 / 1.81 / 1.77 ms per GiB on zipf255 against 1.73
-                                                       without, uniform255 1.43 -> 1.60-2.02: ONE wave's scan takes as long as all eight waves' - what compaction
-                                                       saves is instruction issue, and what this kernel waits for is the latency of a scan and its barriers) */
+#ifndef DFAST_JUMP_FROM_ROUND
+#define DFAST_JUMP_FROM_ROUND 1                      /* the round loop's pass from which runs of one byte value are looked for (dfast_run_jump) */
 #endif
+/* (Round 4 also measured, and dropped again: a run-in of 96-192 bits in FRONT of a share before its first scan - 1.72 -> 1.66 ms per
+ *  GiB on zipf255, 1.11 -> 1.31-1.54 on uniform bytes - and the same with the moved starts compacted into one wave's rescan - 1.73 ->
+ *  1.77-1.91: profiles/r04/dfast_pre_runin.txt, dfast_compact.txt.) */
 
 template <int THREADS>
 struct DfastLds {
@@ -62,6 +61,13 @@ struct DfastLds {
     static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
     static_assert(STAGE_WORDS + 4u <= AREA_WORDS, "the linear stage fits the area of the interleaved stage and its marks");
     static_assert(offsetof(DecShared<THREADS>, pay) % 16 == 0, "16-byte stage stores");
+    /* the table of pairs (dfast_pair_table) behind the stage: the rest of the marks' area and the first entries of `ent` */
+    static constexpr uint32_t PAIR_WORD = STAGE_WORDS + 4u;
+    static constexpr uint32_t PAIR_WORDS = (1u << DEC_LUT_BITS) / 2u;
+    static_assert(offsetof(DecShared<THREADS>, ent) == offsetof(DecShared<THREADS>, mark) + sizeof(DecShared<THREADS>::mark), "ent runs on from the marks");
+    static_assert((PAIR_WORD + PAIR_WORDS) * 4u <= sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark) + sizeof(DecShared<THREADS>::ent), "the pairs fit");
+    static_assert((PAIR_WORD * 4u) % 16u == 0u, "16-byte stores of the pairs");
+    __device__ static __forceinline__ uint16_t *pairs(DecShared<THREADS> &sh) { return reinterpret_cast<uint16_t *>(sh.pay + PAIR_WORD); }
 };
 
 #ifdef DFAST_DEBUG
@@ -156,26 +162,58 @@ __device__ __forceinline__ uint32_t dfast_next(const DecShared<THREADS> &sh, Lin
 typedef const __attribute__((address_space(3))) uint32_t *dfast_lds_words;
 typedef const __attribute__((address_space(3))) uint16_t *dfast_lds_halves;
 
+/* Round 4, the table the scans of a block WITHOUT `long` entries read: what the next 12 bits hold as a whole.
+ *   P[x] = (bits of the first codeword in the 12 bits x, and of the second if it lies completely inside) | (how many) << 12
+ * for zipf255 1.5 codewords a look-up, for log text 1.9 (uniform bytes: one, their codes have 8 bits); a `bad` entry of the
+ * table of single codewords (decode.hpp) is one look-up that advances by its `skip`, as it is there.  The kernel is bound
+ * by vector instruction issue (46 a symbol, 21 of them in the scans): the sum of the entries a track has met IS its
+ * position (low 12 bits) and its count (the bits above), one v_add3_u32 for two look-ups.
+ * Eight entries per thread; P lies behind the stage (DfastLds::pairs). */
+template <int THREADS>
+__device__ __forceinline__ void dfast_pair_table(DecShared<THREADS> &sh)
+{
+    static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
+    constexpr uint32_t MASK = (1u << DEC_LUT_BITS) - 1u;
+    const uint32_t x0 = (uint32_t)threadIdx.x * 8u;
+    uint32_t p[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t idx = x0 + j;
+        const uint32_t e = sh.lut[idx];
+        const uint32_t len = dec_e_adv(e);
+        const uint32_t e2 = sh.lut[(idx << len) & MASK];                   /* the bits behind, zeros behind those: right for a codeword that ends inside */
+        const bool two = e < DEC_E_BAD && e2 < DEC_E_BAD && len + (e2 >> 8) <= (uint32_t)DEC_LUT_BITS;
+        p[j] = two ? (len + (e2 >> 8)) | 0x2000u : len | 0x1000u;
+    }
+    *reinterpret_cast<uint4 *>(DfastLds<THREADS>::pairs(sh) + x0) = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+}
+
 /* One scan of a lane: from `start` to the first codeword start at or behind `hi` (positions are bits of the
  * staged segment).  *end = that position, *cnt = table look-ups taken on the way (= codewords on a track that
  * meets no walk out of the tree; the write pass checks that).  qbase = 8 x the LDS byte address of the stage,
- * lut_addr = the LDS byte address of the table.  LONGS = the block's table has `long` entries (codes of more
- * than 12 bits, walked bit by bit behind a ballot); blocks without them - most - run the loop without the test. */
-template <int THREADS, bool LONGS>
-__device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
+ * lut_addr = the LDS byte address of the table, pair_addr = that of the table of pairs.
+ *   DFAST_LONGS (the block's table has `long` entries: codes of more than 12 bits, walked bit by bit behind a ballot):
+ * look-up by look-up in the table of single codewords, every one asked whether it still is the lane's.
+ *   DFAST_PAIRS (blocks of 32 KiB and more with codes of six bits and less: most): window by window - two look-ups
+ * in the table of pairs, up to four codewords, 13 vector instructions - as long as a window BEGINS in front of `hi`;
+ * the last window is then looked at again, codeword by codeword, for the end and the count.
+ *   DFAST_SINGLES (the rest): the same with the table of single codewords.  (The end has to be the TRACK's - the first codeword start at or behind `hi`
+ * - and not the end of whatever window crossed `hi`: two tracks that have met have the same codewords, not the
+ * same windows, and an end that depends on the windows moves every lane to the right of a lane that moved.) */
+enum { DFAST_SINGLES = 0, DFAST_LONGS = 1, DFAST_PAIRS = 2 };
+template <int THREADS, int MODE>
+__device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr, uint32_t pair_addr,
                                            uint32_t start, uint32_t hi, uint32_t lim, uint32_t *end, uint32_t *cnt)
 {
+    constexpr bool LONGS = MODE == DFAST_LONGS;
     uint32_t Q = start - 1u + qbase;                 /* (position - 1) + 8 x stage address: see decode_sub.hpp */
     const uint32_t hiQ = hi - 1u + qbase;
     uint32_t c = 0;
     DFAST_DBGW(8, 1);
 #ifndef DFAST_CHECKED_SCAN
-    if (!LONGS) {
-        /* Round 4: blocks without `long` entries (most).  The loop above asks of EVERY look-up whether it still belongs to
-         * the lane (24 vector instructions per window of two); this one only notes where the last window began that
-         * started in front of `hi` and how many did (17 per window), and that one window is then looked at again, look-up
-         * by look-up, for the end and the count.  A lane that is done walks on until its wave is (what lies there is
-         * read and ignored; the slack behind the stage and the fields behind that are LDS of this workgroup). */
+    if (MODE == DFAST_SINGLES) {
+        /* the same with the table of single codewords (blocks whose codes are too long for pairs, small blocks): two
+         * look-ups, two codewords and 17 vector instructions per window */
         uint32_t Qg = Q, ng = 0;
         for (;;) {
             const bool act = Q < hiQ;
@@ -189,7 +227,8 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             const uint32_t l1 = (e1 >> 8) & 31u;
             const uint32_t d2 = d1 << l1;
             const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
-            /* (a leaf or `bad` entry advances by at most DEC_LUT_BITS: the second look-up always has its whole index) */
+            /* (a leaf or `bad` entry advances by at most DEC_LUT_BITS: the second look-up always has its whole index.)  A lane
+             * that is done walks on until its wave is: what lies there is read and ignored. */
             Q += l1 + ((e2 >> 8) & 31u);
         }
         if (ng != 0u) {
@@ -205,6 +244,52 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             Q = t1 + (take2 ? l2 : 0u);
         } else {
             Q = start - 1u + qbase;
+        }
+        *end = Q + 1u - qbase;
+        *cnt = c;
+        return;
+    }
+    if (MODE == DFAST_PAIRS) {
+        const uint32_t Q0 = Q;
+        uint32_t S = 0, Sg = 0;                      /* the entries met: bits in the low 12 bits (a share and a window: < 4 096), codewords above */
+        for (;;) {
+            const bool act = Q < hiQ;
+            if (!__any(act)) break;
+            DFAST_DBGW(9, 1);
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d1 >> 19) & 0x1ffeu));
+            const uint32_t d2 = d1 << (e1 & 31u);      /* (v_lshlrev_b32 takes the low five bits itself) */
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d2 >> 19) & 0x1ffeu));
+            /* (an entry advances by at most DEC_LUT_BITS: the second look-up always has its whole index.)  A lane that is done
+             * stands still while its wave walks on. */
+            if (act) {
+                Sg = S;
+                S += e1 + e2;
+            }
+            Q = Q0 + (S & 0xfffu);
+        }
+        const bool any = S != 0u;                      /* (every entry counts at least one) */
+        if (__ballot(any)) {
+            /* the last window again: its codewords start at Qg, b1 (the first entry's second, if it has one), b2, b3 (the
+             * second entry's second) and the window ends at b4 >= hi */
+            const uint32_t Qg = Q0 + (Sg & 0xfffu);
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg >> 3) & ~3u);
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Qg);
+            const uint32_t i1 = (d1 >> 19) & 0x1ffeu;
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(pair_addr + i1);
+            const uint32_t a1 = (*(dfast_lds_halves)(uintptr_t)(lut_addr + i1) >> 8) & 31u;
+            const uint32_t i2 = ((d1 << (e1 & 31u)) >> 19) & 0x1ffeu;
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(pair_addr + i2);
+            const uint32_t a2 = (*(dfast_lds_halves)(uintptr_t)(lut_addr + i2) >> 8) & 31u;
+            const uint32_t b1 = Qg + a1, b2 = Qg + (e1 & 31u), b3 = b2 + a2, b4 = b2 + (e2 & 31u);
+            const bool in1 = b1 < hiQ, in2 = b2 < hiQ, in3 = b3 < hiQ;
+            const uint32_t endQ = !in1 ? b1 : !in2 ? b2 : !in3 ? b3 : b4;
+            const uint32_t cn = (Sg >> 12) + 1u + ((in1 && (e1 & 0x2000u)) ? 1u : 0u) + (in2 ? 1u : 0u) + ((in3 && (e2 & 0x2000u)) ? 1u : 0u);
+            if (any) {
+                Q = endQ;
+                c = cn;
+            }
         }
         *end = Q + 1u - qbase;
         *cnt = c;
@@ -411,26 +496,30 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;                  /* bits a walk may look at */
     /* does the table hold `long` entries at all?  (eight entries per thread) */
-    bool longs;
+    bool longs, pairs = false;
     {
         const uint32_t *t = reinterpret_cast<const uint32_t *>(sh.lut) + 4 * tid;      /* (the table is 4-byte aligned) */
-        const uint32_t any = (t[0] | t[1] | t[2] | t[3]) & 0x80008000u;   /* bit 15: long (bad entries have bit 14 only) */
+        const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+        const uint32_t any = (t0 | t1 | t2 | t3) & 0x80008000u;            /* bit 15: long (bad entries have bit 14 only) */
         static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && DEC_E_LONG == 0xC000u && DEC_E_BAD == 0x4000u, "eight entries per thread");
         longs = __syncthreads_or(any != 0u) != 0;
+#ifndef DFAST_CHECKED_SCAN
+        /* the table of pairs pays for itself (its build, the longer look at a scan's last window) when codewords are short
+         * enough to come in pairs - one of six bits or less: it fits the 12 bits twice - and the block is long enough
+         * (1 GiB: zipf255 1.63 -> 1.54 ms, log text 1.53 -> 1.47; uniform bytes, without a pair, 1.03 -> 1.08 with it, zipf255 in
+         * 16 KiB blocks 2.97 -> 3.06: those keep the table of singles) */
+        if (!longs && block_len >= DFAST_PAIRS_FROM) {
+            const uint32_t m = dmin<uint32_t>(dmin<uint32_t>(dmin<uint32_t>(t0 & 0xffffu, t0 >> 16), dmin<uint32_t>(t1 & 0xffffu, t1 >> 16)),
+                                              dmin<uint32_t>(dmin<uint32_t>(t2 & 0xffffu, t2 >> 16), dmin<uint32_t>(t3 & 0xffffu, t3 >> 16)));
+            pairs = __syncthreads_or(m < 0x0700u) != 0;                     /* a leaf is (bits << 8) | byte */
+        }
+#endif
     }
+    const uint32_t pair_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)L::pairs(sh);
+    if (pairs) dfast_pair_table<THREADS>(sh);                          /* (read behind the stage's first barrier) */
     uint64_t true_start = 0, produced = 0;
     bool ok = true;
     bool trust = true;                                                 /* (uniform) guesses at the block's end are allowed */
-#if DFAST_PRE
-    uint32_t pre = DFAST_PRE;
-    if (!end_bits && block_len != 0) {
-        /* whole bits per symbol (up to the last byte's padding), and that many dividing the share: codes of one length */
-        const uint64_t per = pay_bits / block_len;
-        if (per != 0 && pay_bits - per * block_len < 8u && DFAST_SUB_BITS % (uint32_t)per == 0u) pre = 0;
-    }
-    if (end_bits) pre = 0;                                             /* (the raw-stream probe keeps round 3's form) */
-    pre = uni32(pre);
-#endif
     while (produced < block_len) {
         if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }             /* input exhausted: the exact decoder says how */
         const uint64_t seg0 = true_start & ~31ull;
@@ -511,26 +600,10 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             guessed = (uint32_t)(THREADS - 1) * sb >= bound;
         }
         uint32_t end = hi, cnt = 0;
-#if DFAST_PRE
-        /* Round 4: the speculation begins DFAST_PRE bits in FRONT of the share (its left neighbour's last bits): a lane
-         * that walks those first stands on a codeword start of the real track when it reaches its own share in 97-99 % of
-         * all cases (tools/sim/sim_sync.py), where the share's own first bit is one in 13 %.  On its own that buys little
-         * (nearly every WAVE still holds a lane whose start moves, and scans again as a whole: 1.72 -> 1.66 ms per GiB);
-         * with the compacted rescans below it does.  Not for codes of ONE length that divides the share (uniform bytes:
-         * 32 codes of 9 bits): there every share's first bit IS a codeword start. */
-        if (pre != 0u && __ballot(!dead && tid != 0)) {
-            const uint32_t lo = hi - sb;
-            const uint32_t from = (lo >= first + pre) ? lo - pre : first;
-            const bool walk = !dead && tid != 0;
-            uint32_t e0 = lo, c0 = 0;
-            if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, walk ? from : lo, lo, lim, &e0, &c0);
-            else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, walk ? from : lo, lo, lim, &e0, &c0);
-            if (walk && e0 < hi) start = e0;
-        }
-#endif
         if (__ballot(!dead)) {
-            if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
-            else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            if (longs) dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            else if (pairs) dfast_scan<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            else dfast_scan<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
             if (dead) { end = hi; cnt = 0; }
         }
         /*  - after it: the speculative counts are right to a few symbols either way; a lane in front of which they
@@ -545,63 +618,6 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             }
             guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
         }
-#if DFAST_COMPACT_ROUNDS && DFAST_PRE
-        /* Round 4: the lanes whose start has to move are few once the speculation begins in front of the share (2-3 %);
-         * left to their waves they cost a whole scan of every wave that holds one.  COMPACTED into the first lanes of the
-         * workgroup they cost one wave's scan: ends, starts and counts pass through LDS (the area behind the stage).
-         * Only a lane whose LEFT neighbour's start stands is taken (its new start then is final unless something further
-         * left still moves); what has not settled after DFAST_COMPACT_ROUNDS rounds - runs of one byte value, codes
-         * that fall into step slowly - is the loop's below, which also has the last word on "nothing moves any more". */
-        if (!end_bits && pre != 0u) {
-            uint32_t *cE = stage + L::STAGE_WORDS + 4u;                /* [THREADS] a lane's end */
-            uint32_t *cS = cE + THREADS;                               /* [THREADS] start << 10 | count of a lane scanned again */
-            uint16_t *clist = reinterpret_cast<uint16_t *>(cS + THREADS);
-            static_assert(L::STAGE_WORDS + 4u + 2u * THREADS + THREADS / 2u <= L::AREA_WORDS, "the compaction's arrays fit behind the stage");
-            cE[tid] = end;
-            if (tid == 0) sh.firstone = 0;
-            __syncthreads();
-            for (int cr = 0; cr < DFAST_COMPACT_ROUNDS; cr++) {
-                const uint32_t ns = tid ? cE[tid - 1] : first;
-                const bool bad = !dead && ns != start;
-                const unsigned long long bm = __ballot(bad);
-                if (lane == 63) sh.part[wave] = (uint32_t)(bm >> 63);
-                if (!__syncthreads_or(bad ? 1 : 0)) break;
-                const bool left_bad = lane ? ((bm >> (lane - 1)) & 1ull) != 0ull : (tid != 0 && sh.part[wave - 1] != 0u);
-                const bool fixme = bad && !left_bad;
-                {
-                    const unsigned long long m = __ballot(fixme);
-                    uint32_t base = 0;
-                    if (lane == 0 && m) base = atomicAdd(&sh.firstone, (uint32_t)__popcll(m));
-                    base = wave_lane_u32(base, 0);
-                    if (fixme) clist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-                }
-                __syncthreads();
-                const uint32_t n = uni32(sh.firstone);
-                if ((uint32_t)tid < ((n + 63u) & ~63u)) {              /* (whole waves) */
-                    const bool mine = (uint32_t)tid < n;
-                    const uint32_t li = mine ? clist[tid] : 0u;
-                    const uint32_t hi_li = (li + 1u) * sb;
-                    const uint32_t st = li ? cE[li - 1u] : first;
-                    uint32_t e2 = hi_li, c2 = 0;
-                    if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, mine ? st : hi_li, hi_li, lim, &e2, &c2);
-                    else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, mine ? st : hi_li, hi_li, lim, &e2, &c2);
-                    if (mine) {
-                        cS[li] = (st << 10) | (c2 & 1023u);
-                        cE[li] = e2;
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) sh.firstone = 0;
-                if (fixme) {
-                    const uint32_t v = cS[tid];
-                    start = v >> 10;
-                    cnt = v & 1023u;
-                    end = cE[tid];
-                }
-            }
-            __syncthreads();                                           /* (sh.part is the sums' again below) */
-        }
-#endif
         if (lane == 63) sh.wend[wave] = end;
         __syncthreads();
         DPROF_ADD(2, pt); pt = DPROF_T();
@@ -613,15 +629,18 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             const int changed = (ns != start) && !dead;
             __syncthreads();                                           /* everyone has read sh.wend */
             if (__ballot(changed != 0)) {
+                DFAST_DBGW(rounds == 0 ? 6 : rounds == 1 ? 7 : 14, 1);
                 if (changed) start = ns;
                 uint32_t e2 = end, c2 = cnt;
-                if (longs) dfast_scan<THREADS, true>(sh, stage, qbase, lut_addr, changed ? start : hi, hi, lim, &e2, &c2);
-                else dfast_scan<THREADS, false>(sh, stage, qbase, lut_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                if (longs) dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                else if (pairs) dfast_scan<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                else dfast_scan<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
                 if (changed) { end = e2; cnt = c2; }
             }
             /* ---- runs of one byte value (only when the starts have not settled in two rounds): dfast_run_jump ---- */
             int jumped = 0;
-            if (rounds >= 1 && __ballot(changed != 0)) {
+            if (rounds >= DFAST_JUMP_FROM_ROUND && __ballot(changed != 0)) {
+                DFAST_DBGW(15, 1);
                 const uint4 r = dfast_run_jump(qbase, lut_addr, changed != 0, dead, hi, sb, pay_rel, start, end, cnt);
                 start = r.x; end = r.y; cnt = r.z; jumped = (int)r.w;
             }

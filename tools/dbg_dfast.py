@@ -34,4 +34,5 @@ for wl in [a for a in sys.argv[1:] if a != "--raw"] or ["zipf255", "uniform256"]
     a = list(arr)
     print(wl, "blocks", nb, "fail: exhausted", a[0], "rounds", a[1], "lane_ok", a[2], "take0", a[3], "| lanes !ok", a[4], "lanes exh", a[5],
           "| scan calls/blk %.1f iters/call %.1f rounds/blk %.2f segments/blk %.2f" % (a[8] / nb, a[9] / max(a[8], 1), a[10] / nb, a[11] / nb),
+          "| waves that scan again in round 0 / 1 / later, per segment: %.2f %.2f %.2f, run_jump calls %.2f" % tuple(a[i] / max(a[11], 1) for i in (6, 7, 14, 15)),
           "| segments with a guessed end", a[12], "done again", a[13], "equal", torch.equal(back, data))

@@ -1119,13 +1119,28 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
             HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
             ctx->disc_cands = cap;
         }
-        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks);
+        /* (the candidates' block_len fields pass through d_cand_end, which the probes then overwrite with the ends) */
+        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks, ctx->d_cand_end);
         DISC_TRACE("discover write done");
-        cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(st, ctx->d_cand, ncand, ctx->d_spec_off);
+        cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_cand_end, ncand, ctx->d_spec_off);
         probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap);
         DISC_TRACE("probe done");
         link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
         DISC_TRACE("link done");
+#ifdef DISC_DEBUG
+        if (ncand <= 32) {
+            uint64_t hc[32], he[32], ho[33]; int32_t hs[32]; uint32_t hn[32];
+            (void)hipMemcpy(hc, ctx->d_cand, ncand * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(he, ctx->d_cand_end, ncand * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ho, ctx->d_spec_off, (ncand + 1) * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hs, ctx->d_cand_status, ncand * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hn, ctx->d_nxt, ncand * 4, hipMemcpyDeviceToHost);
+            for (uint64_t i = 0; i < ncand; i++)
+                fprintf(stderr, "disc: cand %llu at %llu end %llu status %d nxt %u spec_off %llu\n", (unsigned long long)i, (unsigned long long)hc[i],
+                        (unsigned long long)he[i], hs[i], hn[i], (unsigned long long)ho[i]);
+            fprintf(stderr, "disc: spec_off total %llu out_cap %llu length %llu\n", (unsigned long long)ho[ncand], (unsigned long long)out_cap, (unsigned long long)length);
+        }
+#endif
         walk_kernel<<<dim3(1), dim3(WALK_THREADS), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
         DISC_TRACE("walk done");
         HIP_OK(ctx, hipGetLastError());

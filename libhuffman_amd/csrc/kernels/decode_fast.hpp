@@ -484,8 +484,11 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
  * payload is never part of a track that passes the checks, so it need not be zeroed). */
 template <int THREADS>
 __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
-                                    uint8_t *gout, uint64_t *end_bits = nullptr)
+                                    uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
 {
+    /* end_bits: the caller does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the stream) and
+     * wants to be told.  hint_bytes (with end_bits): where it probably ends - the next header candidate; taken for the end
+     * as the guesses below are, and given up like them by the segment whose symbols come short of the block. */
     typedef DfastLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
@@ -527,9 +530,10 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
          * is as full as the others instead of a quarter full on average, and every scan is that much shorter (zipf255 at
          * 64 KiB: 3.2 segments of 288-bit shares -> 4 of 232).  The raw-stream probe does not know the end: 288 as before. */
         uint32_t sb = DFAST_SUB_BITS;
+        const bool hinted = uni32((end_bits && trust && hint_bytes * 8ull > seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
 #ifndef DFAST_FIXED_SHARES
-        if (!end_bits) {
-            const uint64_t rem = pay_bits - seg0;
+        if (!end_bits || hinted) {
+            const uint64_t rem = (hinted ? hint_bytes * 8ull : pay_bits) - seg0;
             const uint64_t nseg = (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
             const uint64_t even = (rem + nseg * THREADS - 1u) / (nseg * THREADS);
             sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), DFAST_SUB_BITS);
@@ -592,6 +596,12 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
          * done again without guessing):
          *  - before the first scan: the bits per symbol of the block so far, a sixteenth more, and 1 024 bits; */
         bool guessed = false;                                          /* (uniform) lanes may have been taken for dead */
+        if (hinted) {
+            /* (round 4) the next candidate's offset: nearly always the end, and then this is the indexed decoder's segment */
+            const uint32_t bound = (uint32_t)dmin<uint64_t>(hint_bytes * 8ull - seg0, 0xfffffff0ull);
+            if (!dead && hi - sb >= bound) dead = true;
+            guessed = (uint32_t)(THREADS - 1) * sb >= bound;
+        } else
         if (end_bits && trust && produced != 0) {
             const float est = (float)remaining * ((float)true_start / (float)produced);
             const float lim_f = (float)first + est * 1.0625f + 1024.0f;
@@ -608,7 +618,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         }
         /*  - after it: the speculative counts are right to a few symbols either way; a lane in front of which they
          *    already hold the rest of the block and a margin is taken for dead. */
-        if (end_bits && trust) {
+        if (end_bits && trust && !hinted) {
             uint32_t spec_total;
             const uint32_t exs = block_excl_scan_u32<THREADS>(cnt, sh.part, spec_total);
             if (!dead && (uint64_t)exs >= remaining + 128u + ((uint32_t)tid >> 2)) {

@@ -61,6 +61,31 @@ __device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl
     const int nact = __popcll(__ballot(1));
     int open = 1;                                                /* child slots still to be filled */
     bool bad = false;
+    if (nact == 64 && tl <= HUF_TREE_MAX) {
+        /* Round 4: a whole wave (all but the stream's last).  The loop below fetches 64 entries, sums, fetches the next 64: seventeen
+         * memory round trips for the 1 021 entries of a 255-symbol tree, 24 us in which the wave's workgroup keeps its place on
+         * the CU - and every real header costs one such check: 16 384 of them were three quarters of the kernel's 260 us per GiB.
+         * Here every lane asks for all of its entries first (one round trip), the sums are DPP scans. */
+        typedef uint16_t __attribute__((aligned(1))) unaligned_u16;
+        constexpr int STEPS = (HUF_TREE_MAX + 63) / 64;
+        uint32_t e[STEPS];
+#pragma unroll
+        for (int j = 0; j < STEPS; j++) {
+            const int i = j * 64 + lane;
+            e[j] = (i < tl) ? (uint32_t)*reinterpret_cast<const unaligned_u16 *>(t + 2 * i) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < STEPS; j++) {
+            if (j * 64 < tl) {                                   /* uniform */
+                const int i = j * 64 + lane;
+                const int d = (i < tl) ? ((e[j] != 0xffffu) ? 1 : -1) : 0;
+                const int inc = (int)wave_incl_scan_u32((uint32_t)d);
+                if (i < tl && open + inc - d <= 0) bad = true;       /* an entry behind a complete tree */
+                open += (int)wave_lane_u32((uint32_t)inc, 63);
+            }
+        }
+        return __ballot(bad) == 0ull && open == 0;
+    }
     for (int base = 0; base < tl; base += nact) {                /* uniform */
         const int i = base + lane;
         int d = 0;
@@ -83,7 +108,8 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                                                                 uint32_t *__restrict__ wg_counts,
                                                                 const uint64_t *__restrict__ wg_base,
                                                                 uint64_t *__restrict__ cand,
-                                                                uint64_t *__restrict__ masks)
+                                                                uint64_t *__restrict__ masks,
+                                                                uint64_t *__restrict__ cand_len = nullptr)
 {
     /* A thread owns DISC_ITERS consecutive 16-byte pieces (thread order = stream order, one scan
      * per workgroup of 16 KiB: with 4 KiB workgroups the kernel was bound by their dispatch). */
@@ -176,7 +202,11 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
         while (mask) {
             const int k = __builtin_ctzll(mask);
             mask &= mask - 1;
-            cand[at++] = t0 + (uint64_t)k;
+            cand[at] = t0 + (uint64_t)k;
+            /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
+             * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> ... us) */
+            cand_len[at] = load_u64_unaligned(stream + t0 + (uint64_t)k);
+            at++;
         }
     }
 }
@@ -192,12 +222,11 @@ __global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__
 /* Where the output of candidate i would start if every candidate were a block of the stream, in
  * order: the exclusive prefix sum of the block_len fields (ONE workgroup; spec_off[ncand] = sum). */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint8_t *__restrict__ stream,
-                                                            const uint64_t *__restrict__ cand, uint64_t ncand,
+__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint64_t *__restrict__ cand_len, uint64_t ncand,
                                                             uint64_t *__restrict__ spec_off)
 {
     const uint64_t total = chunked_excl_scan<THREADS>(ncand, spec_off, [=](uint64_t i) {
-        return load_u64_unaligned(stream + cand[i]);
+        return cand_len[i];
     });
     if (threadIdx.x == 0) spec_off[ncand] = total;
 }
@@ -228,8 +257,13 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
 #ifndef PROBE_EXACT_ONLY
     if (store && block_len != 0 && tl >= 9 && pay0 <= avail) {
         int leaf = -1;
-        if (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0 &&
-            decode_payload_fast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits)) {
+        /* (round 4) the tables from the tree's shape where decode_fast_kernel takes them from it, and the next candidate's
+         * offset as a first guess at where this one's payload ends: probe 1.62 -> ... ms per GiB of zipf255 */
+        const uint64_t nextc = (blockIdx.x + 1u < gridDim.x) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
+        const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
+        const bool shaped = block_len >= 32768u && tl <= HUF_TREE_MAX && dfast_tables_from_tree<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl);
+        if ((shaped || (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0)) &&
+            decode_payload_fast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint)) {
             if (threadIdx.x == 0) {
                 cand_status[blockIdx.x] = HUFE_OK;
                 cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
@@ -331,15 +365,31 @@ __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const uint64_t *__re
                 m += run;
                 c += run;
                 if (run == 64u || c >= top) continue;
-                /* one link of another kind */
-                const uint32_t nx = s_nxt[c - base];
-                if (nx == LINK_BAD) { resume = s_cand[c - base]; stop = true; break; }
-                if (lane == 0) block_offsets[m] = s_cand[c - base];
-                if (c != m) contiguous = false;
-                m++;
-                if (nx == LINK_TERMINAL) { complete = 1; consumed = cand_end[c]; stop = true; break; }
-                if (nx == LINK_NOTFOUND) { resume = cand_end[c]; stop = true; break; }
-                c = nx;                                    /* nx > c: the chain only moves forward */
+                /* one link of another kind.  (Round 4: a link that jumps over a candidate - a block whose payload holds the
+                 * bytes of a header - was never followed: hipcc 7.2 compiled the chain of early exits this was into code that
+                 * kept `c` for every link below 2^31 and counted m up until block_offsets[] ended;
+                 * test_raw_stream_with_a_false_header_inside_a_payload.  One exit now, the link read as a wave-uniform value.) */
+                const uint32_t nx = uni32(s_nxt[c - base]);
+                const uint64_t here = s_cand[c - base];
+                if (nx == LINK_BAD) {
+                    resume = here;
+                    stop = true;
+                } else {
+                    if (lane == 0) block_offsets[m] = here;
+                    if (c != m) contiguous = false;
+                    m++;
+                    if (nx == LINK_TERMINAL) {
+                        complete = 1;
+                        consumed = cand_end[c];
+                        stop = true;
+                    } else if (nx == LINK_NOTFOUND || (uint64_t)nx <= c) {   /* (the chain only moves forward) */
+                        resume = cand_end[c];
+                        stop = true;
+                    } else {
+                        c = (uint64_t)nx;
+                    }
+                }
+                if (stop) break;
             }
             if (lane == 0) {
                 s_cur = c;

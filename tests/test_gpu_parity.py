@@ -351,6 +351,45 @@ def test_decode_stream_parallel_discovery(torch_mod, codec, oracle, kind, n, bs)
         assert np.array_equal(out[:raw].cpu().numpy(), data)
 
 
+def _handmade_block(payload: bytes, leaves: int) -> bytes:
+    """A block whose tree is complete with 2 or 4 leaves ('A' = 0, 'B' = 1 / 'A'..'D' = 00..11): its payload is ANY byte
+    string, one symbol a bit or two (src/decoder.c:34-96 walks whatever tree the stream brings)."""
+    import struct
+    tree = [0x0101, 0x41, -1, -1, 0x42, -1, -1] if leaves == 2 else \
+           [0x0103, 0x0101, 0x41, -1, -1, 0x42, -1, -1, 0x0102, 0x43, -1, -1, 0x44, -1, -1]
+    per_byte = 8 if leaves == 2 else 4
+    return struct.pack("<Qh", per_byte * len(payload), len(tree)) + b"".join(struct.pack("<h", v) for v in tree) + payload
+
+
+@pytest.mark.parametrize("leaves,pay_bytes,at", [(2, 8192, 3000), (4, 8192, 3000), (4, 60000, 50000), (4, 60000, 17), (2, 60000, 31000)])
+def test_raw_stream_with_a_false_header_inside_a_payload(torch_mod, codec, oracle, leaves, pay_bytes, at):
+    """The discovery takes every offset that LOOKS like a header for a candidate, and a candidate's probe takes the next
+    candidate's offset for the end of its own payload (a guess, given up when the symbols come short).  Here a payload holds
+    the twelve bytes of a syntactically valid header - block_len 1, a tree of one marker - in the first and in a later
+    segment of its block and right behind the real header; blocks of an ordinary encoder stand in front and behind.  The
+    chain of blocks then has a link that jumps over a candidate: round 4 found that walk_kernel never followed such a
+    link (it wrote block offsets until its array ended: a memory fault on a VALID stream).  Bytes, error code and consumed
+    count are the oracle's, with the parallel discovery and without.  (The tree of seven entries takes the exact decoder
+    in the probe, the one of fifteen the lean decoder and its guess.)"""
+    torch = torch_mod
+    rng = np.random.default_rng(77 + at)
+    pay = bytearray(rng.integers(0, 256, pay_bytes, dtype=np.uint8).tobytes())
+    pay[at:at + 12] = bytes([1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0xff, 0xff])
+    tail = oracle.encode(datagen.zipf255(5 * 65536), 65536)
+    head = oracle.encode(datagen.uniform256(2 * 65536), 65536)
+    stream = np.concatenate([head, np.frombuffer(_handmade_block(bytes(pay), leaves), dtype=np.uint8), tail])
+    n = 7 * 65536 + (8 if leaves == 2 else 4) * pay_bytes
+    cap = n + 64
+    oerr, oout, oused = oracle.decode(stream, cap, 1025)
+    assert (oerr, oout.size, oused) == (0, n, stream.size)
+    s = to_dev(torch, stream)
+    for sequential in (False, True):
+        out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(s, stream.size, stream.size, out, relaxed=True, sequential=sequential)
+        assert (err, raw, used) == (oerr, oout.size, oused), (sequential, err, raw, used)
+        assert np.array_equal(out[:raw].cpu().numpy(), oout), sequential
+
+
 def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
     """Corruptions in the middle of a long stream: the parallel path hands the unvalidated rest to
     the in-order decoder, so error code, delivered bytes and consumed count equal the oracle's."""

@@ -390,6 +390,41 @@ def test_raw_stream_with_a_false_header_inside_a_payload(torch_mod, codec, oracl
         assert np.array_equal(out[:raw].cpu().numpy(), oout), sequential
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_streams_of_random_trees_vs_oracle(torch_mod, codec, oracle, seed):
+    """Blocks no encoder wrote (tests/handmade_streams.py): trees of any shape and depth (codes of 1 to > 100 bits, with
+    and without the encoder's one-child root), symbols coded with them, padding of zeros or ones.  The raw stream - parallel
+    discovery and in order - and the indexed decode deliver what the oracle delivers."""
+    import handmade_streams as hm
+    torch = torch_mod
+    rng = np.random.default_rng(9000 + seed)
+    parts, want, deepest = [], [], 0
+    total = 0
+    while total < (150000 if seed % 2 == 0 else 20000):
+        leaves = int(rng.integers(2, 257))
+        skew = float(rng.choice([0.0, 0.3, 0.8, 0.97]))
+        nsym = int(rng.choice([1, 7, 300, 5000, 40000, 70000]))
+        b, syms, depth = hm.block(rng, leaves, skew, bool(rng.integers(0, 2)), nsym, deep_often=bool(rng.integers(0, 2)),
+                                  pad_ones=bool(rng.integers(0, 2)))
+        parts.append(np.frombuffer(b, dtype=np.uint8))
+        want.append(syms)
+        deepest = max(deepest, depth)
+        total += len(b)
+    stream = np.concatenate(parts)
+    data = np.concatenate(want)
+    oerr, oout, oused = oracle.decode(stream, data.size + 64, 1025)
+    assert (oerr, oused) == (0, stream.size) and np.array_equal(oout, data), "the generator and the oracle disagree"
+    s = to_dev(torch, stream)
+    for sequential in (False, True):
+        out = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+        err, raw, used = codec.decode_stream(s, stream.size, stream.size, out, relaxed=True, sequential=sequential)
+        assert (err, raw, used) == (0, data.size, stream.size), (seed, sequential, deepest, err, raw, used)
+        assert np.array_equal(out[:raw].cpu().numpy(), data), (seed, sequential, deepest)
+    offs = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.uint64)
+    got = gpu_decode_indexed(torch, codec, stream, offs, data.size, relaxed=True)
+    assert np.array_equal(got, data), (seed, "indexed", deepest)
+
+
 def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
     """Corruptions in the middle of a long stream: the parallel path hands the unvalidated rest to
     the in-order decoder, so error code, delivered bytes and consumed count equal the oracle's."""

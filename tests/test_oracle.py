@@ -146,3 +146,23 @@ def test_differential_decode_of_garbage(oracle, reference, seed):
         assert rout == oout.tobytes()
         compared += 1
     assert compared > 30
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_handmade_trees_reference_and_oracle_agree(oracle, reference, seed):
+    """Streams no encoder wrote (tests/handmade_streams.py: trees of any shape, codes of 1 to > 100 bits, with and without
+    the encoder's one-child root): the unmodified reference and the oracle deliver the same bytes - which is what lets the
+    GPU tests of such streams take the oracle's word."""
+    import handmade_streams as hm
+    rng = np.random.default_rng(400 + seed)
+    parts, want = [], []
+    for _ in range(int(rng.integers(1, 4))):
+        b, syms, _ = hm.block(rng, int(rng.integers(2, 256)), float(rng.choice([0.0, 0.3, 0.8, 0.97])), bool(rng.integers(0, 2)),
+                              int(rng.integers(1, 20000)), deep_often=bool(rng.integers(0, 2)), pad_ones=bool(rng.integers(0, 2)))
+        parts.append(np.frombuffer(b, dtype=np.uint8))
+        want.append(syms)
+    stream, data = np.concatenate(parts), np.concatenate(want)
+    oerr, oout, oused = oracle.decode(stream, data.size + 64, 1025)
+    assert (oerr, oused) == (0, stream.size) and np.array_equal(oout, data)
+    res = _reference_decode_in_child(reference, stream)
+    assert res is not None and res[0] == 0 and res[1] == data.tobytes()

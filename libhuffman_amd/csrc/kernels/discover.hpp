@@ -111,28 +111,34 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                                                                 uint64_t *__restrict__ masks,
                                                                 uint64_t *__restrict__ cand_len = nullptr)
 {
-    /* A thread owns DISC_ITERS consecutive 16-byte pieces (thread order = stream order, one scan
-     * per workgroup of 16 KiB: with 4 KiB workgroups the kernel was bound by their dispatch). */
-    __shared__ uint32_t s_part[DISC_THREADS / 64];
-    const uint64_t t0 = (uint64_t)blockIdx.x * DISC_CHUNK + (uint64_t)threadIdx.x * (DISC_PER * DISC_ITERS);
+    /* A workgroup scans 16 KiB (with 4 KiB workgroups the kernel was bound by their dispatch) in DISC_ITERS rows of
+     * DISC_THREADS 16-byte pieces; a thread owns piece `tid` of every row.  (Round 4.  Until then a thread owned four
+     * CONSECUTIVE pieces: every load of a wave touched 64 places 64 bytes apart.  Now a row is one contiguous
+     * 4 KiB and the piece behind a thread's own - the window of an offset runs on into it - is the same load 16 bytes on.) */
+    __shared__ uint32_t s_part[DISC_THREADS / 64], s_part2[DISC_THREADS / 64];
+    const uint64_t wg0 = (uint64_t)blockIdx.x * DISC_CHUNK;
+    const uint64_t t0 = wg0 + (uint64_t)threadIdx.x * DISC_PER;                 /* the thread's piece of row 0; row `it`: + it * DISC_THREADS * DISC_PER */
+    constexpr uint64_t ROW = (uint64_t)DISC_THREADS * DISC_PER;
     const uint64_t slot = (uint64_t)blockIdx.x * DISC_THREADS + threadIdx.x;
-    uint64_t mask = 0;
+    uint64_t mask = 0;                                                          /* bit 16 it + k: offset t0 + it * ROW + k */
     /* the counting pass leaves its 64 verdicts per thread for the writing pass, which then reads
      * 1/8 of the stream's size instead of testing the whole stream again */
     if (WRITE) mask = masks[slot];
     else if (t0 < scan_len) {
-        /* all five loads of the thread are issued before the first use (one memory round trip) */
-        uint4 v[DISC_ITERS + 1];
-        v[0] = *reinterpret_cast<const uint4 *>(stream + t0);                  /* 16-byte unit that holds a valid byte */
+        /* all eight loads of the thread are issued before the first use (one memory round trip) */
+        uint4 va[DISC_ITERS], vb[DISC_ITERS];
 #pragma unroll
-        for (int it = 1; it <= DISC_ITERS; it++) {
-            v[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (t0 + (uint64_t)(it * DISC_PER) < avail) v[it] = *reinterpret_cast<const uint4 *>(stream + t0 + it * DISC_PER);
+        for (int it = 0; it < DISC_ITERS; it++) {
+            const uint64_t q = t0 + (uint64_t)it * ROW;
+            va[it] = make_uint4(0u, 0u, 0u, 0u);
+            vb[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < avail) va[it] = *reinterpret_cast<const uint4 *>(stream + q);                  /* (a 16-byte unit that holds a valid byte) */
+            if (q + DISC_PER < avail) vb[it] = *reinterpret_cast<const uint4 *>(stream + q + DISC_PER);
         }
 #pragma unroll
         for (int it = 0; it < DISC_ITERS; it++) {
-            const uint64_t p0 = t0 + (uint64_t)(it * DISC_PER);
-            const uint4 a = v[it], b = v[it + 1];              /* zeros behind the data: no survivors there */
+            const uint64_t p0 = t0 + (uint64_t)it * ROW;
+            const uint4 a = va[it], b = vb[it];                /* zeros behind the data: no survivors there */
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             /* almost no offset survives "the upper half of block_len is zero": that test is done
              * for all 16 offsets without a branch, everything else only for the survivors */
@@ -192,21 +198,35 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
             }
         }
     }
-    uint32_t total;
-    const uint32_t ex = block_excl_scan_u32<DISC_THREADS>((uint32_t)__popcll(mask), s_part, total);
+    /* candidates in stream order: row by row, thread by thread inside a row - four counts (<= 16 a thread, <= 4 096 a row) in
+     * two sums of 16-bit halves */
+    static_assert(DISC_ITERS == 4 && DISC_PER == 16 && DISC_THREADS * DISC_PER < 65536, "four rows of 16-bit counts");
+    uint32_t tot_lo, tot_hi;
+    const uint32_t c_lo = (uint32_t)__popc((uint32_t)mask & 0xffffu) | ((uint32_t)__popc((uint32_t)(mask >> 16) & 0xffffu) << 16);
+    const uint32_t c_hi = (uint32_t)__popc((uint32_t)(mask >> 32) & 0xffffu) | ((uint32_t)__popc((uint32_t)(mask >> 48)) << 16);
+    const uint32_t ex_lo = block_excl_scan_u32<DISC_THREADS>(c_lo, s_part, tot_lo);
+    const uint32_t ex_hi = block_excl_scan_u32<DISC_THREADS>(c_hi, s_part2, tot_hi);
+    const uint32_t tot[4] = {tot_lo & 0xffffu, tot_lo >> 16, tot_hi & 0xffffu, tot_hi >> 16};
     if (!WRITE) {
         masks[slot] = mask;
-        if (threadIdx.x == 0) wg_counts[blockIdx.x] = total;
+        if (threadIdx.x == 0) wg_counts[blockIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
     } else {
-        uint64_t at = wg_base[blockIdx.x] + ex;
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            cand[at] = t0 + (uint64_t)k;
-            /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
-             * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> ... us) */
-            cand_len[at] = load_u64_unaligned(stream + t0 + (uint64_t)k);
-            at++;
+        const uint32_t first[4] = {ex_lo & 0xffffu, tot[0] + (ex_lo >> 16), tot[0] + tot[1] + (ex_hi & 0xffffu), tot[0] + tot[1] + tot[2] + (ex_hi >> 16)};
+        const uint64_t wgb = wg_base[blockIdx.x];
+#pragma unroll
+        for (int it = 0; it < DISC_ITERS; it++) {
+            uint32_t m = (uint32_t)(mask >> (16 * it)) & 0xffffu;
+            uint64_t at = wgb + first[it];
+            while (m) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1;
+                const uint64_t p = t0 + (uint64_t)it * ROW + (uint64_t)k;
+                cand[at] = p;
+                /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
+                 * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> 7 us) */
+                cand_len[at] = load_u64_unaligned(stream + p);
+                at++;
+            }
         }
     }
 }

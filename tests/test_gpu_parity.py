@@ -361,8 +361,10 @@ def _handmade_block(payload: bytes, leaves: int) -> bytes:
     return struct.pack("<Qh", per_byte * len(payload), len(tree)) + b"".join(struct.pack("<h", v) for v in tree) + payload
 
 
-@pytest.mark.parametrize("leaves,pay_bytes,at", [(2, 8192, 3000), (4, 8192, 3000), (4, 60000, 50000), (4, 60000, 17), (2, 60000, 31000)])
-def test_raw_stream_with_a_false_header_inside_a_payload(torch_mod, codec, oracle, leaves, pay_bytes, at):
+@pytest.mark.parametrize("leaves,pay_bytes,at,fake_len,small_blocks",
+                         [(2, 8192, 3000, 1, 0), (4, 8192, 3000, 1, 0), (4, 60000, 50000, 1, 0), (4, 60000, 17, 1, 0), (2, 60000, 31000, 1, 0),
+                          (4, 8192, 3000, 1000000, 0), (4, 8192, 3000, 1, 8190), (2, 8192, 100, 1, 8191)])
+def test_raw_stream_with_a_false_header_inside_a_payload(torch_mod, codec, oracle, leaves, pay_bytes, at, fake_len, small_blocks):
     """The discovery takes every offset that LOOKS like a header for a candidate, and a candidate's probe takes the next
     candidate's offset for the end of its own payload (a guess, given up when the symbols come short).  Here a payload holds
     the twelve bytes of a syntactically valid header - block_len 1, a tree of one marker - in the first and in a later
@@ -370,15 +372,23 @@ def test_raw_stream_with_a_false_header_inside_a_payload(torch_mod, codec, oracl
     chain of blocks then has a link that jumps over a candidate: round 4 found that walk_kernel never followed such a
     link (it wrote block offsets until its array ended: a memory fault on a VALID stream).  Bytes, error code and consumed
     count are the oracle's, with the parallel discovery and without.  (The tree of seven entries takes the exact decoder
-    in the probe, the one of fifteen the lean decoder and its guess.)"""
+    in the probe, the one of fifteen the lean decoder and its guess.  fake_len = 1 000 000: the candidates' claimed
+    lengths no longer fit the output, and the probes only count.  small_blocks: that many 256-byte blocks in front, so
+    that the link that jumps lies at the seam of the walk's chunks of 8 192 candidates.)"""
+    import struct
     torch = torch_mod
     rng = np.random.default_rng(77 + at)
     pay = bytearray(rng.integers(0, 256, pay_bytes, dtype=np.uint8).tobytes())
-    pay[at:at + 12] = bytes([1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0xff, 0xff])
+    pay[at:at + 12] = struct.pack("<Qh", fake_len, 1) + b"\xff\xff"
     tail = oracle.encode(datagen.zipf255(5 * 65536), 65536)
-    head = oracle.encode(datagen.uniform256(2 * 65536), 65536)
+    if small_blocks:
+        head_data = datagen.zipf255(small_blocks * 256)
+        head = oracle.encode(head_data, 256)
+    else:
+        head_data = datagen.uniform256(2 * 65536)
+        head = oracle.encode(head_data, 65536)
     stream = np.concatenate([head, np.frombuffer(_handmade_block(bytes(pay), leaves), dtype=np.uint8), tail])
-    n = 7 * 65536 + (8 if leaves == 2 else 4) * pay_bytes
+    n = head_data.size + 5 * 65536 + (8 if leaves == 2 else 4) * pay_bytes
     cap = n + 64
     oerr, oout, oused = oracle.decode(stream, cap, 1025)
     assert (oerr, oout.size, oused) == (0, n, stream.size)

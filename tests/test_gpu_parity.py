@@ -435,6 +435,46 @@ def test_streams_of_random_trees_vs_oracle(torch_mod, codec, oracle, seed):
     assert np.array_equal(got, data), (seed, "indexed", deepest)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_damaged_streams_of_random_trees_vs_oracle(torch_mod, codec, oracle, seed):
+    """The same hand-made streams with a bit flipped, a byte overwritten, the end cut off or the length given short: error code
+    and bytes delivered are the oracle's (src/decoder.c:69-91, 218-276), raw parallel and raw in order."""
+    import handmade_streams as hm
+    torch = torch_mod
+    rng = np.random.default_rng(12000 + seed)
+    parts, sizes = [], 0
+    while sizes < 120000:
+        b, syms, _ = hm.block(rng, int(rng.integers(2, 257)), float(rng.choice([0.0, 0.3, 0.8, 0.97])), bool(rng.integers(0, 2)),
+                              int(rng.choice([7, 300, 5000, 40000])), deep_often=bool(rng.integers(0, 2)), pad_ones=bool(rng.integers(0, 2)))
+        parts.append(np.frombuffer(b, dtype=np.uint8))
+        sizes += len(b)
+    good = np.concatenate(parts)
+    starts = np.concatenate([[0], np.cumsum([p.size for p in parts])])
+    cap = int(sum(int.from_bytes(p[:8].tobytes(), "little") for p in parts)) + 70000
+    cases = []
+    for _ in range(5):
+        b = good.copy(); i = int(rng.integers(0, good.size)); b[i] ^= 1 << int(rng.integers(0, 8)); cases.append(("bit %d" % i, b, None))
+    for _ in range(3):
+        blk = int(rng.integers(0, len(parts)))
+        b = good.copy(); i = int(starts[blk]) + int(rng.integers(0, 14)); b[i] = int(rng.integers(0, 256)); cases.append(("header byte %d" % i, b, None))
+    cut = int(rng.integers(good.size // 2, good.size))
+    cases.append(("cut at %d" % cut, good[:cut].copy(), None))
+    cases.append(("length %d" % cut, good.copy(), cut))
+    for name, bad, length in cases:
+        oerr, oout, oused = oracle.decode(bad, cap, 1025, length=length)
+        if oerr == 1:
+            continue                                            # (more than the test's buffer: a damaged block_len)
+        s = to_dev(torch, bad)
+        ln = bad.size if length is None else length
+        for sequential in (False, True):
+            out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            err, raw, used = codec.decode_stream(s, bad.size, ln, out, relaxed=True, sequential=sequential)
+            assert (err, raw) == (oerr, oout.size), (seed, name, sequential, (err, raw, used), (oerr, oout.size, oused))
+            assert np.array_equal(out[:raw].cpu().numpy(), oout), (seed, name, sequential)
+            if oerr == 0:                                       # (after an error: what the reader had buffered, not a property of the stream)
+                assert used == oused, (seed, name, sequential)
+
+
 def test_decode_stream_parallel_error_parity(torch_mod, codec, oracle):
     """Corruptions in the middle of a long stream: the parallel path hands the unvalidated rest to
     the in-order decoder, so error code, delivered bytes and consumed count equal the oracle's."""

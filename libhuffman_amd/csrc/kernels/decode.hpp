@@ -176,7 +176,8 @@ struct DecShared {
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
     int16_t ent[ENT];                    /* the tree's entries (behind the marks: decode_fast_kernel's table of pairs runs on into it when the
                                             block has no codes that need the entries, decode_fast.hpp) */
-    uint32_t wend[THREADS / 64];         /* end position of the last lane of each wave (neighbours use shuffles) */
+    __attribute__((aligned(16))) uint32_t wend[THREADS / 64];   /* end position of the last lane of each wave (neighbours use shuffles).  (Aligned: `ent` in
+                                            front of it is not a multiple of 16 bytes, and decode_sub reads wtile[] sixteen bytes at a time.) */
     uint32_t part[THREADS / 64];
     uint32_t wtile[32];                  /* decode_sub: payload bits of the chunk's wave tiles */
     uint32_t fastk;                      /* decode_sub: leaves of the tables dsub_fast_tables built (0: the tables are dec_build_tables') */

@@ -33,6 +33,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -284,6 +285,31 @@ def launch_ranks(args) -> int:
     if lines:
         print(lines[-1], flush=True)
     return proc.returncode
+
+
+def ranks_agree(dist, torch, end_group, all_good_here: bool) -> bool:
+    """The last thing the ranks of a job with more than one rank do together: does EVERY rank stand here, and did every rank's
+    extra figure (root_placement) go through?  One all-reduce of a flag over a gloo group made for it (CPU tensors, a
+    timeout that raises instead of a watchdog that kills): a rank that is missing or that failed makes this False on all the
+    others within the group's timeout - where a barrier of the RCCL group would wait until the launcher kills the job and
+    rank 0's line with it (tests/test_bench_host.py runs it with two and three gloo ranks, one failing, one missing)."""
+    try:
+        flag = torch.tensor([1 if all_good_here else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=end_group)
+        return bool(int(flag.item()) == 1)
+    except Exception:
+        return False
+
+
+def wait_for_file(path: str, seconds: float) -> bool:
+    """(a rank that leaves with an error first gives rank 0 the time to print: the launcher tears every rank down as soon as one
+    has failed)"""
+    t_end = time.time() + seconds
+    while time.time() < t_end:
+        if os.path.exists(path):
+            return True
+        time.sleep(0.2)
+    return False
 
 
 class Bench:
@@ -764,6 +790,13 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    end_group = None
+    done_path = os.path.join(tempfile.gettempdir(), "huf_bench_done_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "0")))
+    if world > 1:
+        import datetime
+        if rank == 0 and os.path.exists(done_path):
+            os.remove(done_path)                     # (a job of the same port that did not end clean)
+        end_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("BENCH_END_TIMEOUT", "180"))))
 
     from libhuffman_amd.codec import GpuCodec
 
@@ -919,9 +952,30 @@ def main() -> None:
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
+    if world > 1:
+        # The ranks part WITHOUT a barrier of the RCCL group and without its teardown (either waits for a rank that is gone until
+        # the launcher kills the job, and the line with it): they agree over the gloo group whether all of them got here clean.
+        all_ok = ranks_agree(dist, torch, end_group, root_ok)
+        if rank != 0:
+            if not all_ok:
+                wait_for_file(done_path, 240.0)      # (rank 0 prints at once when the ranks do not agree)
+            os._exit(0 if all_ok else 1)
+        if all_ok:
+            py_rec, capi_rec = host_legs()           # the other ranks are idle or gone: every GPU of the node is this process's
+            if py_rec is not None:
+                result["secondary"]["logtext_huffmanfile"] = py_rec
+            if capi_rec is not None:
+                result["secondary"]["c_api_memstream"] = capi_rec
+        else:
+            result["ranks_left_clean"] = False       # (the error, if it was this rank's, is inside root_placement)
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
+        try:
+            open(done_path, "w").close()
+        except OSError:
+            pass
+        os._exit(0 if all_ok else 1)
     if not root_ok:
-        # a movement of the extra figure failed or timed out on this rank: the ranks are out of step, so no
-        # barrier and no teardown (both would wait for the missing ones)
         if rank == 0:
             print(json.dumps(result), flush=True)
         os._exit(1)                                  # (the line is there, with the error inside root_placement; the job did not run clean)
@@ -929,12 +983,6 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world > 1:
-            py_rec, capi_rec = host_legs()
-            if py_rec is not None:
-                result["secondary"]["logtext_huffmanfile"] = py_rec
-            if capi_rec is not None:
-                result["secondary"]["c_api_memstream"] = capi_rec
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(result), flush=True)
 

@@ -85,3 +85,24 @@ def test_counter_passes_are_read_per_launch_of_the_named_kernel(clean_env, tmp_p
     got = bench.live_traffic("zipf255", ["decode_sub_kernel", "pack_kernel", "no_such_kernel"], ["--bytes-per-gpu", str(1 << 28)])
     assert got == {"decode_sub_kernel": 1000 * 1024 * 2 + 500 * 1024, "pack_kernel": 99999 * 1024 * 3}
     assert bench.live_traffic("zipf255", ["no_such_kernel"]) is None
+
+
+@pytest.mark.parametrize("case,world,want", [("all_good", 3, True), ("one_fails", 3, False), ("one_missing", 2, False)])
+def test_the_ranks_of_a_job_agree_at_its_end(tmp_path, case, world, want):
+    """bench.py with more than one rank ends with bench.ranks_agree over a gloo group instead of a barrier and a teardown of the RCCL
+    group: every rank learns within the group's timeout whether all of them stand at the end clean - also when one of them failed
+    its extra figure, also when one is gone - and rank 0 prints its line either way."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_end_child.py"), str(r), str(world), port, case, str(tmp_path)])
+             for r in range(world)]
+    for p in procs:
+        p.wait(timeout=120)
+    present = world - (1 if case == "one_missing" else 0)
+    for r in range(present):
+        agreed, seconds = (tmp_path / ("rank%d" % r)).read_text().split()
+        assert (agreed == "1") == want, (case, r)
+        assert float(seconds) < 30.0

@@ -313,10 +313,24 @@ def wait_for_file(path: str, seconds: float) -> bool:
 
 
 class Bench:
-    def __init__(self, args, torch, dist, codec, rank, world, local_rank, use_dist):
+    def __init__(self, args, torch, dist, codec, rank, world, local_rank, use_dist, ctl_group=None):
         self.a, self.torch, self.dist, self.codec = args, torch, dist, codec
         self.rank, self.world, self.local_rank, self.use_dist = rank, world, local_rank, use_dist
         self.dev = torch.device("cuda", local_rank)
+        # the extra figure's CONTROL traffic (flags, barriers, the legs' times) goes over the gloo group of main() when there is
+        # one: its timeout raises, where a barrier of the RCCL group behind a rank that failed alone waits for the watchdog
+        self.ctl = ctl_group
+
+    def ctl_barrier(self):
+        if self.ctl is not None:
+            self.dist.barrier(group=self.ctl)
+        else:
+            self.dist.barrier()
+
+    def ctl_reduce(self, value, op):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=("cpu" if self.ctl is not None else self.dev))
+        self.dist.all_reduce(t, op=op, group=self.ctl)
+        return float(t.item())
 
     def make_input(self, workload: str, n: int, first: int):
         torch = self.torch
@@ -599,9 +613,7 @@ class Bench:
             del spare                                   # what the gathered stream will need on rank 0
         except Exception as e:
             alloc_ok, alloc_err = 0, repr(e)
-        flag = torch.tensor([alloc_ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        if int(self.ctl_reduce(alloc_ok, dist.ReduceOp.MIN)) == 0:
             return {"error": "allocation failed on some rank: %s" % alloc_err} if rank == 0 else None
         in_sizes = [h - l for l, h in plan]
         gathered = None
@@ -623,7 +635,7 @@ class Bench:
                 legs = {key: 0.0 for key in legs}
                 total = 0.0
             torch.cuda.synchronize()
-            dist.barrier()
+            self.ctl_barrier()
             t0 = time.perf_counter()
             timed("scatter_in", lambda: sharding.scatter_from_root(full, in_sizes, shard, 0, timeout=leg_timeout))
             timed("encode", lambda: codec.encode(shard, bs, out=out, offsets=offs, sync=False, sub_index=sub))
@@ -634,18 +646,17 @@ class Bench:
                                                  sub_index=sub, raw_size=n, blocksize=bs))
             timed("gather_out", lambda: sharding.gather_to_root(back, in_sizes, result, 0, timeout=leg_timeout))
             torch.cuda.synchronize()
-            dist.barrier()
+            self.ctl_barrier()
             total += time.perf_counter() - t0
         legs_all = [None] * world
-        dist.all_gather_object(legs_all, {k: round(v / max(steps, 1) * 1e3, 3) for k, v in legs.items()})
-        tmax = torch.tensor([total], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(legs_all, {k: round(v / max(steps, 1) * 1e3, 3) for k, v in legs.items()}, group=self.ctl)
+        tmax_s = self.ctl_reduce(total, dist.ReduceOp.MAX)
         ok = True
         if rank == 0 and not a.no_verify:
             ok = bool(torch.equal(result, full))
         if rank != 0:
             return None
-        sec = float(tmax.item()) / steps
+        sec = tmax_s / steps
         return {"value": round(n_total / GIB / sec, 3), "unit": "GiB/s", "ms_per_step": round(sec * 1e3, 3),
                 "steps": steps, "bit_exact_roundtrip": ok, "stream_bytes": int(sum(csizes)),
                 "legs_ms_rank0": {key: round(v / steps * 1e3, 3) for key, v in legs.items()},
@@ -801,7 +812,7 @@ def main() -> None:
     from libhuffman_amd.codec import GpuCodec
 
     codec = GpuCodec(local_rank)
-    bench = Bench(args, torch, dist, codec, rank, world, local_rank, use_dist)
+    bench = Bench(args, torch, dist, codec, rank, world, local_rank, use_dist, ctl_group=end_group)
     if args.secondary is None:
         secondary = DEFAULT_SECONDARY.get(args.workload, [])
     else:

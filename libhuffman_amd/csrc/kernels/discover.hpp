@@ -278,7 +278,7 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
     if (store && block_len != 0 && tl >= 9 && pay0 <= avail) {
         int leaf = -1;
         /* (round 4) the tables from the tree's shape where decode_fast_kernel takes them from it, and the next candidate's
-         * offset as a first guess at where this one's payload ends: probe 1.62 -> ... ms per GiB of zipf255 */
+         * offset as a first guess at where this one's payload ends: probe 1.62 -> 1.53 ms per GiB of zipf255, the indexed decoder's time (profiles/r04/raw_stream_kernels.txt) */
         const uint64_t nextc = (blockIdx.x + 1u < gridDim.x) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
         const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
         const bool shaped = block_len >= 32768u && tl <= HUF_TREE_MAX && dfast_tables_from_tree<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl);

@@ -25,7 +25,8 @@ namespace hufgpu {
  * byte k of the loaded dword into bits 8..15 over the lane's column offset - no extract, no shift, no
  * compare.  All waves of the workgroup share the array (lane l of every wave adds to the same word; the
  * adds are atomic), the rows are summed at the end with 16-byte reads and DPP row sums.
- * LDS: 64 KiB -> two workgroups of 512 threads per CU; every thread has all of its loads in flight
+ * LDS: 64 KiB in round 3 (two workgroups of 512 threads per CU), 32 KiB since round 4 (16-bit counters, below): three
+ * workgroups per CU - its 72 registers a lane set that now; every thread has all of its loads in flight
  * before it counts (128 bytes per thread at 64 KiB blocks), so the kernel runs at the rate HBM delivers.
  * ==================================================================================== */
 #define HL_THREADS 512
@@ -33,7 +34,7 @@ namespace hufgpu {
 /* Round 4: 16-bit counters.  Lanes l and l + 32 of a wave share a word (low and high half); an LDS instruction serves
  * lanes 0-31 and 32-63 in different cycles anyway, so the 32 lanes of a half still meet 32 different banks - two passes
  * per ds_add as before - and the array is 32 KiB: four workgroups per CU instead of two, half as much to zero and to
- * sum.  A counter sees lane l of all eight waves: 1 024 bytes of a 64 KiB block, 32 768 of the largest block that
+ * sum (the registers, not the LDS, then decide: three workgroups).  A counter sees lane l of all eight waves: 1 024 bytes of a 64 KiB block, 32 768 of the largest block that
  * comes here (below 2 MiB; chunks of 256 KiB above that) - 16 bits hold it.  The address is byte << 7 | (lane & 31) << 2:
  * the v_perm puts the byte over twice the column, one shift halves both. */
 #ifndef HL_COUNTER16
@@ -43,7 +44,8 @@ namespace hufgpu {
 #define HL_AHEAD 8                /* 16-byte vectors a thread requests before it counts the first */
 #endif
 #ifndef HL_WAVES_PER_SIMD
-#define HL_WAVES_PER_SIMD 4       /* (8 waves a workgroup: 4 = two workgroups per CU, what 97 registers allow) */
+#define HL_WAVES_PER_SIMD 4       /* (the least the compiler has to leave room for: 8 waves a workgroup, two workgroups per CU; with 72 registers
+                                     it is three) */
 #endif
 #define HL_LDS_BYTES (HL_COUNTER16 ? HUF_NSYM * 32 * 4 : HUF_NSYM * 64 * 4)
 #define HL_MAX_PER_COUNTER 65535u

@@ -981,6 +981,13 @@ def main() -> None:
         # The ranks part WITHOUT a barrier of the RCCL group and without its teardown (either waits for a rank that is gone until
         # the launcher kills the job, and the line with it): they agree over the gloo group whether all of them got here clean.
         all_ok = ranks_agree(dist, torch, end_group, root_ok)
+        if all_ok:
+            # every rank stands here: the RCCL group can be taken down the ordinary way, by all of them at once (rank 0 goes on to
+            # use the GPUs alone: no communicator, and no watchdog of one, must be left behind that could mind the others' leaving)
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
         if rank != 0:
             if not all_ok:
                 wait_for_file(done_path, 240.0)      # (rank 0 prints at once when the ranks do not agree)

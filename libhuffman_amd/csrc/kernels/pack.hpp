@@ -158,27 +158,17 @@ __device__ __forceinline__ uint32_t header_byte(uint32_t j, uint64_t block_len, 
     return (e >> (8 * (j & 1))) & 0xffu;
 }
 
-template <int THREADS, typename CodeT, int GROUP = 1>
-__device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint64_t len,
-                                           const hufcode_t *__restrict__ codes64,
-                                           const int16_t *__restrict__ tb, uint32_t tree_len,
-                                           uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
-                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage,
-                                           uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
+/* The block header (encoder.c:322-339) and - for a block of one distinct byte - its whole payload.  Whole aligned
+ * words are stored here, the unfinished last word becomes the incoming tail of the payload's first lane
+ * (s_tail[WAVES]).  Returns false when the record is complete (one distinct byte); *hdr_end_out = the header's end
+ * in bytes from A0. */
+template <int THREADS>
+__device__ __forceinline__ bool pack_header(uint64_t len, const int16_t *__restrict__ tb, uint32_t tree_len,
+                                            uint8_t *g_a0, uint32_t *g_w0, uint32_t rec_lo, uint64_t rec_hi,
+                                            uint32_t *s_tail, uint32_t *hdr_end_out)
 {
-    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
-    constexpr int TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-
-    uint8_t *g_a0 = out + (dst0 & ~3ull);
-    const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
-    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
-    uint32_t *g_w0 = reinterpret_cast<uint32_t *>(g_a0);
-
-    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = (CodeT)codes64[i];
-
     /* ---- header: whole aligned words are stored here, the unfinished last word becomes the
      *      incoming tail of the payload's first lane ---- */
     const uint32_t hdr_bytes = HUF_HEADER_FIXED + 2u * tree_len;
@@ -214,7 +204,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
         for (uint64_t i = (uint64_t)tid; i < ((b1 - b0) >> 4); i += THREADS) store_pack16(q + i, zero4);
         for (uint64_t bp = b1 + tid; bp < z1; bp += THREADS) g_a0[bp] = 0;
-        return;
+        return false;
     }
     if (tid == 0) {
         uint32_t t = 0;                                          /* big-endian partial word */
@@ -223,6 +213,33 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         s_tail[WAVES] = t;                                       /* carry: value of the (hdr_end&3)*8 leading bits */
     }
     __syncthreads();
+    *hdr_end_out = hdr_end;
+    return true;
+}
+
+template <int THREADS, typename CodeT, int GROUP = 1>
+__device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint64_t len,
+                                           const hufcode_t *__restrict__ codes64,
+                                           const int16_t *__restrict__ tb, uint32_t tree_len,
+                                           uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
+                                           CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage,
+                                           uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
+{
+    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
+    constexpr int TILE = THREADS * PACK_SPT;
+    constexpr int WAVES = THREADS / 64;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    uint8_t *g_a0 = out + (dst0 & ~3ull);
+    const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
+    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
+    uint32_t *g_w0 = reinterpret_cast<uint32_t *>(g_a0);
+
+    for (int i = tid; i < HUF_NSYM; i += THREADS) s_code[i] = (CodeT)codes64[i];
+
+    uint32_t hdr_end;
+    if (!pack_header<THREADS>(len, tb, tree_len, g_a0, g_w0, rec_lo, rec_hi, s_tail, &hdr_end)) return;
 
     uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
 
@@ -347,6 +364,254 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
     }
 }
 
+/* ======================================================================================
+ * Blocks whose longest code has at most 15 bits (GROUP = 2: two codes a push) or 10 bits (GROUP = 3), i.e. text,
+ * Zipf bytes, uniform bytes: round 5's placement loop.  pack_kernel spends its time issuing vector instructions
+ * (15.4 a symbol in round 4, 86 % of the kernel's cycles), so the loop is built around what a push costs:
+ *
+ *   - the table entry is EIGHT bytes (one ds_read_b64: 64 banks): x = the code, right-aligned and clean, y = the
+ *     length three times - bits 0..4 as it is, bits 16..20 as (32 - len) & 31, bits 27..31 as it is.  The sum
+ *     of the y of a group's entries (one v_add_u32 / v_add3_u32, nothing to mask: the fields cannot carry into
+ *     each other) is then, as it stands: the group's bit count (low half: the lane's 32 symbols summed,
+ *     v_add3_u32 over the groups), the shift that makes room in the accumulator (v_lshl_or_b32 looks at bits
+ *     0..4), the shift that recovers the bits pushed out of it (byte 2 through SDWA: -count mod 32), and -
+ *     added to a running total kept in the same three fields - the carry out of bit 31 says "a 32-bit word is
+ *     complete" (v_add_co_u32: sum and test in one instruction) while bits 0..4 of the total are the amount
+ *     v_alignbit_b32 cuts the finished word out by.  A push of two codes is 4 instructions and 4 more when
+ *     some lane finishes a word; round 4's was 8 + 8.
+ *   - every finished word goes to the stage, the lane's first included (round 4 kept it in a register and
+ *     tested "is this my first" at every push): its leading bits are zero - the accumulator starts empty - and
+ *     the left neighbour's unfinished tail is OR-ed into them behind the barrier (ds_or_b32).
+ * A tile whose words do not fit the stage (far above 12 bits a symbol) is placed symbol by symbol, straight to HBM.
+ * ==================================================================================== */
+struct PackEnt {
+    uint32_t code;      /* right-aligned, at most 15 bits */
+    uint32_t lens;      /* len | ((32 - len) & 31) << 16 | len << 27; 0 for an absent byte value */
+};
+__device__ __forceinline__ uint2 pack_ent_of(hufcode_t e)
+{
+    const uint32_t len = (uint32_t)(e & 0xffu);
+    return make_uint2((uint32_t)(e >> 8), len | (((32u - len) & 31u) << 16) | (len << 27));
+}
+/* bits the push of `lens` shifts out of `acc`: acc >> (-count mod 32), the amount read from byte 2 of `lens` */
+__device__ __forceinline__ uint32_t pack_pushed_out(uint32_t lens, uint32_t acc)
+{
+    uint32_t o;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD"
+        : "=v"(o) : "v"(lens), "v"(acc));
+    return o;
+}
+
+/* The lane's 32 bytes (w: eight dwords) looked up and joined group by group: pc = the group's codes as one bit
+ * string, ph = the sum of their length fields; returns the lane's bit count.  PARTIAL: bytes from nsym on are absent.
+ * (A batch of look-ups, then their joins: all 32 entries in flight at once would be 64 registers.) */
+template <int GROUP, bool PARTIAL>
+__device__ __forceinline__ uint32_t pack_join(const uint2 *s_ent, const uint32_t (&w)[8], uint32_t nsym,
+                                              uint32_t (&pc)[(PACK_SPT + GROUP - 1) / GROUP], uint32_t (&ph)[(PACK_SPT + GROUP - 1) / GROUP])
+{
+    constexpr int NG = (PACK_SPT + GROUP - 1) / GROUP;
+    constexpr int BATCH = GROUP == 2 ? 4 : 2;                    /* groups a batch */
+    uint32_t bits = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g % BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+        const int k = g * GROUP;
+        uint2 e[3];
+#pragma unroll
+        for (int j = 0; j < GROUP; j++) {
+            const int kk = k + j;
+            if (kk < PACK_SPT) {
+                e[j] = s_ent[(w[kk >> 2] >> (8 * (kk & 3))) & 0xffu];
+                if (PARTIAL && kk >= (int)nsym) e[j] = make_uint2(0u, 0u);
+            }
+        }
+        if (GROUP == 3 && k + 2 < PACK_SPT) {
+            pc[g] = (((e[0].x << (e[1].y & 31u)) | e[1].x) << (e[2].y & 31u)) | e[2].x;
+            ph[g] = e[0].y + e[1].y + e[2].y;
+        } else {
+            pc[g] = (e[0].x << (e[1].y & 31u)) | e[1].x;
+            ph[g] = e[0].y + e[1].y;
+        }
+        bits += ph[g];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return bits & 0xffffu;
+}
+
+template <int THREADS, int GROUP>
+__device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src, uint64_t len,
+                                                 const hufcode_t *__restrict__ codes64,
+                                                 const int16_t *__restrict__ tb, uint32_t tree_len,
+                                                 uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
+                                                 uint2 *s_ent, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage,
+                                                 uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
+{
+    static_assert(GROUP == 2 || GROUP == 3, "two or three codes a push");
+    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
+    constexpr int TILE = THREADS * PACK_SPT;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int NG = (PACK_SPT + GROUP - 1) / GROUP;           /* pushes a lane: 16 pairs, or 10 triples and a pair */
+    typedef __attribute__((address_space(3))) uint32_t *lds_word;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    uint8_t *g_a0 = out + (dst0 & ~3ull);
+    const uint32_t rec_lo = (uint32_t)(dst0 & 3ull);            /* record bytes relative to A0 */
+    const uint64_t rec_hi = rec_lo + (dst1 - dst0);
+    uint32_t *g_w0 = reinterpret_cast<uint32_t *>(g_a0);
+
+    for (int i = tid; i < HUF_NSYM; i += THREADS) s_ent[i] = pack_ent_of(codes64[i]);
+
+    uint32_t hdr_end;
+    if (!pack_header<THREADS>(len, tb, tree_len, g_a0, g_w0, rec_lo, rec_hi, s_tail, &hdr_end)) return;
+
+    uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
+
+    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
+        /* ---- load + look up: the codes of a group are joined as they arrive ---- */
+        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SPT;
+        const uint32_t nsym = my0 < len ? (uint32_t)dmin<uint64_t>(PACK_SPT, len - my0) : 0u;
+        const uint8_t *p = src + my0;
+        uint32_t pc[NG], ph[NG];                                 /* a group's joined codes / summed length fields */
+        uint32_t mybits;
+        /* (one branch for the wave: the tile of whole, aligned lanes - every tile of a 64 KiB block - has no
+         *  per-symbol "is it there" in it) */
+        if (__builtin_amdgcn_ballot_w64(!(nsym == PACK_SPT && (((uintptr_t)p) & 15u) == 0)) == 0ull) {
+#ifdef PACK_ABLATE_LOAD             /* (timing experiments: the kernel without its input; the output is garbage) */
+            const uint32_t x_ = (uint32_t)my0 * 2654435761u;
+            const uint4 v0 = make_uint4(x_, x_ >> 3, x_ >> 5, x_ >> 7), v1 = make_uint4(x_ >> 1, x_ >> 2, x_ >> 4, x_ >> 6);
+#else
+            const uint4 v0 = load_stream16(reinterpret_cast<const uint4 *>(p));
+            const uint4 v1 = load_stream16(reinterpret_cast<const uint4 *>(p) + 1);
+#endif
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            mybits = pack_join<GROUP, false>(s_ent, w, nsym, pc, ph);
+        } else {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                w[i] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * i + j < (int)nsym) w[i] |= (uint32_t)p[4 * i + j] << (8 * j);
+            }
+            mybits = pack_join<GROUP, true>(s_ent, w, nsym, pc, ph);
+        }
+        uint32_t tile_bits;
+        const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
+        if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
+            if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
+            if (tid == 0) sub_tiles[t0 / TILE] = bitpos - (uint64_t)hdr_end * 8ull;
+        }
+
+        /* ---- shift the codes out (stage, flush: as pack_block).  A lane's place relative to the tile's first word in
+         *      32-bit arithmetic: the tile's first bit is the same for every lane ---- */
+        const uint64_t w_lo = bitpos >> 5, w_hi = (bitpos + tile_bits) >> 5;   /* tile's finished words [w_lo, w_hi) */
+        const uintptr_t stage_addr = (uintptr_t)(g_w0 + w_lo) & ~(uintptr_t)15;
+        const uint32_t i_lo = (uint32_t)(((uintptr_t)(g_w0 + w_lo) - stage_addr) >> 2);
+        const uint32_t i_hi = i_lo + (uint32_t)(w_hi - w_lo);
+        const bool staged = i_hi + 2 <= PACK_STAGE_WORDS;        /* workgroup-uniform */
+        const uint32_t rel = (uint32_t)(bitpos & 31u) + ex;      /* my first bit, from the first bit of word w_lo */
+        const uint32_t n_in = rel & 31u;                         /* leading bits come from the left */
+        uint32_t *const g_first = g_w0 + w_lo + (rel >> 5);
+        uint32_t *const s_first = s_stage + (i_lo + (rel >> 5));
+        uint32_t nwords, nacc, tail_val, first = 0;
+        if (staged) {
+            uint32_t acc = 0;
+            uint32_t tot = n_in | (n_in << 27);                  /* bits so far: bits 0..4 and 27..31 count them mod 32 */
+            const uint32_t gw0 = (uint32_t)(uintptr_t)(lds_word)s_first - 4u;
+            uint32_t gw = gw0;                                   /* LDS byte address of the last finished word (moved, then stored
+                                                                    through: one v_add in place, no copy of the address) */
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                uint32_t tot2;
+                const bool word_done = __builtin_add_overflow(tot, ph[g], &tot2);
+                const uint32_t acc2 = (acc << (ph[g] & 31u)) | pc[g];
+                if (word_done) {
+                    const uint32_t word = __builtin_amdgcn_alignbit(pack_pushed_out(ph[g], acc), acc2, tot2);
+                    gw += 4;
+                    asm volatile("" : "+v"(gw));
+#ifndef PACK_ABLATE_PLACE
+                    *(lds_word)(uintptr_t)gw = __builtin_bswap32(word);
+#else
+                    asm volatile("" :: "v"(word));
+#endif
+                }
+                acc = acc2;
+                tot = tot2;
+            }
+            nwords = (gw - gw0) >> 2;
+            nacc = tot & 31u;
+            tail_val = acc & ((1u << nacc) - 1u);
+        } else {
+            PackAcc<uint32_t> a;
+            a.acc = 0;
+            a.nacc = n_in;
+            a.have_first = false;
+            a.first = 0;
+            a.gw = g_first;
+#pragma unroll 1
+            for (uint32_t k = 0; k < nsym; k++) {
+                const uint2 e = s_ent[src[my0 + k]];
+                a.push32(e.x, e.y & 31u);
+            }
+            nwords = (uint32_t)(a.gw - g_first);
+            nacc = a.nacc;
+            tail_val = a.tail();
+            first = a.first;
+        }
+
+        /* ---- tails hop one lane to the right ---- */
+        uint32_t in_tail = wave_up1_u32(tail_val);
+        if (lane == 63) s_tail[wave] = tail_val;
+        __syncthreads();
+        if (lane == 0) in_tail = (wave == 0) ? s_tail[WAVES] : s_tail[wave - 1];
+        const bool is_last = (nsym > 0) && (my0 + nsym == len);  /* holds the block's last symbol */
+        if (nwords) {
+            const uint32_t lead = n_in ? (in_tail << (32 - n_in)) : 0u;
+            if (staged) {
+                if (n_in) __hip_atomic_fetch_or(s_first, __builtin_bswap32(lead), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                *g_first = __builtin_bswap32(first | lead);
+            }
+        }
+        uint32_t out_tail = tail_val;
+        if (!nwords && nsym > 0) {
+            /* only the block's last lane can be shorter than a word: its tail continues the
+             * neighbour's */
+            out_tail = (n_in ? (in_tail << (nacc - n_in)) : 0u) | tail_val;
+        }
+        if (is_last && nacc) {
+            /* zero-padded final byte(s) (encoder.c:123-128); bytes past the record belong to
+             * the next block */
+            const uint32_t word = out_tail << (32 - nacc);
+            const uint32_t nbytes = (nacc + 7) >> 3;
+            uint8_t *b = reinterpret_cast<uint8_t *>(g_first + nwords);
+            for (uint32_t k = 0; k < nbytes; k++) b[k] = (uint8_t)(word >> (24 - 8 * k));
+        }
+        __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
+        if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
+#ifdef PACK_ABLATE_FLUSH            /* (timing experiments: the kernel without its stores; the output is garbage) */
+        if (staged && len == 0x123456789aull) {
+#else
+        if (staged) {
+#endif
+            uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
+            for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
+                const uint32_t i0 = 4 * u;
+                if (i0 >= i_lo && i0 + 4 <= i_hi) {
+                    store_pack16(reinterpret_cast<uint4 *>(g16 + 4 * i0), *reinterpret_cast<const uint4 *>(s_stage + i0));
+                } else {
+                    for (uint32_t i = (i0 > i_lo ? i0 : i_lo); i < i0 + 4 && i < i_hi; i++)
+                        *reinterpret_cast<uint32_t *>(g16 + 4 * i) = s_stage[i];
+                }
+            }
+        }
+        bitpos += tile_bits;
+        (void)rec_hi;
+    }
+}
+
 /* SHORT = true: the host guarantees that no code of this launch is longer than 24 bits (any
  * Huffman merge order on n <= 121392 symbols gives depth <= 23, plus the wrap-root bit; the
  * deepest tree needs Fibonacci weights), so only the 32-bit code path is compiled - fewer
@@ -370,11 +635,15 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
                                                        uint64_t *__restrict__ offsets, TwoLevel sizes,
                                                        uint8_t *__restrict__ out, HufSubIndex sub)
 {
-    __shared__ hufcode_t s_code[SHORT ? HUF_NSYM / 2 : HUF_NSYM];   /* u32[256] on the short-code path */
+    __shared__ hufcode_t s_code[HUF_NSYM];   /* eight-byte entries on the paths of two and three codes a push (PackEnt), u32[256] for codes up to 24 bits */
     __shared__ uint32_t s_part[THREADS / 64];
     __shared__ uint32_t s_tail[THREADS / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
 
+#ifdef PACK_LDS_PAD             /* (occupancy experiments: fewer workgroups per CU) */
+    __shared__ uint32_t lds_pad[PACK_LDS_PAD / 4];
+    if (n == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
+#endif
 #ifdef PACK_VGPR_SLACK      /* test builds only: "v72" gives the 72-VGPR (7 waves per SIMD) build its register of slack */
     asm volatile("; one VGPR more than the kernel uses" ::: PACK_VGPR_SLACK);
 #endif
@@ -397,12 +666,22 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb : nullptr;
     if (sub.tile_bits && m.tree_len != 5)
         for (int i = (int)threadIdx.x; i < HUF_NSYM; i += THREADS) sub.lens[blk * HUF_NSYM + i] = (uint8_t)(codes[i] & 0xffu);
+#if !defined(PACK_ROUND4_PUSH) && !defined(PACK_ACC64)   /* (-DPACK_ROUND4_PUSH: round 4's placement loop for these blocks too, for A/B timing;
+                                                             -DPACK_ACC64 = round 2's kernel, tests/test_isa_check.py) */
     if (m.max_len <= 10)                 /* three codes per push */
+        pack_block_multi<THREADS, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                     reinterpret_cast<uint2 *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
+    else if (m.max_len <= 15)            /* two codes per push (at most 30 bits) */
+        pack_block_multi<THREADS, 2>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
+                                     reinterpret_cast<uint2 *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
+#else
+    if (m.max_len <= 10)
         pack_block<THREADS, uint32_t, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                          reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
-    else if (m.max_len <= 15)            /* two codes per push (at most 31 bits: PackAcc<uint32_t>) */
+    else if (m.max_len <= 15)
         pack_block<THREADS, uint32_t, 2>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                             reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);
+#endif
     else if (SHORT || m.max_len <= 24)
         pack_block<THREADS, uint32_t>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                       reinterpret_cast<uint32_t *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);

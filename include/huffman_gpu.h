@@ -102,7 +102,7 @@ int hufgpu_decode(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
 /*
  * The same pair with the encoder's SUB-INDEX: besides the block index the encoder can hand over
  * where, inside every block's payload, each group of 32 symbols starts (2 bytes per 32 symbols +
- * 8 bytes per 8 192 symbols + the 256 code lengths of every block; hufgpu_sub_index_bytes() bytes, 8-byte aligned, in HBM).  Like the
+ * 8 bytes per 2 048 symbols + the 256 code lengths of every block; hufgpu_sub_index_bytes() bytes, 8-byte aligned, in HBM).  Like the
  * block index it is in-process side information - the stream is the reference's, byte for byte.
  * With it hufgpu_decode_sub() decodes every symbol once instead of finding the codeword starts by
  * decoding speculatively (src/decoder.c:34-96 has the same information implicitly: it walks the

@@ -14,7 +14,8 @@ namespace hufgpu {
 
 /* ======================================================================================
  * Decode with the sub-index pack_kernel writes (pack.hpp, HufSubIndex): the payload bits of every
- * group of 32 symbols and the first payload bit of every tile of 8 192 symbols.
+ * group of 32 symbols and the first payload bit of every tile of 2 048 symbols (= 64 groups = what
+ * one wavefront takes at a time).
  *
  * The self-synchronising decoder (decode.hpp) has to find out where codewords start: every symbol
  * is decoded at least twice (count pass + write pass) plus the synchronisation rounds.  Here a
@@ -24,20 +25,37 @@ namespace hufgpu {
  *   (a) the block's first tile starts at payload bit 0,
  *   (b) a lane's 32 codewords take exactly the bits its group is said to have, none of its walks
  *       leaves the tree and none needs bits past the payload,
- *   (c) a chunk (the part of a block one workgroup decodes) ends where the next chunk is said to
- *       start.
+ *   (c) a tile ends where the next tile of the block is said to start (the block's last: inside
+ *       the payload).
  * By induction over the lanes these make the output equal to that of the in-order decoder of
  * src/decoder.c:34-96.  A block that fails any of them - a stale or foreign sub-index, a damaged
  * stream - is appended to a list and decoded again by decode_fix_kernel with the exact
  * self-synchronising decoder, which also produces the reference's error code: a wrong sub-index
  * costs time, never correctness.
+ *
+ * Round 5: every wave is on its own from the table build on (round 4 staged a chunk's 2 048 group
+ * counts in LDS and summed them across the workgroup to find the waves' starts - 4 KiB, a load
+ * through LDS-DMA, two scans and two barriers - where the sub-index now simply says where a wave
+ * tile starts), and the payload words of a tile lie in LDS as one private COLUMN per lane: word g
+ * of a lane's group at row D - 1 - g of the wave's slice, a row = the 64 lanes' words side by side.
+ * A lane's reads fall into its own bank whatever the positions of the other lanes are (round 4: a
+ * linear stage, the window read - two dwords a lane at data-dependent offsets - cost 10 LDS cycles
+ * where it now costs 4; SQ_LDS_BANK_CONFLICT was 60 % of the kernel's LDS cycles).  The price: a
+ * lane loads its own twelve dwords (three 16-byte loads at the lane's own 4-byte aligned address;
+ * neighbours overlap, the overlap comes from the vector cache) instead of a 16-byte share of the
+ * tile's, and a group must fit eleven words behind its first (at most 320 bits, i.e. 10 bits a
+ * symbol; tiles beyond that are staged and decoded step by step).
  * ==================================================================================== */
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
 #define DSUB_L2_BITS 6u                     /* a second-level table takes codes of up to 12 + 6 bits */
-#define DSUB_L2_ENTRIES 1024u               /* it lives in DecShared::ent */
-#define DSUB_SLACK_WORDS 16                 /* staged behind the last needed word: what a lane that runs wild (32 look-ups of at most 18 bits) or a long code's walk may look at */
+#define DSUB_L2_ENTRIES 1024u               /* it lives in DsubShared::ent */
+#define DSUB_SLACK_WORDS 16                 /* (step-by-step path) staged behind the last needed word: what a lane that runs wild (32 look-ups of at most 18 bits) or a long code's walk may look at */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
-#define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: four tiles of 512 x 32 */
+#define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: 32 wave tiles */
+#define DSUB_ROWS 12                         /* words of a lane's column */
+#define DSUB_COL_BITS (32u * (DSUB_ROWS - 1))   /* a lane's lead + group bits may be this much: the window at the group's last
+                                                codeword reads the word behind the one it starts in */
+static_assert(HUF_SUB_TILE == 64 * DSUB_SPL, "a sub-index tile is a wave tile");
 
 /* The staged payload words of a wave lie in its LDS slice in REVERSED order: word g (big-endian, 32 payload bits)
  * at top[-g].  The hot loop's position register then counts DOWN, and both the pair's LDS address and the
@@ -93,25 +111,6 @@ struct RevReader {
 #define DSE_LEN(e) ((e) & 31u)
 #define DSE_IS_L2(e) (((e) & 0x3fu) == DSE_L2)
 
-/* bit-serial walk from the root on the reversed stage (tables of dec_build_tables: sh.lr, sh.ent);
- * result as dec_rare_packed */
-template <int THREADS>
-__device__ __forceinline__ uint64_t dsub_rare_walk(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t pos, uint32_t lim)
-{
-    uint32_t node = 0;
-    uint32_t p = pos;
-    for (;;) {
-        if (p >= lim) return (uint64_t)CW_EXH << 40;
-        const uint32_t bit = (rev_word(top, p >> 5) >> (31u - (p & 31u))) & 1u;
-        p++;
-        const uint32_t nx = dec_child(sh.lr[node], bit);
-        if (nx == DEC_NULL) return ((uint64_t)CW_BAD << 40) | p;
-        node = nx;
-        if (sh.lr[node] == DEC_LEAF_LR) break;
-    }
-    return ((uint64_t)CW_OK << 40) | ((uint64_t)(uint8_t)sh.ent[node] << 32) | p;
-}
-
 /* ======================================================================================
  * Tables from the stream's tree AND the encoder's code lengths, in a few parallel steps.
  *
@@ -135,14 +134,33 @@ __device__ __forceinline__ uint64_t dsub_rare_walk(const DecShared<THREADS> &sh,
  * LDS: code[256] (left-aligned in 32 bits), length[256], byte[256] of the leaves in preorder in
  * sh.lr; sh.fastk = K.
  * ==================================================================================== */
+template <class SH>
+struct FastLdsOf {
+    __device__ static __forceinline__ uint32_t *code(SH &sh) { return sh.lr; }
+    __device__ static __forceinline__ uint8_t *len(SH &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 256); }
+    __device__ static __forceinline__ uint8_t *sym(SH &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 320); }
+    __device__ static __forceinline__ const uint32_t *code(const SH &sh) { return sh.lr; }
+    __device__ static __forceinline__ const uint8_t *len(const SH &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 256); }
+    __device__ static __forceinline__ const uint8_t *sym(const SH &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 320); }
+};
 template <int THREADS>
-struct DsubFastLds {
-    __device__ static __forceinline__ uint32_t *code(DecShared<THREADS> &sh) { return sh.lr; }
-    __device__ static __forceinline__ uint8_t *len(DecShared<THREADS> &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 256); }
-    __device__ static __forceinline__ uint8_t *sym(DecShared<THREADS> &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 320); }
-    __device__ static __forceinline__ const uint32_t *code(const DecShared<THREADS> &sh) { return sh.lr; }
-    __device__ static __forceinline__ const uint8_t *len(const DecShared<THREADS> &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 256); }
-    __device__ static __forceinline__ const uint8_t *sym(const DecShared<THREADS> &sh) { return reinterpret_cast<const uint8_t *>(sh.lr + 320); }
+using DsubFastLds = FastLdsOf<DecShared<THREADS>>;        /* (decode_fast.hpp keeps its leaves the same way) */
+
+/* LDS of decode_sub_kernel.  (Member names as in DecShared where the table build uses them.) */
+template <int THREADS>
+struct DsubShared {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr uint32_t SLICE_WORDS = 64u * DSUB_ROWS;      /* a wave's columns: row r of lane l at slice[64 r + l] */
+    uint16_t lut[1 << DEC_LUT_BITS];                             /* first-level table */
+    uint32_t lr[384];                                            /* the leaves in preorder: code[256] (left-aligned), length[256], byte[256] (FastLdsOf) */
+    int16_t ent[DSUB_L2_ENTRIES];                                /* second-level tables */
+    __attribute__((aligned(256))) uint32_t pay[WAVES * SLICE_WORDS];  /* the waves' slices (the table build's scratch before that); a ROW - 256 bytes -
+                                                                    at a multiple of 256: a row's number and a lane's offset in it are bit fields of an LDS address */
+    uint32_t part[WAVES];
+    uint32_t wtile[3 * WAVES];                                   /* partial sums of the table build's code scan */
+    uint32_t fastk;                                              /* leaves of the tables */
+    uint32_t l2n;                                                /* entries of the second-level tables (0: none) */
+    uint32_t firstone;                                           /* decode_single_leaf */
 };
 
 /* largest k < K with code[k] <= v (code[0] = 0) */
@@ -185,11 +203,11 @@ __device__ __forceinline__ DsubTreeWords dsub_tree_request(const uint8_t *tree, 
     return w;
 }
 
-template <int THREADS>
-__device__ bool dsub_fast_tables(DecShared<THREADS> &sh, int tree_len, const DsubTreeWords &tw)
+template <int THREADS, class SH>
+__device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
 {
-    typedef DsubFastLds<THREADS> F;
-    constexpr int ENT = DecShared<THREADS>::ENT;
+    typedef FastLdsOf<SH> F;
+    constexpr int ENT = HUF_TREE_MAX + 1;
     constexpr int WAVES = THREADS / 64;
     static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256 && WAVES <= 8, "two entries per thread");
     const int tid = (int)threadIdx.x;
@@ -356,32 +374,9 @@ __device__ bool dsub_fast_tables(DecShared<THREADS> &sh, int tree_len, const Dsu
     return __syncthreads_and(ok ? 1 : 0) != 0;
 }
 
-/* The tables of dec_build_tables (any grammar-valid tree; taken when dsub_fast_tables declines) in the sub-index
- * path's entry format: eight entries per thread.  `long` codes are then walked from the root. */
-template <int THREADS>
-__device__ __forceinline__ void dsub_convert_tables(DecShared<THREADS> &sh)
-{
-    static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
-    uint32_t *t = reinterpret_cast<uint32_t *>(sh.lut) + 4 * threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t two = t[i];
-        uint32_t r = 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t e = (two >> (16 * h)) & 0xffffu;
-            const uint32_t n = (e >= DEC_E_LONG) ? DSE_LONG : (e >= DEC_E_BAD) ? DSE_BAD : (((e & 0xffu) << 8) | (e >> 8));
-            r |= n << (16 * h);
-        }
-        t[i] = r;
-    }
-    if (threadIdx.x == 0) { sh.fastk = 0; sh.l2n = 0; }
-    __syncthreads();
-}
-
 /* a second-level entry of the first table resolved with the 32 bits at the codeword's start */
-template <int THREADS>
-__device__ __forceinline__ uint32_t dsub_l2(const DecShared<THREADS> &sh, uint32_t e, uint32_t bits32)
+template <class SH>
+__device__ __forceinline__ uint32_t dsub_l2(const SH &sh, uint32_t e, uint32_t bits32)
 {
     const uint32_t nb = ((e >> 5) & 6u) + 2u;
     return reinterpret_cast<const uint16_t *>(sh.ent)[((e >> 8) << 2) + ((bits32 << DEC_LUT_BITS) >> (32u - nb))];
@@ -389,10 +384,10 @@ __device__ __forceinline__ uint32_t dsub_l2(const DecShared<THREADS> &sh, uint32
 
 /* a codeword longer than the table's 12 bits with dsub_fast_tables' tables: the leaf whose code
  * interval holds the 32 bits at the position; result as dec_rare_packed */
-template <int THREADS>
-__device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t pos, uint32_t lim)
+template <class SH>
+__device__ __forceinline__ uint64_t dec_rare_fast(const SH &sh, const uint32_t *top, uint32_t pos, uint32_t lim)
 {
-    typedef DsubFastLds<THREADS> F;
+    typedef FastLdsOf<SH> F;
     const uint32_t g = pos >> 5, o = pos & 31u;
     const uint32_t w = o ? ((rev_word(top, g) << o) | (rev_word(top, g + 1) >> (32u - o))) : rev_word(top, g);
     if (w >> 31) return ((uint64_t)CW_BAD << 40) | (pos + 1u);
@@ -404,15 +399,15 @@ __device__ __forceinline__ uint64_t dec_rare_fast(const DecShared<THREADS> &sh, 
 
 /* One table step of a lane on the step-by-step path: returns the entry (high byte = symbol); *ok is cleared
  * when the lookup is not a codeword.  The rare paths sit behind one wave-uniform branch. */
-template <int THREADS>
-__device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, RevReader &rd, uint32_t lim, bool &ok)
+template <class SH>
+__device__ __forceinline__ uint32_t dsub_next(const SH &sh, RevReader &rd, uint32_t lim, bool &ok)
 {
     uint32_t e = sh.lut[rd.index()];
     if (__builtin_expect(__ballot(DSE_LEN(e) == 0u) != 0ull, 0)) {
         if (DSE_IS_L2(e)) {
-            e = dsub_l2<THREADS>(sh, e, rd.hi);
+            e = dsub_l2(sh, e, rd.hi);
         } else if (e == DSE_LONG) {
-            const uint64_t r = sh.fastk ? dec_rare_fast<THREADS>(sh, rd.top, rd.pos(), lim) : dsub_rare_walk<THREADS>(sh, rd.top, rd.pos(), lim);
+            const uint64_t r = dec_rare_fast(sh, rd.top, rd.pos(), lim);
             if ((int)(r >> 40) == CW_OK) {
                 rd.load((uint32_t)r);
                 e = ((uint32_t)(r >> 32) & 0xffu) << 8;    /* advance 0: the reader already stands behind it */
@@ -429,49 +424,20 @@ __device__ __forceinline__ uint32_t dsub_next(const DecShared<THREADS> &sh, RevR
     return e;
 }
 
-/* LDS of the sub-index path inside DecShared: the area of the self-synchronising decoder's payload
- * image and marks holds one private slice of staged payload words per WAVE and, at its end, the
- * chunk's group bit counts (fetched by LDS-DMA while the tables are built; the table build's
- * scratch lies in front of them). */
+/* The step-by-step path (long codes, tiles that do not fit the columns, the block's last, short group) stages
+ * into the wave's slice linearly and in reversed order: word g at top[-g]. */
 template <int THREADS>
 struct DsubLds {
-    static constexpr int WAVES = THREADS / 64;
-    static constexpr uint32_t AREA_WORDS = (uint32_t)((sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark)) / sizeof(uint32_t));
-    static constexpr uint32_t GROUPS = DSUB_CHUNK_SYMS / DSUB_SPL;          /* groups per chunk */
-    static constexpr uint32_t WTILES = GROUPS / 64;                         /* wave tiles (64 groups) per chunk */
-    static constexpr uint32_t GB_WORDS = GROUPS / 2;                        /* two 16-bit counts per word */
-    static constexpr uint32_t SLICE_WORDS = ((AREA_WORDS - GB_WORDS) / WAVES) & ~3u;
-    static constexpr uint32_t CAP_BITS = (SLICE_WORDS - DSUB_SLACK_WORDS - 2 - 4) * 32u;   /* (- 4: slices are written 16 bytes at a time) */
-    static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
-    static_assert(offsetof(DecShared<THREADS>, pay) % 16 == 0 && SLICE_WORDS % 4 == 0, "16-byte slice stores");
+    static constexpr uint32_t SLICE_WORDS = DsubShared<THREADS>::SLICE_WORDS;
+    static constexpr uint32_t CAP_BITS = (SLICE_WORDS - DSUB_SLACK_WORDS - 2 - 4) * 32u;
     static_assert(CAP_BITS >= DSUB_MAX_GROUP_BITS + 32u, "one lane's group always fits a slice");
-    static_assert(SLICE_WORDS <= 3 * 256, "three staging steps of 64 lanes x 4 words cover a slice");
-    static_assert((AREA_WORDS - GB_WORDS) * 4 >= ((DecShared<THREADS>::ENT + 1) / 2) * 4 + 2 * 2048 * 2, "the table build's scratch lies in front of the group counts");
-    static_assert(WTILES <= 64 && WTILES % WAVES == 0 && WTILES <= sizeof(DecShared<THREADS>::wtile) / 4, "a wave scans the tile totals in one step");
-    __device__ static __forceinline__ uint32_t *slice(DecShared<THREADS> &sh, int wave) { return sh.pay + (uint32_t)wave * SLICE_WORDS; }
-    __device__ static __forceinline__ uint32_t *gb(DecShared<THREADS> &sh) { return sh.pay + (AREA_WORDS - GB_WORDS); }
+    __device__ static __forceinline__ uint32_t *slice(DsubShared<THREADS> &sh, int wave) { return sh.pay + (uint32_t)wave * SLICE_WORDS; }
 };
-
-/* The chunk's group bit counts are requested first (LDS-DMA: no register waits for them), so that
- * their latency passes under the table build.  grp = the chunk's first count (4-byte aligned: rows
- * of the sub-index are padded), ngrp = groups the chunk has. */
-template <int THREADS>
-__device__ __forceinline__ void dsub_prefetch(DecShared<THREADS> &sh, const uint16_t *__restrict__ grp, uint32_t ngrp)
-{
-    const uint32_t *g32 = reinterpret_cast<const uint32_t *>(grp);
-    const uint32_t nd = (ngrp + 1u) >> 1;
-    const uint32_t wave = threadIdx.x >> 6;
-#pragma unroll
-    for (uint32_t k = 0; k < DsubLds<THREADS>::GB_WORDS / THREADS; k++) {
-        const uint32_t d = k * THREADS + threadIdx.x;
-        if (d < nd) __builtin_amdgcn_global_load_lds(g32 + d, DsubLds<THREADS>::gb(sh) + k * THREADS + wave * 64u, 4, 0, 0);
-    }
-}
 
 /* A group again, step by step with the rare paths (long codes; the block's last, short group).
  * Out of line: inlined, its state competes with the hot loop's for the 64 VGPRs. */
 template <int THREADS>
-__device__ __noinline__ bool dsub_redo_group(const DecShared<THREADS> &sh, const uint32_t *top, uint32_t s, uint32_t nsym,
+__device__ __noinline__ bool dsub_redo_group(const DsubShared<THREADS> &sh, const uint32_t *top, uint32_t s, uint32_t nsym,
                                              uint32_t lim, uint32_t gb, uint8_t *dst)
 {
     bool ok = true;
@@ -479,19 +445,19 @@ __device__ __noinline__ bool dsub_redo_group(const DecShared<THREADS> &sh, const
     rd.top = top;
     rd.load(s);
     for (uint32_t k = 0; k < nsym; k++) {
-        dst[k] = (uint8_t)(dsub_next<THREADS>(sh, rd, lim, ok) >> 8);
+        dst[k] = (uint8_t)(dsub_next(sh, rd, lim, ok) >> 8);
         if (rd.avail <= 32) rd.refill();
     }
     return ok && rd.pos() - s == gb;
 }
 
-/* A wave tile whose bits do not fit the wave's slice in one piece (codes far longer than the 9-bit average), or
- * whose words cannot be loaded 16 bytes at a time (the stream ends right behind them): the lanes in several
- * runs, staged word by word, decoded step by step.  Rare, and out of line for the hot path's registers.
- * first = the tile's first payload bit, ex / incl = the lane's exclusive / inclusive bit counts inside the tile,
- * active = the lane's group is to be decoded. */
+/* A wave tile the columns cannot take (a group of more than 320 bits: codes far longer than the 9-bit average; a
+ * tile whose loads would run past the stream's end), or lanes of a tile that met a code the tables do not hold:
+ * the lanes in several runs, staged word by word, decoded step by step.  Rare, and out of line for the hot path's
+ * registers.  first_bit = the tile's first payload bit, ex / incl = the lane's exclusive / inclusive bit counts
+ * inside the tile, active = the lane's group is to be decoded. */
 template <int THREADS>
-__device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32_t *top, const uint8_t *pay, uint64_t pay_bytes,
+__device__ __noinline__ bool dsub_tile_slow(const DsubShared<THREADS> &sh, uint32_t *top, const uint8_t *pay, uint64_t pay_bytes,
                                             uint64_t first_bit, uint32_t ex, uint32_t incl, uint32_t nsym, bool active, uint8_t *dst)
 {
     constexpr uint32_t CAP_BITS = DsubLds<THREADS>::CAP_BITS;
@@ -520,61 +486,40 @@ __device__ __noinline__ bool dsub_tile_slow(const DecShared<THREADS> &sh, uint32
 }
 
 /* The symbols [sym0, sym1) of a block (sym0 a multiple of DSUB_CHUNK_SYMS) with the block's sub-index.
- * Tables are in sh, dsub_prefetch has been called.  Returns true (workgroup-uniform) when everything
- * was verified; *end_bit = the payload bit behind the chunk's last symbol.  T0 = the chunk's first
- * payload bit, as told; readable = bytes that may be loaded from `pay` on (to the end of the stream); safe = an
- * address with 19 readable bytes behind it (the block's header and tree).
+ * Returns true (workgroup-uniform) when everything was verified.  told = the first payload bit of the chunk's wave
+ * tiles as the sub-index has them (told[q] for the chunk's tile q; told[ntiles] is looked at only when the block goes
+ * on behind the chunk), grp = the chunk's group bit counts; readable = bytes that may be loaded from `pay` on (to the
+ * end of the stream); safe = an address with 64 readable bytes behind it (the block's header and tree: >= 19 bytes,
+ * then payload or the next block - see the caller).
  *
- * After one scan of the group counts every WAVE is on its own: a wave tile = 64 groups = 2 048
- * symbols; wave w takes tiles w, w + 8, ...; it stages the tile's payload words in its private LDS
- * slice (LDS operations of one wave are in order: no barrier), decodes, stores.  The words of the wave's
- * NEXT tile are requested before it decodes this one and wait in twelve registers: the HBM latency
- * (a quarter of a workgroup's life when every tile waited for its own loads) passes under the decoding. */
+ * Wave w takes tiles w, w + 8, ...: the lanes' bit counts, one scan, the check against the next tile's start, and
+ * every lane requests the twelve dwords from the one that holds its first bit on.  The words of the wave's NEXT tile
+ * are requested before it decodes this one and wait in twelve registers: the HBM latency passes under the decoding.
+ * No barrier after the table build. */
 template <int THREADS>
-__device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *lens_g,
+__device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *lens_g,
                                    const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, const uint8_t *safe,
-                                   uint64_t sym0, uint64_t sym1, uint64_t T0, uint8_t *gout, uint64_t *end_bit)
+                                   uint64_t sym0, uint64_t sym1, bool block_goes_on, const uint64_t *__restrict__ told,
+                                   const uint16_t *__restrict__ grp, uint8_t *gout)
 {
-    /* the table build's words from global memory are on their way while the group counts are scanned */
+    /* the table build's words from global memory are on their way while the first tile is set up */
     const DsubTreeWords tw = dsub_tree_request<THREADS>(tree, tree_len, lens_g);
     typedef DsubLds<THREADS> L;
     constexpr int WAVES = THREADS / 64;
-    constexpr uint32_t CAP_BITS = L::CAP_BITS;
+    constexpr uint32_t ROWS = DSUB_ROWS;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = (int)uni32((uint32_t)tid >> 6);       /* (the compiler does not know that a wave's threads share tid >> 6) */
     const uint64_t pay_bits = pay_bytes * 8ull;
-    const uint16_t *s_gb = reinterpret_cast<const uint16_t *>(L::gb(sh));
-    uint32_t *top = L::slice(sh, wave) + (L::SLICE_WORDS - 1u);      /* staged word g of the wave's tile at top[-g] */
-    const uint32_t ngrp = (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL);
+    uint32_t *slice = L::slice(sh, wave);
+    uint32_t *top = slice + (L::SLICE_WORDS - 1u);                   /* step-by-step path: staged word g at top[-g] */
+    const uint32_t nchunk = (uint32_t)(sym1 - sym0);
+    const uint32_t ngrp = (nchunk + DSUB_SPL - 1) / DSUB_SPL;
+    const uint32_t ntiles = (ngrp + 63u) / 64u;
     bool ok = true;
     unsigned long long pt = DPROF_T();
 
-    /* the group counts requested by dsub_prefetch have landed (every wave waits for its own
-     * requests, the barrier makes them everybody's) */
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (sym0 == 0 && T0 != 0) ok = false;          /* (a) */
-
-    /* bits of every wave tile, then their inclusive sums (lane q of every wave holds tile q's) */
-#pragma unroll
-    for (uint32_t k = 0; k < L::WTILES / WAVES; k++) {
-        const uint32_t q = (uint32_t)wave * (L::WTILES / WAVES) + k;
-        const uint32_t g = q * 64u + (uint32_t)lane;
-        uint32_t v = (g < ngrp) ? (uint32_t)s_gb[g] : 0u;
-        if (v > DSUB_MAX_GROUP_BITS) { v = DSUB_MAX_GROUP_BITS; ok = false; }
-        v = wave_lane_u32(wave_incl_scan_u32(v), 63);
-        if (lane == 0) sh.wtile[q] = v;
-    }
-    __syncthreads();
-    const uint32_t tincl = wave_incl_scan_u32(((uint32_t)lane < L::WTILES) ? sh.wtile[lane] : 0u);   /* lane q: bits of tiles 0 .. q */
-    const uint32_t chunk_bits = wave_lane_u32(tincl, 63);
-    if (T0 + chunk_bits > pay_bits) {                                /* (b): bits past the payload (the same in every thread) */
-        *end_bit = 0;
-        return false;
-    }
-    DPROF_ADD(8, pt);
-
     typedef const __attribute__((address_space(3))) uint32_t *lds_words;
+    typedef __attribute__((address_space(3))) uint32_t *lds_words_w;
     typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
     typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
     typedef uint32_t dwords4 __attribute__((ext_vector_type(4)));
@@ -582,88 +527,122 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
     typedef const __attribute__((address_space(1))) dwords4_a4 *global_q4;
     typedef __attribute__((address_space(1))) uint8_t *global_out;
     typedef __attribute__((address_space(1))) dwords4 *global_out4;
-    /* The position register: R = 8 * (LDS byte address of top[-1]) + 31 - (position - 1), position = bits from the
-     * stage's word 0.  With the words in reversed order, (R >> 3) & ~3 IS the LDS address of the SECOND word of the
-     * pair that holds bit position - 1, and the low five bits of R are the amount v_alignbit_b32 shifts that pair
-     * by to leave the 32 bits at the position (0..31: the position is never the pair's first bit) - no negation,
+    /* The position register of a lane: R = 32 * (number of the slice's last row) - position, position = bits from
+     * the first bit of the lane's word 0, rows numbered from LDS address 0 in units of 256 bytes (the slices lie at
+     * multiples of that).  Word g lies at row last - g, so R >> 5 IS the row of word g + 1 - the lower of the two
+     * rows that hold the 32 bits at the position: its address is (R << 3) & ~255 | 4 * lane, one shift and one
+     * v_and_or_b32 - and the low five bits of R are the amount v_alignbit_b32 shifts that pair by (0..31; at amount
+     * 0 the position is the first bit of the LOWER row's word and the upper row is not looked at) - no negation,
      * and a codeword is R -= len. */
-    const uint32_t r_origin = 8u * (uint32_t)(uintptr_t)(lds_words)(top - 1) + 32u;       /* R of position 0 */
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    const uint32_t slice_a = uni32((uint32_t)(uintptr_t)(lds_words)slice);                             /* LDS byte address of the wave's slice */
+    const uint32_t r_top = 32u * ((slice_a >> 8) + ROWS - 1u);                                           /* R of position 0 */
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
     const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
     const uintptr_t cout_a = (uintptr_t)uni64((uint64_t)(uintptr_t)(gout + sym0));           /* the chunk's first output byte */
     const global_out cout = (global_out)cout_a;
-    const uint32_t nchunk = (uint32_t)(sym1 - sym0);
     const uint64_t end_a = uni64((uint64_t)pay_a + readable);                                 /* the stream's end */
     const uintptr_t safe_a = ((uintptr_t)uni64((uint64_t)(uintptr_t)safe) + 3u) & ~(uintptr_t)3;
 
-    /* A tile's staging, all wave-uniform: word 0 of the stage is the aligned 32-bit word of MEMORY that holds the
-     * tile's first bit (the stage words are then byte-swapped dwords, whatever the payload's alignment);
-     * `lead` = bits of that word in front of the tile, `nwords` = words to stage; `quick` = its bits fit the slice
-     * and 16-byte loads of all of them stay inside the stream. */
-    uint32_t q = (uint32_t)wave;
+    /* A tile's set-up.  The lane's column starts with the aligned 32-bit word of MEMORY that holds the lane's first
+     * bit (the staged words are then byte-swapped dwords, whatever the payload's alignment).
+     *   gb, nsym   : the lane's group as told / its symbols
+     *   ex         : payload bits of the tile in front of the lane's group
+     *   lead       : bits of the column's word 0 in front of the group (0..31)
+     *   quick      : every group fits its column and the loads stay inside the stream (wave-uniform)
+     *   V[3]       : the column's twelve dwords, requested here
+     * and check (c) / (a) of the tile.  (The loads are issued - and waited for further down - for every tile, also
+     * when there is nothing to load: the block's first bytes then, not stored.  Loads under a condition leave the
+     * compiler with "maybe pending" registers at the top of the loop, and its wait for those is a wait for the
+     * previous tile's STORES as well.) */
     uint4 V[3];
-    uint32_t lead = 0, nwords = 0;
-    bool quick = false;
-/* (The loads are issued - and waited for further down - for every tile, also when there is nothing to load: the words
- * of the block's first bytes then, not stored.  Loads under a condition leave the compiler with "maybe pending"
- * registers at the top of the loop, and its wait for those is a wait for the previous tile's STORES as well.) */
-#define DSUB_GEOMETRY(Q_, VALID_)                                                                              \
+    uint32_t gb_n = 0, nsym_n = 0, lead_n = 0;
+    bool quick_n = false;
+    /* What the sub-index says about a tile is requested TWO tiles ahead (the words themselves one tile ahead): the
+     * tile's start and the next tile's through the scalar cache (the sub-index is not written by this kernel: constant
+     * address space), the lane's bit count by one 2-byte load.  Asked for where they are used, each tile began with two
+     * memory round trips one after the other. */
+    typedef const __attribute__((address_space(4))) uint64_t *const_u64;
+    const const_u64 told_c = (const_u64)(uintptr_t)uni64((uint64_t)(uintptr_t)told);
+    uint64_t t_f = 0, tn_f = 0;                                      /* fetched: the tile's first bit, the next tile's */
+    uint32_t gb_f = 0;                                               /* fetched: my group's bits */
+#define DSUB_FETCH(Q_)                                                                                         \
     {                                                                                                         \
-        const uint32_t qq_ = (VALID_) ? (Q_) : 0u;                                                            \
-        const uint32_t t0_ = qq_ ? wave_lane_u32(tincl, qq_ - 1u) : 0u;                                        \
-        const uint32_t tb_ = wave_lane_u32(tincl, qq_) - t0_;                                                  \
-        const uint64_t first_ = T0 + t0_;                                                                     \
-        const uintptr_t a_ = pay_a + (uintptr_t)(first_ >> 3);                                                \
-        lead = (uint32_t)(first_ & 7u) + 8u * (uint32_t)(a_ & 3u);                                            \
-        const uint32_t need_ = lead + tb_;                                                                    \
-        nwords = ((need_ + 31u) >> 5) + DSUB_SLACK_WORDS + 2u;                                                \
-        /* (the aligned word may begin up to 3 bytes in front of the payload: header and tree lie there) */      \
-        const int64_t left_ = (int64_t)(end_a - (uint64_t)(a_ & ~(uintptr_t)3));    /* readable bytes from the aligned word on */ \
-        quick = (VALID_) && need_ <= CAP_BITS && left_ >= (int64_t)(4u * nwords + 16u);                       \
-        global_bytes base_ = (global_bytes)(uintptr_t)uni64((uint64_t)(quick ? (a_ & ~(uintptr_t)3) : safe_a)); \
-        const uint32_t last16_ = uni32(quick ? 4u * ((nwords - 1u) & ~3u) : 0u);                              \
-        if (!quick) nwords = 0;                                                                               \
-        uint32_t ln_ = (uint32_t)lane;                                                                        \
-        asm volatile("" : "+v"(ln_));            /* (offsets computed here, not kept in registers around the tile loop) */ \
+        const uint32_t q_ = (Q_);                                                                             \
+        const bool valid_ = q_ < ntiles;                                                                      \
+        const uint32_t qq_ = valid_ ? q_ : 0u;                                                                \
+        const bool more_ = valid_ && (qq_ + 1u < ntiles || block_goes_on);                                    \
+        t_f = told_c[qq_];                                                                                    \
+        tn_f = told_c[more_ ? qq_ + 1u : qq_];                                                                \
+        const uint32_t g_ = qq_ * 64u + (uint32_t)lane;                                                       \
+        gb_f = (valid_ && g_ < ngrp) ? (uint32_t)grp[g_] : 0u;                                                \
+    }
+/* (Everything about a tile relative to the chunk's first, in 32-bit scalar arithmetic: a chunk's payload is less
+ * than 2^22 bits long; a told start that is not inside that is wrong.  The fetch for the tile after the next
+ * stands BETWEEN this tile's arithmetic and its loads: what it asks for is then complete when the words are, and
+ * the top of the loop waits for nothing - behind the words it would wait for the previous tile's stores as well.) */
+#define DSUB_SETUP(Q_, FETCH_Q_)                                                                               \
+    {                                                                                                         \
+        const uint32_t q_ = (Q_);                                                                             \
+        const bool valid_ = q_ < ntiles;                                                                      \
+        const uint32_t qq_ = valid_ ? q_ : 0u;                                                                \
+        const uint64_t d_ = t_f - T0;                                                   /* the tile's first bit from the chunk's */ \
+        const uint32_t rel_t_ = (uint32_t)d_;                                                                 \
+        const bool more_ = valid_ && (qq_ + 1u < ntiles || block_goes_on);                                    \
+        const uint32_t g_ = qq_ * 64u + (uint32_t)lane;                                                       \
+        gb_n = dmin<uint32_t>(gb_f, DSUB_MAX_GROUP_BITS);                                                     \
+        nsym_n = (valid_ && g_ < ngrp) ? dmin<uint32_t>(DSUB_SPL, nchunk - g_ * DSUB_SPL) : 0u;               \
+        const uint32_t incl_ = wave_incl_scan_u32(gb_n);                                                      \
+        const uint32_t tb_ = wave_lane_u32(incl_, 63);                                                        \
+        const bool fine_ = valid_ && chunk_fine && uni32((uint32_t)(d_ >> 32)) == 0u && rel_t_ <= room0 && tb_ <= room0 - rel_t_;   /* (b) */ \
+        if (valid_ && !fine_) ok = false;                                                                     \
+        if (fine_ && more_ && t_f + tb_ != tn_f) ok = false;                             /* (c) */              \
+        const uint32_t rel_ = uni32(lead0 + (fine_ ? rel_t_ : 0u)) + (incl_ - gb_n);     /* my first bit from the chunk's aligned first word */ \
+        lead_n = rel_ & 31u;                                                                                  \
+        uint32_t off_ = (rel_ >> 5) << 2;                                               /* my column's word 0, bytes from that word */ \
+        const uint32_t last_ = wave_lane_u32(off_, 63);                                 /* (offsets grow with the lane) */ \
+        quick_n = fine_ && last_ <= left0 && left0 - last_ >= 4u * ROWS && __ballot(lead_n + gb_n > DSUB_COL_BITS) == 0ull; \
+        global_bytes base_ = (global_bytes)(uintptr_t)uni64((uint64_t)(quick_n ? base0 : safe_a));             \
+        if (!quick_n) off_ = 0;                                                                               \
+        DSUB_FETCH(FETCH_Q_)                                                                                  \
         _Pragma("unroll")                                                                                     \
         for (int k = 0; k < 3; k++) {                                                                         \
-            /* every lane loads (lanes past the needed words load the last ones again and do not store them) */ \
-            const uint32_t off_ = dmin<uint32_t>(16u * ln_ + 1024u * (uint32_t)k, last16_);                   \
-            const dwords4 v_ = *(global_q4)(base_ + off_);                                                    \
+            const dwords4 v_ = *(global_q4)(base_ + off_ + 16 * k);                                           \
             V[k] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                                        \
         }                                                                                                     \
     }
-/* the loaded words into the slice: four byte-swapped dwords per lane and step, one 16-byte LDS store
- * (words i4 .. i4 + 3 at top[-i4 - 3 .. -i4]) */
+/* the loaded words into the column: word g (byte-swapped) at row ROWS - 1 - g */
 #define DSUB_TO_SLICE()                                                                                        \
-    {                                                                                                         \
-        uint32_t ln_ = (uint32_t)lane;                                                                        \
-        asm volatile("" : "+v"(ln_));                                                                         \
+    if (quick_n) {                                                                                            \
+        lds_words_w col_ = (lds_words_w)(uintptr_t)(slice_a + lane4);   /* row 0 of my column */               \
+        const uint32_t wv_[12] = {V[0].x, V[0].y, V[0].z, V[0].w, V[1].x, V[1].y, V[1].z, V[1].w, V[2].x, V[2].y, V[2].z, V[2].w}; \
         _Pragma("unroll")                                                                                     \
-        for (int k = 0; k < 3; k++) {                                                                         \
-            const uint32_t i4 = 4u * (ln_ + 64u * (uint32_t)k);                                               \
-            if (i4 < nwords)                                                                                  \
-                *reinterpret_cast<uint4 *>(top - (i4 + 3u)) =                                                 \
-                    make_uint4(__builtin_bswap32(V[k].w), __builtin_bswap32(V[k].z), __builtin_bswap32(V[k].y), __builtin_bswap32(V[k].x)); \
-        }                                                                                                     \
+        for (int g = 0; g < (int)ROWS; g++) col_[64 * ((int)ROWS - 1 - g)] = __builtin_bswap32(wv_[g]);       \
     }
-    DSUB_GEOMETRY(q, q * 64u < ngrp)
-    /* ... and the wave's first tile is on its way while the tables are built.  Tables the quick way from the
-     * sub-index's code lengths, checked against the tree; any other tree: walked (dec_build_tables) */
+    static_assert(DSUB_ROWS == 12, "three 16-byte loads a lane");
+
+    /* the chunk's first tile, as told: (a), and where its first bit lies */
+    const uint64_t T0 = told_c[0];
+    uint64_t room64;
+    const bool chunk_fine = !__builtin_sub_overflow(pay_bits, T0, &room64) && !(sym0 == 0 && T0 != 0);
+    if (!chunk_fine) ok = false;
+    const uint32_t room0 = (uint32_t)(room64 >> 32) != 0u ? 0xffffffffu : (uint32_t)room64;   /* payload bits from the chunk's first on (all that matter) */
+    const uintptr_t a0 = pay_a + (uintptr_t)((chunk_fine ? T0 : 0ull) >> 3);
+    const uint32_t lead0 = ((uint32_t)T0 & 7u) + 8u * (uint32_t)(a0 & 3u);
+    const uintptr_t base0 = a0 & ~(uintptr_t)3;                     /* (may begin up to 3 bytes in front of the payload: header and tree lie there) */
+    const uint64_t left64 = end_a - (uint64_t)base0;                /* readable bytes from there on */
+    const uint32_t left0 = (uint32_t)(left64 >> 32) != 0u ? 0xffffffffu : (uint32_t)left64;
+    uint32_t q = (uint32_t)wave;
+    DSUB_FETCH(q)
+    DSUB_SETUP(q, q + WAVES)
+    /* ... and the wave's first tile is on its way while the tables are built: the quick way from the sub-index's
+     * code lengths, checked against the tree; any other tree leaves the block to the exact decoder */
     {
         unsigned long long kt = DPROF_T();
 #ifdef DSUB_TABLES_TWICE        /* (what one table build costs where it stands: the kernel with two of them) */
         dsub_fast_tables<THREADS>(sh, tree_len, tw);
 #endif
-        if (!dsub_fast_tables<THREADS>(sh, tree_len, tw)) {
-            int leaf = -1;
-            const int rc = dec_build_tables<THREADS, false>(sh, tree, tree_len, &leaf);
-            if (rc != HUFE_OK || leaf >= 0) {                       /* (an unusual one-leaf tree: the exact decoder's) */
-                *end_bit = 0;
-                return false;
-            }
-            dsub_convert_tables<THREADS>(sh);
-        }
+        if (!dsub_fast_tables<THREADS>(sh, tree_len, tw)) return false;          /* (workgroup-uniform) */
         DPROF_ADD(3, kt);
     }
     const bool use_l2 = uni32(sh.l2n) != 0u;                          /* the block has codes in a second-level table */
@@ -674,19 +653,14 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
     uint32_t slow_tiles = 0, redo_tiles = 0;
 
 #pragma unroll 1
-    for (uint32_t ti = 0; q * 64u < ngrp; q += WAVES, ti++) {
+    for (uint32_t ti = 0; q < ntiles; q += WAVES, ti++) {
         pt = DPROF_T();
-        const uint32_t g = q * 64u + (uint32_t)lane;
-        const uint32_t my0 = g * DSUB_SPL;                              /* relative to the chunk: 32-bit arithmetic, one offset register */
-        uint32_t nsym = 0, gb = 0;
-        if (g < ngrp) {
-            nsym = dmin<uint32_t>(DSUB_SPL, nchunk - my0);
-            gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
-        }
-        const uint32_t s = lead + wave_incl_scan_u32(gb) - gb;          /* the stage bit of my first symbol */
-        const bool cur_quick = quick;
-        /* the next tile's words are requested now and arrive while this one is decoded */
-        DSUB_GEOMETRY(q + WAVES, (q + WAVES) * 64u < ngrp)
+        const uint32_t my0 = (q * 64u + (uint32_t)lane) * DSUB_SPL;     /* relative to the chunk: 32-bit arithmetic, one offset register */
+        const uint32_t nsym = nsym_n, gb = gb_n, s = lead_n;            /* this tile's: my symbols, my group's bits, the bit I start at */
+        const bool cur_quick = quick_n;
+        /* the next tile's words are requested now and arrive while this one is decoded (what the sub-index says
+         * about the tile behind it, too) */
+        DSUB_SETUP(q + WAVES, q + 2 * WAVES)
         DPROF_ADD(9, pt); pt = DPROF_T();
         if (!cur_quick) {
             slow_tiles |= 1u << ti;
@@ -695,7 +669,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
             bool group_ok = false;
             if (nsym == DSUB_SPL) {
                 /* The common case has no branch.  Every two symbols the 32 bits at the position are read
-                 * again from the stage (one ds_read2_b32, one v_alignbit_b32) - no bit buffer to refill -
+                 * again from the column (one ds_read2st64_b32, one v_alignbit_b32) - no bit buffer to refill -
                  * and looked up twice; the entries' low five bits shift the window and their sum moves the
                  * position as they stand.  An entry that is not a leaf has length 0: the lane stands still
                  * from then on (a `long` code, a walk that leaves the tree: the low byte is 0) and its last
@@ -707,7 +681,7 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
                  * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
                  * symbol; a lane decoding the two halves of its group side by side.) */
                 const bool aligned = (cout_a & 15u) == 0;             /* (the offset is a multiple of 32) */
-                const uint32_t r0 = r_origin - s;
+                const uint32_t r0 = r_top - s;
                 uint32_t R = r0;
                 uint32_t special = 0, e_last = 0;
 /* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
@@ -716,18 +690,18 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
  * without such codes (zipf255, uniform bytes) run the loop without the ballots. */
 #define DSUB_WINDOW(PAIR, L2)                                                                                 \
                 {                                                                                             \
-                    lds_words wp_ = (lds_words)(uintptr_t)((R >> 3) & ~3u);                                    \
-                    const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[1], wp_[0], R);                         \
+                    lds_words wp_ = (lds_words)(uintptr_t)(((R << 3) & 0xffffff00u) | lane4);                  \
+                    const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[64], wp_[0], R);                        \
                     uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));              \
                     if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
-                        if (DSE_IS_L2(e1_)) e1_ = dsub_l2<THREADS>(sh, e1_, d1_);                             \
+                        if (DSE_IS_L2(e1_)) e1_ = dsub_l2(sh, e1_, d1_);                                      \
                     }                                                                                         \
                     const uint32_t d2_ = d1_ << (e1_ & 31u);                                                  \
                     uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));              \
                     if (L2 && __ballot(DSE_IS_L2(e2_))) {                                                     \
                         /* (the window has 32 - len bits left) */                                             \
                         if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
-                            e2_ = dsub_l2<THREADS>(sh, e2_, d2_);                                             \
+                            e2_ = dsub_l2(sh, e2_, d2_);                                                      \
                     }                                                                                         \
                     if (L2) {                                                                                 \
                         special |= e1_ | e2_;                                                                 \
@@ -762,7 +736,10 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
                         for (int k = 0; k < 32; k++) (cout + o_)[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));  \
                     }                                                                                         \
                 }
-                if (use_l2) { DSUB_ROUNDS(true) } else { DSUB_ROUNDS(false) }
+                /* (two loops, whole: the compiler otherwise moves their common first look-up in front of the branch
+                 *  and spills the position register around it) */
+                if (use_l2) { asm volatile("; codes in a second-level table" : "+v"(R)); DSUB_ROUNDS(true) }
+                else { asm volatile("; every code in the first table" : "+v"(R)); DSUB_ROUNDS(false) }
 #undef DSUB_ROUNDS
 #undef DSUB_WINDOW
                 redo = DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u;
@@ -772,14 +749,15 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
             else if (!group_ok) ok = false;
         }
         DPROF_ADD(10, pt);
-        /* the slice is free: the next tile's words (the wait for them counts the stores behind them out) */
+        /* the columns are free: the next tile's words (the wait for them counts the stores behind them out) */
         DSUB_TO_SLICE()
     }
 #undef DSUB_TO_SLICE
-#undef DSUB_GEOMETRY
+#undef DSUB_SETUP
+#undef DSUB_FETCH
     if (__builtin_expect(slow_tiles != 0u || __ballot(redo_tiles != 0u) != 0ull, 0)) {
 #pragma unroll 1
-        for (uint32_t ti = 0; ti < L::WTILES / WAVES; ti++) {
+        for (uint32_t ti = 0; ti * WAVES + (uint32_t)wave < ntiles; ti++) {
             const bool whole = ((slow_tiles >> ti) & 1u) != 0u;
             const bool mine = whole || ((redo_tiles >> ti) & 1u) != 0u;
             if (!__ballot(mine)) continue;
@@ -789,14 +767,16 @@ __device__ bool decode_payload_sub(DecShared<THREADS> &sh, const uint8_t *tree, 
             uint32_t nsym = 0, gb = 0;
             if (g < ngrp) {
                 nsym = dmin<uint32_t>(DSUB_SPL, nchunk - my0);
-                gb = dmin<uint32_t>((uint32_t)s_gb[g], DSUB_MAX_GROUP_BITS);
+                gb = dmin<uint32_t>((uint32_t)grp[g], DSUB_MAX_GROUP_BITS);
             }
             const uint32_t incl = wave_incl_scan_u32(gb);
-            const uint64_t tfirst = T0 + (q ? wave_lane_u32(tincl, q - 1u) : 0u);
-            if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + sym0 + my0)) ok = false;
+            const uint64_t tfirst = uni64(told[q]);
+            /* (a tile whose told start or bits lie outside the payload was counted out by its set-up: ok is false) */
+            if (tfirst <= pay_bits && (uint64_t)wave_lane_u32(incl, 63) <= pay_bits - tfirst) {
+                if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + sym0 + my0)) ok = false;
+            }
         }
     }
-    *end_bit = T0 + chunk_bits;
     return __syncthreads_and(ok ? 1 : 0) != 0;
 }
 
@@ -819,24 +799,23 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
     uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
     unsigned long long *__restrict__ result, HufSubIndex sub, uint64_t blocksize, uint32_t cpb, DecFixList fix)
 {
-    __shared__ DecShared<THREADS> sh;
+    __shared__ DsubShared<THREADS> sh;
 #ifdef DSUB_LDS_PAD             /* (occupancy experiments: fewer workgroups per CU) */
     __shared__ uint32_t lds_pad[DSUB_LDS_PAD / 4];
     if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
 #endif
-    static_assert(DSUB_CHUNK_SYMS % (THREADS * DSUB_SPL) == 0 && (THREADS * DSUB_SPL) % HUF_SUB_TILE == 0, "chunks are whole tiles");
+    static_assert(DSUB_CHUNK_SYMS % (THREADS * DSUB_SPL) == 0 && DSUB_CHUNK_SYMS % HUF_SUB_TILE == 0, "chunks are whole tiles");
     const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x / cpb;
     const uint32_t c = (uint32_t)(blockIdx.x % cpb);
     unsigned long long kt = DPROF_T();
     /* Everything about the block is the same in all lanes: kept in SGPRs (held in VGPRs these values pushed the
-     * tile loop's state out to scratch), and everything is REQUESTED before the first of it is looked at: six
+     * tile loop's state out to scratch), and everything is REQUESTED before the first of it is looked at: five
      * scalar loads, one wait (one after the other they were a sixth of a workgroup's life). */
     HufDecodeMeta m = dmeta[blk];
     const uint64_t out_group = lens.gprefix[blk / SCAN_GROUP], out_local = lens.local[blk];
     const uint64_t off0 = offsets[blk], off1 = offsets[blk + 1];
-    const uint64_t t0_told = sub.tile_bits[blk * sub.tpb + (uint64_t)c * (DSUB_CHUNK_SYMS / HUF_SUB_TILE)];   /* (c < cpb: inside the block's row) */
-    pin_uniform(m.block_len); pin_uniform(out_group); pin_uniform(out_local); pin_uniform(off0); pin_uniform(off1); pin_uniform(t0_told);
+    pin_uniform(m.block_len); pin_uniform(out_group); pin_uniform(out_local); pin_uniform(off0); pin_uniform(off1);
     m.block_len = uni64(m.block_len);
     m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
     m.leaf = (int16_t)uni32((uint32_t)(uint16_t)m.leaf);
@@ -873,15 +852,16 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
                decode_single_leaf<THREADS, true>(sh, (uint32_t)m.leaf, pay + (sym0 >> 3), sym1 - sym0,
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
-        dsub_prefetch<THREADS>(sh, sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL,
-                               (uint32_t)((sym1 - sym0 + DSUB_SPL - 1) / DSUB_SPL));
-        const uint64_t T0 = uni64(t0_told);                           /* first payload bit of the chunk, as told */
         DPROF_ADD(2, kt);
-        uint64_t end_bit = 0;
-        good = decode_payload_sub<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM, pay, pay_bytes,
-                                           stream_len - (uint64_t)(pay - stream), stream + o0, sym0, sym1, T0, out + obase, &end_bit);
-        /* (c) the next chunk starts where this one ends */
-        if (good && sym1 < m.block_len && sub.tile_bits[blk * sub.tpb + sym1 / HUF_SUB_TILE] != end_bit) good = false;
+        /* `safe`: where a tile with nothing to load points its loads - 64 readable bytes if the stream has them
+         * behind the block's start, else none are issued against it (a stream that short has no quick tile and
+         * its loads go to ... the same place: the test below makes that place the stream's last 64 bytes) */
+        const uint8_t *safe = stream + (stream_len >= o0 + 64 ? o0 : (stream_len >= 64 ? stream_len - 64 : 0));
+        good = stream_len >= 64 + 3 &&
+               decode_payload_sub<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM, pay, pay_bytes,
+                                           stream_len - (uint64_t)(pay - stream), safe, sym0, sym1, sym1 < m.block_len,
+                                           sub.tile_bits + blk * sub.tpb + sym0 / HUF_SUB_TILE,
+                                           sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL, out + obase);
     }
 #ifdef DSUB_ABLATE_VERIFY       /* (diagnostic builds with a phase removed produce garbage: do not decode it again) */
     good = true;

@@ -34,11 +34,12 @@ namespace hufgpu {
  * the encoder knows where every lane's PACK_SPT symbols start, the decoder would otherwise have to
  * find out by decoding everything twice (self-synchronisation).  Per group of HUF_SUB_GROUP symbols
  * the number of payload bits they occupy, per tile of HUF_SUB_TILE symbols the payload bit the tile
- * starts at.  Block b owns groups [b * gpb, (b+1) * gpb) and tiles [b * tpb, (b+1) * tpb), gpb/tpb =
+ * starts at (a tile = the 64 groups one wavefront of the decoder takes at a time).  Block b owns groups [b * gpb, (b+1) * gpb) and tiles [b * tpb, (b+1) * tpb), gpb/tpb =
  * ceil(blocksize / group or tile).  The decoder VERIFIES what it is told (a group must decode to
  * exactly its bit count), so a wrong or stale sub-index costs time, never correctness. */
 #define HUF_SUB_GROUP PACK_SPT
-#define HUF_SUB_TILE  (256 * PACK_SPT)
+#define HUF_SUB_TILE  (64 * PACK_SPT)     /* 2 048 symbols: what one wave decodes at a time (decode_sub.hpp; round 4: 8 192, and the decoder
+                                            summed a block's group counts in LDS to find its waves' starts) */
 struct HufSubIndex {
     uint64_t *tile_bits;      /* NULL = no sub-index */
     uint16_t *group_bits;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
                                            CodeT *s_code, uint32_t *s_part, uint32_t *s_tail, uint32_t *s_stage,
                                            uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
 {
-    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
+    static_assert(HUF_SUB_TILE == 64 * PACK_SPT, "a sub-index tile is one wave of a pack tile");
     constexpr int TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
@@ -273,7 +274,7 @@ __device__ __forceinline__ void pack_block(const uint8_t *__restrict__ src, uint
         const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
         if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
             if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
-            if (tid == 0) sub_tiles[t0 / TILE] = bitpos - (uint64_t)hdr_end * 8ull;
+            if (lane == 0 && nsym) sub_tiles[my0 / HUF_SUB_TILE] = bitpos + ex - (uint64_t)hdr_end * 8ull;   /* (my0 = t0 + wave * 2 048) */
         }
 
         /* ---- shift the codes out ----
@@ -447,7 +448,7 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
                                                  uint64_t *__restrict__ sub_tiles, uint16_t *__restrict__ sub_groups)
 {
     static_assert(GROUP == 2 || GROUP == 3, "two or three codes a push");
-    static_assert(THREADS * PACK_SPT == HUF_SUB_TILE, "a pack tile is a sub-index tile");
+    static_assert(HUF_SUB_TILE == 64 * PACK_SPT, "a sub-index tile is one wave of a pack tile");
     constexpr int TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
     constexpr int NG = (PACK_SPT + GROUP - 1) / GROUP;           /* pushes a lane: 16 pairs, or 10 triples and a pair */
@@ -501,7 +502,7 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
         const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
         if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
             if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
-            if (tid == 0) sub_tiles[t0 / TILE] = bitpos - (uint64_t)hdr_end * 8ull;
+            if (lane == 0 && nsym) sub_tiles[my0 / HUF_SUB_TILE] = bitpos + ex - (uint64_t)hdr_end * 8ull;   /* (my0 = t0 + wave * 2 048) */
         }
 
         /* ---- shift the codes out (stage, flush: as pack_block).  A lane's place relative to the tile's first word in

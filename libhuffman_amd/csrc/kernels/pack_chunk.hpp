@@ -211,7 +211,7 @@ __device__ __forceinline__ void pack_segment(const uint8_t *__restrict__ src, ui
         const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
         if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
             if (nsym) sub_groups[my0 / PACK_SPT] = (uint16_t)mybits;
-            if (tid == 0) sub_tiles[t0 / TILE] = pay_rel0 + done_bits;
+            if ((tid & 63) == 0 && nsym) sub_tiles[my0 / HUF_SUB_TILE] = pay_rel0 + done_bits + ex;   /* (my0 = t0 + wave * 2 048) */
         }
         done_bits += tile_bits;
         const bool final_tile = t0 + TILE >= len;

@@ -117,7 +117,7 @@ def test_wrong_sub_index_costs_time_not_correctness(torch_mod, codec, what):
     stream, offs, length, sub = encode_sub(torch, codec, data, bs)
     bad = sub.clone()
     nb = codec.block_count(n, bs)
-    tiles = nb * ((bs + 8191) // 8192)               # int64 words of tile starts in front of the group counts
+    tiles = nb * ((bs + 2047) // 2048)               # int64 words of tile starts in front of the group counts
     if what == "garbage":
         bad = torch.randint(-2**62, 2**62, bad.shape, dtype=torch.int64, device="cuda")
     elif what == "zeros":
@@ -134,7 +134,7 @@ def test_wrong_sub_index_costs_time_not_correctness(torch_mod, codec, what):
         v[g] += 1
         v[g + 1] -= 1
     elif what == "tile_off":
-        bad[2 * 8 + 5] += 8                          # tile 5 of block 2
+        bad[2 * 32 + 5] += 8                         # tile 5 of block 2
     raw, out = decode_sub(torch, codec, stream, length, offs, n, bs, bad)
     assert raw == n and torch.equal(out[:n], dev(torch, data)), what
     # and the codec context is as good as new afterwards
@@ -286,8 +286,8 @@ def test_big_blocks_are_chunked_bit_exact(torch_mod, codec, oracle, kind, n, bs)
     assert codec.decode(stream, length, offs, nb, out2, relaxed=True) == n and torch.equal(out2, out[:n])
     # a damaged chunk start in the sub-index of a big block: found by the chunk in front of it
     bad = sub.clone()
-    bad[1] += 8                                         # tile 1 of block 0 = not a chunk start: no effect
-    tiles_per_chunk = 65536 // 8192
+    bad[1] += 8                                         # tile 1 of block 0: in the middle of a chunk
+    tiles_per_chunk = 65536 // 2048
     bad[tiles_per_chunk] += 8                           # first tile of decode chunk 1 of block 0
     raw, out3 = decode_sub(torch, codec, stream, length, offs, n, bs, bad, relaxed=True)
     assert raw == n and torch.equal(out3[:n], dev(torch, data))
@@ -334,7 +334,7 @@ def test_code_lengths_in_the_sub_index_are_checked_against_the_tree(torch_mod, c
         data = datagen.GENERATORS[kind](n)
         stream, offs, length, sub = encode_sub(torch, codec, data, bs)
         nb = codec.block_count(n, bs)
-        tiles = nb * ((bs + 8191) // 8192)
+        tiles = nb * ((bs + 2047) // 2048)
         gpb = ((bs + 31) // 32 + 7) & ~7
         lens0 = 8 * tiles + 2 * nb * gpb                   # byte offset of the lengths
         v = sub.view(torch.uint8)

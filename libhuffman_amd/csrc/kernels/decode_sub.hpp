@@ -217,6 +217,8 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
     if (tree_len < 9 || tree_len > HUF_TREE_MAX || ((tree_len - 1) & 3) != 0) return false;     /* uniform */
     uint8_t *s_lens = reinterpret_cast<uint8_t *>(sh.pay);                      /* [256] the claimed lengths by byte value */
     uint16_t *s_pos = reinterpret_cast<uint16_t *>(sh.pay + 64);                /* [256] entry index of the k-th leaf */
+    uint16_t *s_ent16 = reinterpret_cast<uint16_t *>(sh.pay + 192);            /* [256] the table entry of the k-th leaf's codewords */
+    uint16_t *s_mark = reinterpret_cast<uint16_t *>(sh.pay + 512);              /* [2048] twice the number of the leaf that begins at a table entry (0: none, or leaf 0) */
     uint32_t *s_cpart = sh.wtile;                                               /* [3][WAVES] partial sums of the code scan */
     static_assert(sizeof(sh.wtile) >= 3 * WAVES * sizeof(uint32_t), "partials of the code scan");
     bool ok = true;
@@ -228,6 +230,7 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
     {
         const uint32_t mis = tw.mis, d0 = tw.d0, d1 = tw.d1, d2 = tw.d2;
         if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = tw.lens4;
+        if (tid < 256) reinterpret_cast<uint4 *>(s_mark)[tid] = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t two01 = mis ? __builtin_amdgcn_alignbit(d1, d0, 8u * mis) : d0;
         const uint32_t two23 = mis ? __builtin_amdgcn_alignbit(d2, d1, 8u * mis) : d1;
         const int i0 = 2 * tid;
@@ -260,18 +263,24 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
     }
     __syncthreads();
     /* ---- claimed lengths -> codes; they must fill the left half of the code space exactly.  A code's share of
-     *      the 32-bit code space is 2^(32 - d) <= 2^30: scanned as two 16-bit halves (DPP, no 64-bit shuffles) ---- */
+     *      the 32-bit code space is 2^(32 - d) <= 2^30: scanned as two 16-bit halves (DPP, no 64-bit shuffles).
+     *      (Round 5: only the waves that hold leaves - K <= 256: the first four at most - do any of this; the
+     *      table build is a third of the kernel's vector instructions for a block of 64 KiB.) ---- */
+    const bool leafwave = uni32((uint32_t)wave * 64u) < K;
     uint32_t d = 2;
     bool anylong;
     {
-        uint32_t whi = 0, wlo = 0;
-        if ((uint32_t)tid < K) {
-            d = s_lens[F::sym(sh)[tid]];
-            if (d < 2u || d > 32u) { ok = false; d = 2; }
-            else if (d >= 16u) wlo = 1u << (32u - d);                           /* <= 2^16 */
-            else whi = 1u << (16u - d);                                         /* 2^(32 - d) >> 16 */
+        uint32_t whi = 0, wlo = 0, ihi = 0, ilo = 0;
+        if (leafwave) {
+            if ((uint32_t)tid < K) {
+                d = s_lens[F::sym(sh)[tid]];
+                if (d < 2u || d > 32u) { ok = false; d = 2; }
+                else if (d >= 16u) wlo = 1u << (32u - d);                       /* <= 2^16 */
+                else whi = 1u << (16u - d);                                     /* 2^(32 - d) >> 16 */
+            }
+            ihi = wave_incl_scan_u32(whi);
+            ilo = wave_incl_scan_u32(wlo);
         }
-        const uint32_t ihi = wave_incl_scan_u32(whi), ilo = wave_incl_scan_u32(wlo);
         const unsigned long long lg = __ballot(d > (uint32_t)DEC_LUT_BITS);
         if (lane == 63) {
             s_cpart[wave] = ihi;
@@ -279,25 +288,40 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
             s_cpart[2 * WAVES + wave] = lg != 0ull;
         }
         __syncthreads();
-        uint64_t base = 0, tot = 0;
         uint32_t lf = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; i++) {
-            const uint64_t x = ((uint64_t)s_cpart[i] << 16) + s_cpart[WAVES + i];
-            if (i < wave) base += x;
-            tot += x;
-            lf |= s_cpart[2 * WAVES + i];
-        }
+        for (int i = 0; i < WAVES; i++) lf |= s_cpart[2 * WAVES + i];
         anylong = uni32(lf) != 0u;
-        if (tot != (1ull << 31)) ok = false;
-        if ((uint32_t)tid < K) {
-            F::code(sh)[tid] = (uint32_t)(base + (((uint64_t)(ihi - whi)) << 16) + (ilo - wlo));
-            F::len(sh)[tid] = (uint8_t)d;
+        if (leafwave) {
+            uint64_t base = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < (WAVES < 4 ? WAVES : 4); i++) {                 /* (the waves behind the fourth hold no leaves) */
+                const uint64_t x = ((uint64_t)s_cpart[i] << 16) + s_cpart[WAVES + i];
+                if (i < wave) base += x;
+                tot += x;
+            }
+            if (tot != (1ull << 31)) ok = false;
+            if ((uint32_t)tid < K) {
+                const uint32_t c = (uint32_t)(base + (((uint64_t)(ihi - whi)) << 16) + (ilo - wlo));
+                F::code(sh)[tid] = c;
+                F::len(sh)[tid] = (uint8_t)d;
+                /* what the table's entries of this leaf hold, and a mark at the first of them (entry = the code's
+                 * first 12 bits; the codes of leaves that share an entry are longer than 12 bits, any of them may
+                 * leave its mark) and at every 512th entry the leaf covers: the marks are leaf numbers (doubled: a
+                 * byte offset into s_ent16) in code order, an entry's leaf is the last mark at or in front of it,
+                 * and a wave of the fill below - 512 entries - finds one at its first entry */
+                const uint32_t x = c >> (32 - DEC_LUT_BITS);
+                const uint32_t span = d <= (uint32_t)DEC_LUT_BITS ? 1u << ((uint32_t)DEC_LUT_BITS - d) : 1u;
+                s_ent16[tid] = d <= (uint32_t)DEC_LUT_BITS ? (uint16_t)(((uint32_t)F::sym(sh)[tid] << 8) | d) : (uint16_t)DSE_LONG;
+                s_mark[x & 2047u] = (uint16_t)(2u * (uint32_t)tid);             /* (x < 2048 when the lengths are right; if not, ok is false) */
+                for (uint32_t bb = (x & ~511u) + 512u; bb < x + span && bb < 2048u; bb += 512u)   /* the 512th entries behind x */
+                    s_mark[bb] = (uint16_t)(2u * (uint32_t)tid);
+            }
         }
     }
     __syncthreads();
     /* ---- the entry positions the lengths imply are the stream's ---- */
-    if ((uint32_t)tid < K) {
+    if (leafwave && (uint32_t)tid < K) {
         const uint32_t k = (uint32_t)tid;
         const uint32_t bits = F::code(sh)[k] >> (32u - d);                      /* the d code bits */
         const uint32_t t = (uint32_t)__builtin_ctz(~bits);                      /* trailing ones (< d: codes start with 0) */
@@ -308,26 +332,32 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
             if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
         } else if (pos + 4u != (uint32_t)tree_len) ok = false;                  /* leaf, its two markers, the root's */
     }
-    /* ---- the table: eight consecutive entries per thread, one 16-byte store ---- */
+    /* ---- the table: eight consecutive entries per thread, one 16-byte store.  The upper half - a first bit of 1:
+     *      the root has no right child - is the same for every tree; in the lower half an entry's leaf is the last
+     *      mark at or in front of it: the marks of a thread's eight entries, a running maximum over the lanes in front
+     *      (DPP), and the leaf's entry from s_ent16 (round 4: a binary search per thread and a walk per entry, 180
+     *      vector instructions where this takes 30) ---- */
     {
-        static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
-        const uint32_t *code = F::code(sh);
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && THREADS == 512, "eight entries per thread, the lower half in the first four waves");
         const uint32_t x0 = (uint32_t)tid * 8u;
-        uint32_t k = dsub_leaf_of(code, K, x0 << (32 - DEC_LUT_BITS));
-        uint32_t e[8];
+        if (x0 >= 2048u) {
+            const uint32_t bad2 = DSE_BAD | (DSE_BAD << 16);
+            *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(bad2, bad2, bad2, bad2);
+        } else {
+            const uint4 m = *reinterpret_cast<const uint4 *>(s_mark + x0);
+            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+            uint32_t t2 = pk_max_u16(pk_max_u16(m.x, m.y), pk_max_u16(m.z, m.w));
+            t2 = dmax<uint32_t>(t2 & 0xffffu, t2 >> 16);                        /* the thread's last mark (0: none) */
+            uint32_t r = wave_excl_max_u32(t2);                                 /* the last mark in front of my entries */
+            uint32_t e[8];
+            const __attribute__((address_space(3))) uint8_t *ent_b = (const __attribute__((address_space(3))) uint8_t *)s_ent16;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t idx = x0 + j;
-            const uint32_t v = idx << (32 - DEC_LUT_BITS);
-            if (v >> 31) {
-                e[j] = DSE_BAD;                  /* the first bit leaves the tree (the root has no right child) */
-            } else {
-                while (k + 1u < K && code[k + 1u] <= v) k++;
-                const uint32_t dk = F::len(sh)[k];
-                e[j] = (dk <= (uint32_t)DEC_LUT_BITS) ? (((uint32_t)F::sym(sh)[k] << 8) | dk) : (uint32_t)DSE_LONG;
+            for (int j = 0; j < 8; j++) {
+                r = dmax<uint32_t>(r, (mw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                e[j] = *(const __attribute__((address_space(3))) uint16_t *)(ent_b + r);
             }
+            *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
         }
-        *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
     /* ---- second level: the subtree below a 12-bit prefix whose codes are at most DSUB_L2_BITS longer
      *      gets a table of its own (2, 4 or 6 more bits) in sh.ent.  Codes beyond that keep their `long`
@@ -793,7 +823,8 @@ struct DecFixList {
 #define DSUB_WAVES_PER_SIMD 8
 #endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kernel(
+__global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) 
+void decode_sub_kernel(
     const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
     const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
     uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
@@ -863,6 +894,7 @@ __global__ __launch_bounds__(THREADS, DSUB_WAVES_PER_SIMD) void decode_sub_kerne
                                            sub.tile_bits + blk * sub.tpb + sym0 / HUF_SUB_TILE,
                                            sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL, out + obase);
     }
+    DPROF_ADD(11, kt);              /* (the workgroup's life, thread 0) */
 #ifdef DSUB_ABLATE_VERIFY       /* (diagnostic builds with a phase removed produce garbage: do not decode it again) */
     good = true;
 #endif

@@ -88,6 +88,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
     return v;
 }
+/* For every lane the maximum over the lanes IN FRONT of it (0 for lane 0; values are unsigned, 0 is neutral): the DPP
+ * steps of wave_incl_scan_u32 with v_max, then one wave_shr. */
+__device__ __forceinline__ uint32_t wave_excl_max_u32(uint32_t v)
+{
+#define HUF_MAX_DPP_(ctrl, rmask, bc) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, bc); v = v > o_ ? v : o_; }
+    HUF_MAX_DPP_(0x111, 0xf, true)      /* row_shr:1 */
+    HUF_MAX_DPP_(0x112, 0xf, true)      /* row_shr:2 */
+    HUF_MAX_DPP_(0x114, 0xf, true)      /* row_shr:4 */
+    HUF_MAX_DPP_(0x118, 0xf, true)      /* row_shr:8 */
+    HUF_MAX_DPP_(0x142, 0xa, false)     /* row_bcast:15 -> rows 1, 3 */
+    HUF_MAX_DPP_(0x143, 0xc, false)     /* row_bcast:31 -> rows 2, 3 */
+#undef HUF_MAX_DPP_
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);         /* wave_shr:1, lane 0 <- 0 */
+}
+/* the two 16-bit halves' maxima in one instruction */
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 r = __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 /* Value of lane (lane ^ D), D a power of two: DPP inside a row of 16 lanes (quad_perm for 1 and 2,
  * two row rotations and a select for 4, one rotation for 8), ds_swizzle for 16 (no address register),
  * ds_bpermute only for 32.  __shfl_xor is a ds_bpermute with a computed address for every distance:

@@ -22,6 +22,9 @@ using namespace hufgpu;
 #define HIST_THREADS 256
 #endif
 #define PACK_THREADS 256
+#ifndef DSUB_THREADS
+#define DSUB_THREADS 256      /* decode_sub_kernel: four waves a workgroup, eight wave tiles a wave - a workgroup's table build is paid once per 64 KiB */
+#endif
 #ifndef DEC_THREADS
 #define DEC_THREADS 512
 #endif
@@ -763,7 +766,7 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
         fix.count = ctx->d_fix_count;
         fix.blocks = ctx->d_fix_blocks;
         fix.flag = ctx->d_fix_flag;
-        decode_sub_kernel<DEC_THREADS><<<dim3((unsigned)(nblocks * cpb)), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, *sub, blocksize, (uint32_t)cpb, fix);
+        decode_sub_kernel<DSUB_THREADS><<<dim3((unsigned)(nblocks * cpb)), dim3(DSUB_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, *sub, blocksize, (uint32_t)cpb, fix);
         const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
         decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
     } else {

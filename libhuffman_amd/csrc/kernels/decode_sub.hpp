@@ -19,7 +19,7 @@ namespace hufgpu {
  *
  * The self-synchronising decoder (decode.hpp) has to find out where codewords start: every symbol
  * is decoded at least twice (count pass + write pass) plus the synchronisation rounds.  Here a
- * lane is TOLD where its 32 symbols start, decodes them once through a 2^12-entry table (a second
+ * lane is TOLD where its 32 symbols start, decodes them once through a table of the first 12 code bits (a second
  * level for codes of up to 18 bits) and stores them as one 32-byte sector.  What it is told is
  * verified, not trusted:
  *   (a) the block's first tile starts at payload bit 0,
@@ -48,10 +48,13 @@ namespace hufgpu {
  * ==================================================================================== */
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
 #define DSUB_L2_BITS 6u                     /* a second-level table takes codes of up to 12 + 6 bits */
-#define DSUB_L2_ENTRIES 1024u               /* it lives in DsubShared::ent */
+#define DSUB_L2_ENTRIES 960u                /* it lives in DsubShared::ent */
 #define DSUB_SLACK_WORDS 16                 /* (step-by-step path) staged behind the last needed word: what a lane that runs wild (32 look-ups of at most 18 bits) or a long code's walk may look at */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: 32 wave tiles */
+#define DSUB_LUT_BITS 11u                    /* the first-level table is indexed by the 11 bits BEHIND a codeword's first bit: that bit is 0 in
+                                                every code of an encoder-made tree (the root has a left child only, tree.c:410-413), and the
+                                                2 048 entries of a first bit 1 all said the same thing.  The first bits are OR-ed as they go by. */
 #define DSUB_ROWS 12                         /* words of a lane's column */
 #define DSUB_COL_BITS (32u * (DSUB_ROWS - 1))   /* a lane's lead + group bits may be this much: the window at the group's last
                                                 codeword reads the word behind the one it starts in */
@@ -78,7 +81,8 @@ struct RevReader {
         avail = (int32_t)(64u - off);
         gf = g + 2;
     }
-    __device__ __forceinline__ uint32_t index() const { return hi >> (32 - DEC_LUT_BITS); }
+    __device__ __forceinline__ uint32_t index() const { return (hi >> (31 - DSUB_LUT_BITS)) & ((1u << DSUB_LUT_BITS) - 1u); }
+    __device__ __forceinline__ bool first_bit() const { return (hi >> 31) != 0u; }
     __device__ __forceinline__ uint32_t pos() const { return (gf << 5) - (uint32_t)avail; }
     __device__ __forceinline__ void consume(uint32_t adv)
     {
@@ -151,16 +155,19 @@ template <int THREADS>
 struct DsubShared {
     static constexpr int WAVES = THREADS / 64;
     static constexpr uint32_t SLICE_WORDS = 64u * DSUB_ROWS;      /* a wave's columns: row r of lane l at slice[64 r + l] */
-    uint16_t lut[1 << DEC_LUT_BITS];                             /* first-level table */
+    uint16_t lut[1 << DSUB_LUT_BITS];                            /* first-level table */
     uint32_t lr[384];                                            /* the leaves in preorder: code[256] (left-aligned), length[256], byte[256] (FastLdsOf) */
     int16_t ent[DSUB_L2_ENTRIES];                                /* second-level tables */
-    __attribute__((aligned(256))) uint32_t pay[WAVES * SLICE_WORDS];  /* the waves' slices (the table build's scratch before that); a ROW - 256 bytes -
-                                                                    at a multiple of 256: a row's number and a lane's offset in it are bit fields of an LDS address */
+    /* (the few words a workgroup shares lie behind the second-level tables, in front of the slices: with them the
+     *  struct is 78 rows of 256 bytes for four waves - eight workgroups a CU with room to spare; behind the slices they
+     *  would make it 80, which is all of the CU's 160 KiB and one allocation granule from seven workgroups) */
     uint32_t part[WAVES];
     uint32_t wtile[3 * WAVES];                                   /* partial sums of the table build's code scan */
     uint32_t fastk;                                              /* leaves of the tables */
     uint32_t l2n;                                                /* entries of the second-level tables (0: none) */
     uint32_t firstone;                                           /* decode_single_leaf */
+    __attribute__((aligned(256))) uint32_t pay[WAVES * SLICE_WORDS];  /* the waves' slices (the table build's scratch before that); a ROW - 256 bytes -
+                                                                    at a multiple of 256: a row's number and a lane's offset in it are bit fields of an LDS address */
 };
 
 /* largest k < K with code[k] <= v (code[0] = 0) */
@@ -184,21 +191,24 @@ __device__ __forceinline__ uint32_t dsub_leaf_of(const uint32_t *code, uint32_t 
 /* what a thread of the table build needs from global memory: the three aligned dwords that hold tree entries
  * 2t .. 2t+3, and (threads 0..63) four of the claimed lengths - requested early, used by dsub_fast_tables */
 struct DsubTreeWords {
-    uint32_t d0, d1, d2, lens4, mis;
+    uint32_t d[4], lens4, mis;
 };
+/* entries a thread classifies: 2 (512 threads) or 4 (256); it looks at two more behind them */
 template <int THREADS>
 __device__ __forceinline__ DsubTreeWords dsub_tree_request(const uint8_t *tree, int tree_len, const uint8_t *__restrict__ lens_g)
 {
+    constexpr uint32_t EPT = 1024 / THREADS;
+    constexpr int NW = EPT / 2 + 2;                              /* aligned dwords that hold EPT + 2 entries at any byte misalignment */
+    static_assert((THREADS == 256 || THREADS == 512) && NW <= 4, "two or four entries a thread");
     DsubTreeWords w;
     const int tid = (int)threadIdx.x;
     const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)tree);
     w.mis = (uint32_t)(a & 3u);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(a - w.mis);
     const uint32_t nbytes = w.mis + 2u * (uint32_t)(tree_len > 0 ? tree_len : 0);      /* bytes from q[0] to the tree's end */
-    const uint32_t t4 = 4u * (uint32_t)tid;
-    w.d0 = (t4 < nbytes) ? q[tid] : 0u;
-    w.d1 = (t4 + 4u < nbytes) ? q[tid + 1] : 0u;
-    w.d2 = (t4 + 8u < nbytes) ? q[tid + 2] : 0u;
+    const uint32_t t4 = 2u * EPT * (uint32_t)tid;                                       /* byte offset of the thread's first dword */
+#pragma unroll
+    for (int i = 0; i < 4; i++) w.d[i] = (i < NW && t4 + 4u * (uint32_t)i < nbytes) ? q[(EPT / 2) * tid + i] : 0u;
     w.lens4 = (tid < 64) ? reinterpret_cast<const uint32_t *>(lens_g)[tid] : 0u;
     return w;
 }
@@ -209,7 +219,7 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
     typedef FastLdsOf<SH> F;
     constexpr int ENT = HUF_TREE_MAX + 1;
     constexpr int WAVES = THREADS / 64;
-    static_assert(THREADS * 2 >= ENT - 2 && THREADS >= 256 && WAVES <= 8, "two entries per thread");
+    static_assert((THREADS == 256 || THREADS == 512) && ENT == 1026, "1 024 entries over the threads, the 1 025th on the side");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t K = (uint32_t)(tree_len - 1) >> 2;
@@ -222,32 +232,36 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
     uint32_t *s_cpart = sh.wtile;                                               /* [3][WAVES] partial sums of the code scan */
     static_assert(sizeof(sh.wtile) >= 3 * WAVES * sizeof(uint32_t), "partials of the code scan");
     bool ok = true;
-    /* ---- shape: leaves, nodes, markers.  Thread t looks at entries 2t .. 2t+3 (three aligned dwords, shifted
-     *      by the tree's byte misalignment; entries at or past tree_len read -1) ---- */
-    uint32_t k0;                                                                /* leaves in front of entry 2t */
-    bool l0, l1;
-    int e0, e1;
+    /* ---- shape: leaves, nodes, markers.  Thread t classifies entries EPT t .. EPT t + EPT - 1 and looks at the two
+     *      behind them (aligned dwords, shifted by the tree's byte misalignment; entries at or past tree_len read
+     *      -1) ---- */
+    constexpr int EPT = 1024 / THREADS;
     {
-        const uint32_t mis = tw.mis, d0 = tw.d0, d1 = tw.d1, d2 = tw.d2;
+        const uint32_t mis = tw.mis;
         if (tid < 64) reinterpret_cast<uint32_t *>(s_lens)[tid] = tw.lens4;
         if (tid < 256) reinterpret_cast<uint4 *>(s_mark)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t two01 = mis ? __builtin_amdgcn_alignbit(d1, d0, 8u * mis) : d0;
-        const uint32_t two23 = mis ? __builtin_amdgcn_alignbit(d2, d1, 8u * mis) : d1;
-        const int i0 = 2 * tid;
-        e0 = (i0 < tree_len) ? (int)(int16_t)(two01 & 0xffffu) : -1;
-        e1 = (i0 + 1 < tree_len) ? (int)(int16_t)(two01 >> 16) : -1;
-        const int e2 = (i0 + 2 < tree_len) ? (int)(int16_t)(two23 & 0xffffu) : -1;
-        const int e3 = (i0 + 3 < tree_len) ? (int)(int16_t)(two23 >> 16) : -1;
-        const bool n0 = e0 != -1, n1 = e1 != -1;
-        l0 = n0 && e1 == -1 && e2 == -1 && i0 + 2 < tree_len;
-        l1 = n1 && e2 == -1 && e3 == -1 && i0 + 3 < tree_len;
-        if (tid == 0 && !n0) ok = false;                                        /* the root */
-        if ((i0 == tree_len - 1 && n0) || (i0 + 1 == tree_len - 1 && n1)) ok = false;      /* the last entry is a marker */
-        if (tid == THREADS - 1 && i0 + 2 == tree_len - 1 && e2 != -1) ok = false;          /* (entry 1024 has no thread of its own) */
-        const uint32_t mine = (uint32_t)l0 + (uint32_t)l1 + (((uint32_t)n0 + (uint32_t)n1) << 16);
+        const int i0 = EPT * tid;
+        int e[EPT + 2];
+#pragma unroll
+        for (int j = 0; j < EPT + 2; j += 2) {
+            const uint32_t two = mis ? __builtin_amdgcn_alignbit(tw.d[j / 2 + 1], tw.d[j / 2], 8u * mis) : tw.d[j / 2];
+            e[j] = (i0 + j < tree_len) ? (int)(int16_t)(two & 0xffffu) : -1;
+            e[j + 1] = (i0 + j + 1 < tree_len) ? (int)(int16_t)(two >> 16) : -1;
+        }
+        uint32_t mine = 0;
+        bool leaf[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const bool node = e[j] != -1;
+            leaf[j] = node && e[j + 1] == -1 && e[j + 2] == -1 && i0 + j + 2 < tree_len;
+            if (i0 + j == tree_len - 1 && node) ok = false;                     /* the last entry is a marker */
+            mine += (uint32_t)leaf[j] + ((uint32_t)node << 16);
+        }
+        if (tid == 0 && e[0] == -1) ok = false;                                 /* the root */
+        if (tid == THREADS - 1 && i0 + EPT == tree_len - 1 && e[EPT] != -1) ok = false;    /* (entry 1024 has no thread of its own) */
         const uint32_t inc = wave_incl_scan_u32(mine);
         if (lane == 63) sh.part[wave] = inc;
-        __syncthreads();                                                        /* (also: s_lens is written) */
+        __syncthreads();                                                        /* (also: s_lens is written, the marks are cleared) */
         uint32_t base = 0, tot = 0;
 #pragma unroll
         for (int i = 0; i < WAVES; i++) {
@@ -256,16 +270,19 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
             tot += x;
         }
         if ((tot & 0xffffu) != K || (tot >> 16) != 2u * K) ok = false;
-        k0 = (base + inc - mine) & 0xffffu;
-        uint32_t k = k0;
-        if (l0 && k < 256u) { s_pos[k] = (uint16_t)i0; F::sym(sh)[k] = (uint8_t)e0; k++; }
-        if (l1 && k < 256u) { s_pos[k] = (uint16_t)(i0 + 1); F::sym(sh)[k] = (uint8_t)e1; }
+        uint32_t k = (base + inc - mine) & 0xffffu;                             /* leaves in front of my entries */
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            if (leaf[j] && k < 256u) { s_pos[k] = (uint16_t)(i0 + j); F::sym(sh)[k] = (uint8_t)e[j]; k++; }
+        }
     }
     __syncthreads();
     /* ---- claimed lengths -> codes; they must fill the left half of the code space exactly.  A code's share of
      *      the 32-bit code space is 2^(32 - d) <= 2^30: scanned as two 16-bit halves (DPP, no 64-bit shuffles).
      *      (Round 5: only the waves that hold leaves - K <= 256: the first four at most - do any of this; the
      *      table build is a third of the kernel's vector instructions for a block of 64 KiB.) ---- */
+    constexpr uint32_t EPF = 2048u / THREADS;                                   /* table entries a thread fills */
+    constexpr uint32_t WSPAN = 64u * EPF;                                       /* ... a wave */
     const bool leafwave = uni32((uint32_t)wave * 64u) < K;
     uint32_t d = 2;
     bool anylong;
@@ -307,14 +324,14 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
                 F::len(sh)[tid] = (uint8_t)d;
                 /* what the table's entries of this leaf hold, and a mark at the first of them (entry = the code's
                  * first 12 bits; the codes of leaves that share an entry are longer than 12 bits, any of them may
-                 * leave its mark) and at every 512th entry the leaf covers: the marks are leaf numbers (doubled: a
-                 * byte offset into s_ent16) in code order, an entry's leaf is the last mark at or in front of it,
-                 * and a wave of the fill below - 512 entries - finds one at its first entry */
+                 * leave its mark) and at the first entry of every wave of the fill below that the leaf covers: the marks
+                 * are leaf numbers (doubled: a byte offset into s_ent16) in code order, an entry's leaf is the last mark
+                 * at or in front of it, and a wave finds one at its first entry */
                 const uint32_t x = c >> (32 - DEC_LUT_BITS);
                 const uint32_t span = d <= (uint32_t)DEC_LUT_BITS ? 1u << ((uint32_t)DEC_LUT_BITS - d) : 1u;
                 s_ent16[tid] = d <= (uint32_t)DEC_LUT_BITS ? (uint16_t)(((uint32_t)F::sym(sh)[tid] << 8) | d) : (uint16_t)DSE_LONG;
                 s_mark[x & 2047u] = (uint16_t)(2u * (uint32_t)tid);             /* (x < 2048 when the lengths are right; if not, ok is false) */
-                for (uint32_t bb = (x & ~511u) + 512u; bb < x + span && bb < 2048u; bb += 512u)   /* the 512th entries behind x */
+                for (uint32_t bb = (x & ~(WSPAN - 1u)) + WSPAN; bb < x + span && bb < 2048u; bb += WSPAN)   /* the fill waves' first entries behind x */
                     s_mark[bb] = (uint16_t)(2u * (uint32_t)tid);
             }
         }
@@ -332,32 +349,37 @@ __device__ bool dsub_fast_tables(SH &sh, int tree_len, const DsubTreeWords &tw)
             if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
         } else if (pos + 4u != (uint32_t)tree_len) ok = false;                  /* leaf, its two markers, the root's */
     }
-    /* ---- the table: eight consecutive entries per thread, one 16-byte store.  The upper half - a first bit of 1:
-     *      the root has no right child - is the same for every tree; in the lower half an entry's leaf is the last
-     *      mark at or in front of it: the marks of a thread's eight entries, a running maximum over the lanes in front
-     *      (DPP), and the leaf's entry from s_ent16 (round 4: a binary search per thread and a walk per entry, 180
-     *      vector instructions where this takes 30) ---- */
+    /* ---- the table (entry = the 11 bits behind a codeword's first): an entry's leaf is the last mark at or in front
+     *      of it - the marks of a thread's entries, a running maximum over the lanes in front (DPP), and the leaf's
+     *      entry from s_ent16 (round 4: a binary search per thread and a walk per entry, 180 vector instructions
+     *      where this takes 30) ---- */
     {
-        static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && THREADS == 512, "eight entries per thread, the lower half in the first four waves");
-        const uint32_t x0 = (uint32_t)tid * 8u;
-        if (x0 >= 2048u) {
-            const uint32_t bad2 = DSE_BAD | (DSE_BAD << 16);
-            *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(bad2, bad2, bad2, bad2);
-        } else {
+        static_assert(EPF == 8 || EPF == 4, "eight or four entries a thread, one store");
+        const uint32_t x0 = (uint32_t)tid * EPF;
+        uint32_t mw[EPF / 2];
+        if constexpr (EPF == 8) {
             const uint4 m = *reinterpret_cast<const uint4 *>(s_mark + x0);
-            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
-            uint32_t t2 = pk_max_u16(pk_max_u16(m.x, m.y), pk_max_u16(m.z, m.w));
-            t2 = dmax<uint32_t>(t2 & 0xffffu, t2 >> 16);                        /* the thread's last mark (0: none) */
-            uint32_t r = wave_excl_max_u32(t2);                                 /* the last mark in front of my entries */
-            uint32_t e[8];
-            const __attribute__((address_space(3))) uint8_t *ent_b = (const __attribute__((address_space(3))) uint8_t *)s_ent16;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                r = dmax<uint32_t>(r, (mw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-                e[j] = *(const __attribute__((address_space(3))) uint16_t *)(ent_b + r);
-            }
-            *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            mw[0] = m.x; mw[1] = m.y; mw[2] = m.z; mw[3] = m.w;
+        } else {
+            const uint2 m = *reinterpret_cast<const uint2 *>(s_mark + x0);
+            mw[0] = m.x; mw[1] = m.y;
         }
+        uint32_t t2 = mw[0];
+#pragma unroll
+        for (uint32_t i = 1; i < EPF / 2; i++) t2 = pk_max_u16(t2, mw[i]);
+        t2 = dmax<uint32_t>(t2 & 0xffffu, t2 >> 16);                            /* the thread's last mark (0: none) */
+        uint32_t r = wave_excl_max_u32(t2);                                     /* the last mark in front of my entries */
+        uint32_t e[EPF];
+        const __attribute__((address_space(3))) uint8_t *ent_b = (const __attribute__((address_space(3))) uint8_t *)s_ent16;
+#pragma unroll
+        for (uint32_t j = 0; j < EPF; j++) {
+            r = dmax<uint32_t>(r, (mw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            e[j] = *(const __attribute__((address_space(3))) uint16_t *)(ent_b + r);
+        }
+        if constexpr (EPF == 8)
+            *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        else
+            *reinterpret_cast<uint2 *>(sh.lut + x0) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
     }
     /* ---- second level: the subtree below a 12-bit prefix whose codes are at most DSUB_L2_BITS longer
      *      gets a table of its own (2, 4 or 6 more bits) in sh.ent.  Codes beyond that keep their `long`
@@ -432,7 +454,7 @@ __device__ __forceinline__ uint64_t dec_rare_fast(const SH &sh, const uint32_t *
 template <class SH>
 __device__ __forceinline__ uint32_t dsub_next(const SH &sh, RevReader &rd, uint32_t lim, bool &ok)
 {
-    uint32_t e = sh.lut[rd.index()];
+    uint32_t e = rd.first_bit() ? (uint32_t)DSE_BAD : (uint32_t)sh.lut[rd.index()];   /* (a first bit of 1 leaves the tree: the root has no right child) */
     if (__builtin_expect(__ballot(DSE_LEN(e) == 0u) != 0ull, 0)) {
         if (DSE_IS_L2(e)) {
             e = dsub_l2(sh, e, rd.hi);
@@ -576,8 +598,7 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
 
     /* A tile's set-up.  The lane's column starts with the aligned 32-bit word of MEMORY that holds the lane's first
      * bit (the staged words are then byte-swapped dwords, whatever the payload's alignment).
-     *   gb, nsym   : the lane's group as told / its symbols
-     *   ex         : payload bits of the tile in front of the lane's group
+         *   ex         : payload bits of the tile in front of the lane's group
      *   lead       : bits of the column's word 0 in front of the group (0..31)
      *   quick      : every group fits its column and the loads stay inside the stream (wave-uniform)
      *   V[3]       : the column's twelve dwords, requested here
@@ -586,7 +607,7 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
      * compiler with "maybe pending" registers at the top of the loop, and its wait for those is a wait for the
      * previous tile's STORES as well.) */
     uint4 V[3];
-    uint32_t gb_n = 0, nsym_n = 0, lead_n = 0;
+    uint32_t state_n = 0;                                           /* the lane's part in the tile that was set up last: see DSUB_STATE */
     bool quick_n = false;
     /* What the sub-index says about a tile is requested TWO tiles ahead (the words themselves one tile ahead): the
      * tile's start and the next tile's through the scalar cache (the sub-index is not written by this kernel: constant
@@ -620,15 +641,18 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         const uint32_t rel_t_ = (uint32_t)d_;                                                                 \
         const bool more_ = valid_ && (qq_ + 1u < ntiles || block_goes_on);                                    \
         const uint32_t g_ = qq_ * 64u + (uint32_t)lane;                                                       \
-        gb_n = dmin<uint32_t>(gb_f, DSUB_MAX_GROUP_BITS);                                                     \
-        nsym_n = (valid_ && g_ < ngrp) ? dmin<uint32_t>(DSUB_SPL, nchunk - g_ * DSUB_SPL) : 0u;               \
+        const uint32_t gb_n = dmin<uint32_t>(gb_f, DSUB_MAX_GROUP_BITS);                                      \
+        const uint32_t nsym_n = (valid_ && g_ < ngrp) ? dmin<uint32_t>(DSUB_SPL, nchunk - g_ * DSUB_SPL) : 0u; \
         const uint32_t incl_ = wave_incl_scan_u32(gb_n);                                                      \
         const uint32_t tb_ = wave_lane_u32(incl_, 63);                                                        \
         const bool fine_ = valid_ && chunk_fine && uni32((uint32_t)(d_ >> 32)) == 0u && rel_t_ <= room0 && tb_ <= room0 - rel_t_;   /* (b) */ \
         if (valid_ && !fine_) ok = false;                                                                     \
         if (fine_ && more_ && t_f + tb_ != tn_f) ok = false;                             /* (c) */              \
         const uint32_t rel_ = uni32(lead0 + (fine_ ? rel_t_ : 0u)) + (incl_ - gb_n);     /* my first bit from the chunk's aligned first word */ \
-        lead_n = rel_ & 31u;                                                                                  \
+        const uint32_t lead_n = rel_ & 31u;                                                                   \
+        /* one register a lane and tile: where the position register starts (13 bits), where (b) wants it to stand  \
+         * behind the group (13 bits), and 2 = all 32 symbols / 1 = the block's last, short group / 0 = none */       \
+        state_n = (r_top - lead_n) | (((r_top - lead_n - gb_n) & 0x1fffu) << 13) | ((nsym_n == DSUB_SPL ? 2u : (nsym_n ? 1u : 0u)) << 26); \
         uint32_t off_ = (rel_ >> 5) << 2;                                               /* my column's word 0, bytes from that word */ \
         const uint32_t last_ = wave_lane_u32(off_, 63);                                 /* (offsets grow with the lane) */ \
         quick_n = fine_ && last_ <= left0 && left0 - last_ >= 4u * ROWS && __ballot(lead_n + gb_n > DSUB_COL_BITS) == 0ull; \
@@ -686,7 +710,7 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     for (uint32_t ti = 0; q < ntiles; q += WAVES, ti++) {
         pt = DPROF_T();
         const uint32_t my0 = (q * 64u + (uint32_t)lane) * DSUB_SPL;     /* relative to the chunk: 32-bit arithmetic, one offset register */
-        const uint32_t nsym = nsym_n, gb = gb_n, s = lead_n;            /* this tile's: my symbols, my group's bits, the bit I start at */
+        const uint32_t state = state_n;                                 /* this tile's */
         const bool cur_quick = quick_n;
         /* the next tile's words are requested now and arrive while this one is decoded (what the sub-index says
          * about the tile behind it, too) */
@@ -694,10 +718,10 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         DPROF_ADD(9, pt); pt = DPROF_T();
         if (!cur_quick) {
             slow_tiles |= 1u << ti;
-        } else if (nsym) {
-            bool redo = nsym != DSUB_SPL;                       /* the block's last, short group */
+        } else if (state >> 26) {
+            bool redo = (state >> 26) != 2u;                    /* the block's last, short group */
             bool group_ok = false;
-            if (nsym == DSUB_SPL) {
+            if ((state >> 26) == 2u) {
                 /* The common case has no branch.  Every two symbols the 32 bits at the position are read
                  * again from the column (one ds_read2st64_b32, one v_alignbit_b32) - no bit buffer to refill -
                  * and looked up twice; the entries' low five bits shift the window and their sum moves the
@@ -711,9 +735,8 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                  * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
                  * symbol; a lane decoding the two halves of its group side by side.) */
                 const bool aligned = (cout_a & 15u) == 0;             /* (the offset is a multiple of 32) */
-                const uint32_t r0 = r_top - s;
-                uint32_t R = r0;
-                uint32_t special = 0, e_last = 0;
+                uint32_t R = state & 0x1fffu;
+                uint32_t special = 0, e_last = 0, firsts = 0;
 /* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
  * wave by a ballot - goes on to the second table with the bits behind the 12-bit prefix; one that cannot
  * (too few bits left in the window) stays what it is and is remembered in `special`.  Blocks
@@ -722,12 +745,12 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                 {                                                                                             \
                     lds_words wp_ = (lds_words)(uintptr_t)(((R << 3) & 0xffffff00u) | lane4);                  \
                     const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[64], wp_[0], R);                        \
-                    uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0x1ffeu));              \
+                    uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0xffeu));               \
                     if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
                         if (DSE_IS_L2(e1_)) e1_ = dsub_l2(sh, e1_, d1_);                                      \
                     }                                                                                         \
                     const uint32_t d2_ = d1_ << (e1_ & 31u);                                                  \
-                    uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0x1ffeu));              \
+                    uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0xffeu));               \
                     if (L2 && __ballot(DSE_IS_L2(e2_))) {                                                     \
                         /* (the window has 32 - len bits left) */                                             \
                         if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
@@ -737,6 +760,8 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                         special |= e1_ | e2_;                                                                 \
                         asm volatile("" : "+v"(special));     /* (now: not 32 entries kept for one big OR at the end) */ \
                     }                                                                                         \
+                    firsts |= d1_ | d2_;          /* (one v_or3_b32: every codeword's first bit, at bit 31) */   \
+                    asm volatile("" : "+v"(firsts));     /* (now: not 32 windows kept for one big OR at the end) */    \
                     R -= (e1_ + e2_) & 0xffu;                                                                 \
                     PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
                     e_last = e2_;                                                                             \
@@ -772,8 +797,8 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                 else { asm volatile("; every code in the first table" : "+v"(R)); DSUB_ROUNDS(false) }
 #undef DSUB_ROUNDS
 #undef DSUB_WINDOW
-                redo = DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u;
-                group_ok = r0 - R == gb;                        /* (b): exactly the bits of the group */
+                redo = DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u || (firsts >> 31) != 0u;     /* (a first bit of 1: the step-by-step path says what the reference says) */
+                group_ok = R == ((state >> 13) & 0x1fffu);      /* (b): exactly the bits of the group */
             }
             if (redo) redo_tiles |= 1u << ti;
             else if (!group_ok) ok = false;

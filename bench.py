@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMD_CLOCK_HZ = 2.4e9            # peak engine clock (MI355X_MICROARCH.md); used for roofline.valu_issue_frac only
 PROFILE_EVERY = 4              # steps of the timed region that carry per-kernel HIP events: 0, 4, 8, ...
 
 WORKLOADS = {
@@ -105,10 +106,22 @@ def cpu_baseline(workload: str, blocksize: int) -> dict:
     all_cores = None
     if kind == "reference":
         try:
+            import signal
             import subprocess
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores-child", workload, str(blocksize)],
-                               capture_output=True, text=True, timeout=180, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
-            all_cores = json.loads(r.stdout.strip().splitlines()[-1])
+            # (its own process group: a child that overruns is killed with the workers it forked, not left to them)
+            pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-all-cores-child", workload, str(blocksize)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                                  env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            try:
+                stdout, _ = pr.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.communicate()
+                raise
+            all_cores = json.loads(stdout.strip().splitlines()[-1])
         except Exception as e:                                  # never fail the bench over the extra figure
             all_cores = {"error": repr(e)}
     return {"value": round(sample_bytes / GIB / (t_enc + t_dec), 5), "unit": "GiB/s", "cores": 1,
@@ -221,10 +234,11 @@ def measured_traffic(workload: str, kernel: str, n: int, bs: int):
         return None
 
 
-def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0):
+def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0, valu: bool = False):
     """HBM bytes per launch of every kernel named in `kernels` counted in THIS run: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domain mixed in; FETCH_SIZE
-    doubled: the gfx950 correction of MI355X_MICROARCH.md; KiB -> bytes).  None when rocprofv3 is not there, this
+    doubled: the gfx950 correction of MI355X_MICROARCH.md; KiB -> bytes); with valu=True a third pass counts SQ_INSTS_VALU
+    (wave instructions per launch, under the key "__valu__").  None when rocprofv3 is not there, this
     process is itself being profiled, or a pass fails or takes too long - the stamp of profiles/traffic.json
     (same kernel sources) stays in the line then."""
     import csv
@@ -239,7 +253,7 @@ def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0)
     got = {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("SQ_INSTS_VALU",) if valu else ()):
                 cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(d, ctr), "-o", "p", "--",
                        sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--workload", workload,
                        "--secondary", "none", "--no-cpu-baseline", "--no-other-decode", "--no-index-free",
@@ -262,6 +276,8 @@ def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0)
                 got[ctr] = {k: total[k] / len(launches[k]) for k in kernels if launches[k]}
         out = {k: round(got["FETCH_SIZE"][k] * 1024 * 2 + got["WRITE_SIZE"][k] * 1024)
                for k in kernels if k in got["FETCH_SIZE"] and k in got["WRITE_SIZE"]}
+        if valu and out:
+            out["__valu__"] = {k: round(v) for k, v in got.get("SQ_INSTS_VALU", {}).items()}      # wave instructions per launch
         return out or None
     except Exception:
         return None
@@ -819,8 +835,14 @@ def main() -> None:
     done_path = os.path.join(tempfile.gettempdir(), "huf_bench_done_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "0")))
     if world > 1:
         import datetime
-        if rank == 0 and os.path.exists(done_path):
-            os.remove(done_path)                     # (a job of the same port that did not end clean)
+        if rank == 0 and os.path.lexists(done_path):
+            try:                                     # (a job of the same port that did not end clean; only a plain file of ours)
+                st = os.lstat(done_path)
+                import stat
+                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid():
+                    os.remove(done_path)
+            except OSError:
+                pass
         end_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("BENCH_END_TIMEOUT", "180"))))
 
     from libhuffman_amd.codec import GpuCodec
@@ -923,6 +945,19 @@ def main() -> None:
                 "kernels": {k: v["avg_ms"] for k, v in r["kernels"].items()},
                 **({"raw_stream_decode": r["raw_stream_decode"]} if "raw_stream_decode" in r else {})}
             for w, r in sec_recs.items()}
+        # the reference's OWN boundary (src/decoder.c:201-287 takes the stream and nothing else): encode + the decode of a
+        # stream that comes with no index at all, against the same 8 TB/s
+        idx_rec = sec_recs.get(args.workload + "_index_free")
+        if idx_rec is not None and "raw_stream_decode" in idx_rec:
+            enc_ms = sum(v["avg_ms"] for k, v in main_rec["kernels"].items() if k in ("hist256", "tree", "scan_sizes", "pack", "hist_tree"))
+            raw_ms = idx_rec["raw_stream_decode"]["ms"]
+            n1 = main_rec["config"]["bytes_per_gpu"]
+            c1 = main_rec["config"]["compressed_bytes_per_gpu"]
+            gbs = 2 * (n1 + c1) / 1e9 / ((enc_ms + raw_ms) / 1e3)
+            result["roofline"]["ref_boundary"] = {
+                "what": "2 (N + C) bytes over encode + raw-stream decode (huf_decode's input: no block index, no sub-index), one GPU",
+                "encode_ms": round(enc_ms, 4), "raw_stream_decode_ms": round(raw_ms, 4), "achieved": round(gbs, 1),
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "GiBps": round(n1 / GIB / ((enc_ms + raw_ms) / 1e3), 1)}
         if root_rec is not None:
             result["root_placement"] = root_rec
         if py_rec is not None:
@@ -937,18 +972,34 @@ def main() -> None:
             live_src = ("counted in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child passes "
                         "of this command (FETCH_SIZE doubled: gfx950)")
             want = sorted({result["roofline"]["kernel"], "pack_kernel", "hist_lanes_kernel", "tree_wave_kernel"})
-            lt = live_traffic(args.workload, want, same)
+            lt = live_traffic(args.workload, want, same, valu=True)
+            valu = lt.pop("__valu__", None) if lt else None
             if lt and result["roofline"]["kernel"] in lt:
                 result["roofline"]["traffic"] = lt[result["roofline"]["kernel"]]
                 result["roofline"]["traffic_source"] = live_src
             if lt:
                 result["kernel_traffic"] = {"bytes_per_launch": lt, "source": live_src}
+            if valu:
+                # how much of a kernel's time its vector instructions alone take to ISSUE: a wave instruction holds its SIMD
+                # for 4 cycles, the chip has 256 CUs x 4 SIMDs at SIMD_CLOCK_HZ (the peak engine clock: a lower bound of the share)
+                kms = {"pack_kernel": "pack", "hist_lanes_kernel": "hist256", "tree_wave_kernel": "tree",
+                       "decode_sub_kernel": "decode", "decode_fast_kernel": "decode"}
+                fr = {k: round(v * 4.0 / (1024 * SIMD_CLOCK_HZ * main_rec["kernels"][kms[k]]["avg_ms"] * 1e-3), 4)
+                      for k, v in valu.items() if k in kms and kms[k] in main_rec["kernels"] and main_rec["kernels"][kms[k]]["avg_ms"] > 0}
+                result["kernel_valu"] = {"wave_instructions_per_launch": valu, "issue_frac": fr,
+                                         "source": "counted in this run: rocprofv3 --pmc SQ_INSTS_VALU, a child pass of this command; "
+                                                   "issue_frac = instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x the kernel's time)"}
+                if result["roofline"]["kernel"] in fr:
+                    result["roofline"]["valu_issue_frac"] = fr[result["roofline"]["kernel"]]
             # the index-alone decoder's kernel: one more pair of passes of the same command with --decode selfsync
             if (args.workload + "_index_free") in sec_recs and args.decode == "sub":
                 same_idx = [x if x != args.decode else "selfsync" for x in same]
                 li = live_traffic(args.workload, ["decode_fast_kernel"], same_idx)
                 if li:
                     result.setdefault("kernel_traffic", {"bytes_per_launch": {}, "source": live_src})["bytes_per_launch"].update(li)
+                    idx = result["secondary"][args.workload + "_index_free"]["roofline"]
+                    if idx.get("kernel") == "decode_fast_kernel":          # the live count in the record it belongs to, not the stamp
+                        idx["traffic"], idx["traffic_source"] = li["decode_fast_kernel"], live_src
         result["roofline"]["copy_ceiling_GBps"] = round(copy_gbs, 1)
         result["roofline"]["read_ceiling_GBps"] = round(ceil["read"][0], 1)
         result["roofline"]["write_ceiling_GBps"] = round(ceil["fill"][0], 1)
@@ -1003,7 +1054,7 @@ def main() -> None:
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(result), flush=True)
         try:
-            open(done_path, "w").close()
+            os.close(os.open(done_path, os.O_CREAT | os.O_EXCL | os.O_WRONLY | os.O_NOFOLLOW, 0o600))
         except OSError:
             pass
         os._exit(0 if all_ok else 1)

@@ -1037,14 +1037,26 @@ static huf_error_t lane_copy(int to_device, void *dev, void *host, size_t n)
     const int nl = lane_count();
     if (n < LANE_MIN || nl <= 0) goto plain;
     (void)hipSetDevice(t_session->device);
-    if (!st->lanes_ready) {
-        if (st->lanes_ready < 0) goto plain;
+    if (st->lanes_ready < 0) goto plain;             /* a set-up that failed once: plain copies from then on */
+    if (st->lanes_ready == 0) {
         st->lanes_ready = -1;
-        if (hipHostMalloc(&st->lane_pin, (size_t)2 * LANE_MAX * LANE_SLOT, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); st->lane_pin = NULL; goto plain; }
-        for (int i = 0; i < LANE_MAX; i++) {
-            if (hipStreamCreateWithFlags(&st->lane_stream[i], hipStreamNonBlocking) != hipSuccess) goto plain;
-            for (int e = 0; e < 2; e++)
-                if (hipEventCreateWithFlags(&st->lane_ev[i][e], hipEventDisableTiming) != hipSuccess) goto plain;
+        int made_streams = 0, made_events = 0, failed = 0;
+        if (hipHostMalloc(&st->lane_pin, (size_t)2 * (size_t)nl * LANE_SLOT, hipHostMallocPortable) != hipSuccess) { st->lane_pin = NULL; failed = 1; }
+        for (int i = 0; i < nl && !failed; i++) {
+            if (hipStreamCreateWithFlags(&st->lane_stream[i], hipStreamNonBlocking) != hipSuccess) { failed = 1; break; }
+            made_streams++;
+            for (int e = 0; e < 2; e++) {
+                if (hipEventCreateWithFlags(&st->lane_ev[i][e], hipEventDisableTiming) != hipSuccess) { failed = 1; break; }
+                made_events++;
+            }
+        }
+        if (failed) {                                /* give back what was made: nothing of it is looked at again */
+            (void)hipGetLastError();
+            for (int k = 0; k < made_events; k++) (void)hipEventDestroy(st->lane_ev[k / 2][k % 2]);
+            for (int i = 0; i < made_streams; i++) (void)hipStreamDestroy(st->lane_stream[i]);
+            if (st->lane_pin) (void)hipHostFree(st->lane_pin);
+            st->lane_pin = NULL;
+            goto plain;
         }
         st->lanes_ready = 1;
     }
@@ -1075,6 +1087,271 @@ static huf_error_t lane_copy(int to_device, void *dev, void *host, size_t n)
 plain:
     return (huf_error_t)(to_device ? hufgpu_memcpy_h2d(g_ctx, dev, host, n) : hufgpu_memcpy_d2h(g_ctx, host, dev, n));
 }
+
+/* ------------------------------------------------------------------ transfers in both directions at once
+ * huf_encode / huf_decode between two memory streams (src/encoder.c:261-388, src/decoder.c:201-287 with the
+ * reference's memory streams on both ends) move N bytes to the device and about as many back; round 4 did one after
+ * the other - copy in, kernels, copy out, per round of 256 MiB - and reached 11 GiB/s over a link that carries 53
+ * each way AT THE SAME TIME.  Here a session owns two sets of persistent copy threads ("lanes"), one per direction;
+ * a lane has two pinned slots, a stream and its events.  The caller publishes SEGMENTS - (host address, device
+ * address, bytes) - per direction; the lanes of that direction take the segments in order and share the pieces of
+ * each (DX_SLOT bytes, dealt out round robin).
+ *   host -> device: memcpy into a slot, asynchronous copy from it, the next piece into the other slot meanwhile.
+ *     A lane reports a segment as ISSUED - its copies are on the lane's stream, an event behind them - and the
+ *     caller makes the compute stream wait for those events: no host thread waits for a copy to arrive.
+ *   device -> host: asynchronous copy into a slot, and while it runs the piece before it goes from the other slot
+ *     to its destination, whose pages the lane populates first (d2h_to_memstream's comment says why not earlier).
+ *     A lane reports a segment as DONE when its pieces are in place.
+ * Rounds of HUF_GPU_ROUND_MB (32) then overlap as: copy-in of round i + 1 | kernels of round i | copy-out of round
+ * i - 1, inside ONE session (two sessions on one GPU lose: profiles/r04/python_layer_sessions.txt). */
+#define DX_LANES_MAX 8
+#define DX_SLOT ((size_t)4 << 20)
+#define DX_RING 16                       /* segments a direction may have in flight */
+typedef struct {
+    char *host, *dev;
+    size_t n;
+    int direct;                          /* host -> device: the host bytes lie in registered (pinned) pages - copied from where they are */
+    int issued_left;                     /* lanes that have not yet put their pieces on their streams (host -> device) */
+    int done_left;                       /* lanes that have not yet finished their pieces */
+} dx_seg_t;
+struct dx_pool;
+typedef struct {
+    struct dx_pool *pool;
+    int dir, idx;
+    pthread_t th;
+    hipStream_t stream;
+    hipEvent_t slot_ev[2];
+    hipEvent_t seg_ev[DX_RING];          /* host -> device: behind the lane's last copy of a segment */
+    char *slot[2];
+} dx_lane_t;
+typedef struct dx_pool {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int device;
+    int ready;                           /* 0 not made, 1 usable, -1 could not be made */
+    int err;                             /* a lane met a failing HIP call (sticky for the pool's life) */
+    int nl[2];                           /* lanes per direction: [0] host -> device, [1] device -> host */
+    int can_register;                    /* hipHostRegister works on this process's pageable memory (dx_register_input) */
+    dx_lane_t lane[2][DX_LANES_MAX];
+    dx_seg_t seg[2][DX_RING];
+    uint64_t published[2];               /* segments ever published per direction (a segment's id is its number) */
+    void *pin;
+} dx_pool_t;
+
+static int dx_lanes_per_dir(void)
+{
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("HUF_GPU_DUPLEX_LANES");
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        n = e ? atoi(e) : (int)(cpus >= 16 ? 5 : (cpus >= 8 ? 3 : (cpus >= 4 ? 2 : 1)));
+        if (n < 0) n = 0;
+        if (n > DX_LANES_MAX) n = DX_LANES_MAX;
+    }
+    return n;
+}
+
+static void dx_fail(dx_pool_t *P) { pthread_mutex_lock(&P->mu); P->err = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); (void)hipGetLastError(); }
+
+static void *dx_lane_main(void *arg)
+{
+    dx_lane_t *L = (dx_lane_t *)arg;
+    dx_pool_t *P = L->pool;
+    const int dir = L->dir, nl = P->nl[dir];
+    if (hipSetDevice(P->device) != hipSuccess) dx_fail(P);
+    uint64_t cur = 0;                    /* the next segment of this direction this lane looks at */
+    unsigned k = 0;                      /* pieces this lane has moved: k & 1 is the slot of the next */
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        while (cur >= P->published[dir]) pthread_cond_wait(&P->cv, &P->mu);
+        const dx_seg_t sg = P->seg[dir][cur % DX_RING];
+        pthread_mutex_unlock(&P->mu);
+        const size_t pieces = (sg.n + DX_SLOT - 1) / DX_SLOT;
+        /* piece q of segment `cur` is lane (q + cur) % nl's: short segments do not all start at lane 0 */
+        size_t q = (size_t)(((uint64_t)L->idx + (uint64_t)nl - cur % (uint64_t)nl) % (uint64_t)nl);
+        int bad = 0;
+        if (dir == 0 && sg.direct) {
+            /* registered pages: one asynchronous copy of the whole segment, by the lane whose turn it is */
+            if (q == 0 && hipMemcpyAsync(sg.dev, sg.host, sg.n, hipMemcpyHostToDevice, L->stream) != hipSuccess) bad = 1;
+            if (hipEventRecord(L->seg_ev[cur % DX_RING], L->stream) != hipSuccess) bad = 1;
+        } else if (dir == 0) {
+            for (; q < pieces && !bad; q += (size_t)nl, k++) {
+                const size_t off = q * DX_SLOT, len = (sg.n - off < DX_SLOT) ? sg.n - off : DX_SLOT;
+                if (k >= 2 && hipEventSynchronize(L->slot_ev[k & 1]) != hipSuccess) { bad = 1; break; }
+                memcpy(L->slot[k & 1], sg.host + off, len);
+                if (hipMemcpyAsync(sg.dev + off, L->slot[k & 1], len, hipMemcpyHostToDevice, L->stream) != hipSuccess ||
+                    hipEventRecord(L->slot_ev[k & 1], L->stream) != hipSuccess) bad = 1;
+            }
+            if (hipEventRecord(L->seg_ev[cur % DX_RING], L->stream) != hipSuccess) bad = 1;
+        } else {
+            /* the copy of piece q + nl is in flight while piece q goes from its slot to the destination */
+            size_t off = q * DX_SLOT, len = 0;
+            if (q < pieces) {
+                len = (sg.n - off < DX_SLOT) ? sg.n - off : DX_SLOT;
+                if (hipMemcpyAsync(L->slot[k & 1], sg.dev + off, len, hipMemcpyDeviceToHost, L->stream) != hipSuccess ||
+                    hipEventRecord(L->slot_ev[k & 1], L->stream) != hipSuccess) bad = 1;
+            }
+            for (; q < pieces && !bad; q += (size_t)nl, k++) {
+                const size_t qn = q + (size_t)nl;
+                size_t offn = 0, lenn = 0;
+                if (qn < pieces) {
+                    offn = qn * DX_SLOT;
+                    lenn = (sg.n - offn < DX_SLOT) ? sg.n - offn : DX_SLOT;
+                    if (hipMemcpyAsync(L->slot[(k + 1) & 1], sg.dev + offn, lenn, hipMemcpyDeviceToHost, L->stream) != hipSuccess ||
+                        hipEventRecord(L->slot_ev[(k + 1) & 1], L->stream) != hipSuccess) { bad = 1; break; }
+                }
+                prefault_t w = {sg.host + off, len};
+                prefault_main(&w);                   /* (contents untouched; pages that are there already cost nothing) */
+                if (hipEventSynchronize(L->slot_ev[k & 1]) != hipSuccess) { bad = 1; break; }
+                memcpy(sg.host + off, L->slot[k & 1], len);
+                off = offn;
+                len = lenn;
+            }
+        }
+        pthread_mutex_lock(&P->mu);
+        if (bad) { P->err = 1; (void)hipGetLastError(); }
+        dx_seg_t *g = &P->seg[dir][cur % DX_RING];
+        g->issued_left--;
+        g->done_left--;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+        cur++;
+    }
+    return NULL;
+}
+
+/* the session's pool, made on first use; NULL when it cannot be made (the callers then move bytes the old way) */
+static dx_pool_t *dx_get(void)
+{
+    static dx_pool_t pools[HUF_MAX_SESSIONS];
+    dx_pool_t *P = &pools[t_session - g_sessions];
+    if (P->ready > 0) return P->err ? NULL : P;
+    if (P->ready < 0) return NULL;
+    const int nl = dx_lanes_per_dir();
+    P->ready = -1;
+    if (nl <= 0) return NULL;
+    (void)hipSetDevice(t_session->device);
+    P->device = t_session->device;
+    P->nl[0] = P->nl[1] = nl;
+    {   /* can this process register pageable memory at all?  (HUF_GPU_REGISTER=0: never tried) */
+        const char *e = getenv("HUF_GPU_REGISTER");
+        void *probe = NULL;
+        if (!(e && atoi(e) == 0) && posix_memalign(&probe, 4096, 1 << 16) == 0) {
+            memset(probe, 1, 1 << 16);
+            if (hipHostRegister(probe, 1 << 16, hipHostRegisterDefault) == hipSuccess) {
+                (void)hipHostUnregister(probe);
+                P->can_register = 1;
+                P->nl[1] = nl + 3 < DX_LANES_MAX ? nl + 3 : DX_LANES_MAX;     /* (threads the other direction will rarely need) */
+            } else (void)hipGetLastError();
+            free(probe);
+        }
+    }
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+    if (hipHostMalloc(&P->pin, (size_t)2 * (size_t)(P->nl[0] + P->nl[1]) * DX_SLOT, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); P->pin = NULL; return NULL; }
+    int ok = 1, slots = 0;
+    for (int d = 0; d < 2 && ok; d++)
+        for (int i = 0; i < P->nl[d] && ok; i++, slots += 2) {
+            dx_lane_t *L = &P->lane[d][i];
+            L->pool = P; L->dir = d; L->idx = i;
+            L->slot[0] = (char *)P->pin + (size_t)slots * DX_SLOT;
+            L->slot[1] = L->slot[0] + DX_SLOT;
+            if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) ok = 0;
+            for (int e = 0; e < 2 && ok; e++) if (hipEventCreateWithFlags(&L->slot_ev[e], hipEventDisableTiming) != hipSuccess) ok = 0;
+            for (int e = 0; e < DX_RING && ok; e++) if (hipEventCreateWithFlags(&L->seg_ev[e], hipEventDisableTiming) != hipSuccess) ok = 0;
+        }
+    if (!ok) { (void)hipGetLastError(); return NULL; }        /* (what was made stays: a process makes at most one pool a session) */
+    for (int d = 0; d < 2; d++)
+        for (int i = 0; i < P->nl[d]; i++) {
+            dx_lane_t *L = &P->lane[d][i];
+            if (pthread_create(&L->th, NULL, dx_lane_main, L) != 0) return NULL;     /* (lanes that run wait for ever for work: harmless) */
+            pthread_detach(L->th);
+        }
+    P->ready = 1;
+    return P;
+}
+
+/* a segment for the lanes of direction `dir`; returns its id.  Waits while the direction's ring is full. */
+static uint64_t dx_publish(dx_pool_t *P, int dir, void *host, void *dev, size_t n, int direct = 0)
+{
+    pthread_mutex_lock(&P->mu);
+    const uint64_t id = P->published[dir];
+    if (id >= DX_RING)
+        while (P->seg[dir][id % DX_RING].done_left > 0 && !P->err) pthread_cond_wait(&P->cv, &P->mu);      /* the segment a ring ago */
+    dx_seg_t *g = &P->seg[dir][id % DX_RING];
+    g->host = (char *)host; g->dev = (char *)dev; g->n = n; g->direct = direct;
+    g->issued_left = g->done_left = P->nl[dir];
+    P->published[dir] = id + 1;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+    return id;
+}
+/* host -> device segment `id`: every lane has its copies on its stream; the default stream (the kernels') waits for them */
+static huf_error_t dx_wait_issued(dx_pool_t *P, uint64_t id)
+{
+    pthread_mutex_lock(&P->mu);
+    while (P->seg[0][id % DX_RING].issued_left > 0 && !P->err) pthread_cond_wait(&P->cv, &P->mu);
+    const int err = P->err;
+    pthread_mutex_unlock(&P->mu);
+    if (err) return HUF_ERROR_FATAL;
+    for (int i = 0; i < P->nl[0]; i++)
+        if (hipStreamWaitEvent((hipStream_t)0, P->lane[0][i].seg_ev[id % DX_RING], 0) != hipSuccess) { (void)hipGetLastError(); return HUF_ERROR_FATAL; }
+    return HUF_ERROR_SUCCESS;
+}
+static huf_error_t dx_wait_done(dx_pool_t *P, int dir, uint64_t id)
+{
+    pthread_mutex_lock(&P->mu);
+    while (P->seg[dir][id % DX_RING].done_left > 0 && !P->err) pthread_cond_wait(&P->cv, &P->mu);
+    const int err = P->err;
+    pthread_mutex_unlock(&P->mu);
+    return err ? HUF_ERROR_FATAL : HUF_ERROR_SUCCESS;
+}
+/* everything published so far has been moved (a failed pool: the lanes still count their segments down) */
+static void dx_drain(dx_pool_t *P)
+{
+    pthread_mutex_lock(&P->mu);
+    for (int d = 0; d < 2; d++) {
+        const uint64_t n = P->published[d];
+        for (uint64_t id = n > DX_RING ? n - DX_RING : 0; id < n; id++)
+            while (P->seg[d][id % DX_RING].done_left > 0) pthread_cond_wait(&P->cv, &P->mu);
+    }
+    pthread_mutex_unlock(&P->mu);
+}
+
+/* What a call reads from host memory has been written by somebody: its pages are there, and registering pages that are
+ * there costs 2 ms per GiB on these boxes (tools/calib/host_link_probe.hip; pages never touched: 45 ms, the faults).  The
+ * whole input is registered ONCE, before the first lane moves - a hipHostRegister beside the output lanes' page
+ * populating brings both to a crawl (the address-space lock: 29 GiB/s where 50 were measured alone, and two threads
+ * that register at once get a fifth of one thread's rate) - and the copies then run straight from the caller's pages:
+ * no memcpy into a slot, 2 GiB of memory traffic per GiB and five busy threads less.  Returns the registered base (to
+ * hand to dx_unregister_input) or NULL: a read-only mapping, pages somebody else has registered - the staged lanes
+ * take the call then. */
+static void *dx_register_input(dx_pool_t *P, const void *host, size_t n)
+{
+    if (!P->can_register || !n) return NULL;
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = (uintptr_t)host & ~(page - 1), hi = ((uintptr_t)host + n + page - 1) & ~(page - 1);   /* (the pages that hold its first and last byte are mapped) */
+    if (hipHostRegister((void *)lo, (size_t)(hi - lo), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    return (void *)lo;
+}
+static void dx_unregister_input(void *base)
+{
+    if (base && hipHostUnregister(base) != hipSuccess) (void)hipGetLastError();
+}
+
+/* bytes a round: HUF_GPU_ROUND_MB, else an eighth of the call between 8 and 32 MiB (a call of 64 MiB in eight rounds
+ * still overlaps seven of them; a round much below 8 MiB is a piece or two for ten lanes) */
+static uint64_t dx_round_bytes(uint64_t total)
+{
+    static long env = -1;
+    if (env < 0) { const char *e = getenv("HUF_GPU_ROUND_MB"); env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    if (env > 0) return (uint64_t)env << 20;
+    uint64_t r = (total / 8) & ~(((uint64_t)1 << 20) - 1);
+    if (r < ((uint64_t)8 << 20)) r = (uint64_t)8 << 20;
+    if (r > ((uint64_t)32 << 20)) r = (uint64_t)32 << 20;
+    return r;
+}
+#define DX_MIN_BYTES ((uint64_t)32 << 20)      /* below this the rounds are too few to overlap anything */
 
 static huf_error_t d2h_to_memstream(membuf_t *wmem, const void *d_src, size_t n)
 {
@@ -1592,6 +1869,101 @@ static int encode_fanout(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf
     return 1;
 }
 
+/* HUF_GPU_DX_TRACE=1: where the calling thread of a duplex call spends its time, one line per call on stderr */
+static int dx_trace(void)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("HUF_GPU_DX_TRACE"); on = (e && atoi(e) != 0) ? 1 : 0; }
+    return on;
+}
+static double dx_now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define DX_T(acc, stmt) do { const double t_ = dx_trace() ? dx_now() : 0.0; stmt; if (dx_trace()) (acc) += dx_now() - t_; } while (0)
+
+static int duplex_enabled(void)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("HUF_GPU_DUPLEX"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on;
+}
+
+/* room for `count` bytes behind the `pending` bytes that lie behind the stream's contents already (results of earlier
+ * rounds, not yet counted in len).  A buffer that has to grow moves: the lanes that write into it finish first. */
+static huf_error_t mem_reserve_behind(membuf_t *m, dx_pool_t *P, size_t pending, size_t count)
+{
+    if (m->cap - m->len >= pending + count) return HUF_ERROR_SUCCESS;
+    dx_drain(P);
+    m->len += pending;                               /* (what a grown buffer takes along) */
+    const huf_error_t rc = mem_reserve(m, count);
+    m->len -= pending;
+    return rc;
+}
+
+/* huf_encode() between two memory streams in rounds whose transfers overlap (the comment above dx_lane_main): returns
+ * 1 when it took the call (*result = what huf_encode returns), 0 when the call is not of that kind - the caller goes
+ * on as before.  Rounds are whole blocks (src/encoder.c:288-374: blocks are independent), the stream is the rounds'
+ * streams one after the other; a round that fails ends the call with the rounds in front of it delivered, as
+ * encode_rounds does. */
+static int encode_duplex(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf_error_t *result)
+{
+    const uint64_t length = enc->config->length, blocksize = enc->config->blocksize;
+    if (!rmem || !wmem || !duplex_enabled() || length < DX_MIN_BYTES || rmem->len - rmem->off < length || blocksize == 0) return 0;
+    uint64_t R = dx_round_bytes(length);
+    if (R < blocksize) R = blocksize;
+    R -= R % blocksize;
+    if (length <= R + R / 2) return 0;
+    dx_pool_t *P = dx_get();
+    if (!P) return 0;
+    const uint64_t bound = (hufgpu_encode_bound(R, blocksize) + 255u) & ~(uint64_t)255;
+    if (grow_dev(&g_stage.d_a, &g_stage.d_a_cap, 2 * R) != HUF_ERROR_SUCCESS ||
+        grow_dev(&g_stage.d_b, &g_stage.d_b_cap, 2 * bound) != HUF_ERROR_SUCCESS) return 0;
+    if (!wmem->fixed && mem_reserve(wmem, hufgpu_encode_bound(length, blocksize)) != HUF_ERROR_SUCCESS) return 0;
+    const uint64_t nr = (length + R - 1) / R;
+    char *src = (char *)*rmem->buf + rmem->off;
+    char *d_in[2] = {(char *)g_stage.d_a, (char *)g_stage.d_a + R};
+    char *d_out[2] = {(char *)g_stage.d_b, (char *)g_stage.d_b + bound};
+#define ROUND_BYTES(i) (((i) + 1) * R <= length ? R : length - (i) * R)
+    void *const reg = dx_register_input(P, src, length);
+    const int direct = reg != NULL;
+    const uint64_t in0 = dx_publish(P, 0, src, d_in[0], ROUND_BYTES((uint64_t)0), direct);
+    if (nr > 1) (void)dx_publish(P, 0, src + R, d_in[1], ROUND_BYTES((uint64_t)1), direct);
+    uint64_t out0 = 0, out_total = 0, done_in = 0;
+    huf_error_t err = HUF_ERROR_SUCCESS;
+    double t_in = 0, t_out = 0, t_k = 0, t_end = 0;
+    const double t_start = dx_trace() ? dx_now() : 0.0;
+    for (uint64_t i = 0; i < nr; i++) {
+        DX_T(t_in, err = dx_wait_issued(P, in0 + i));
+        if (err == HUF_ERROR_SUCCESS && i >= 2) DX_T(t_out, err = dx_wait_done(P, 1, out0 + i - 2));      /* the round that used this output buffer */
+        if (err != HUF_ERROR_SUCCESS) break;
+        uint64_t out_len = 0;
+        DX_T(t_k, err = (huf_error_t)hufgpu_encode(g_ctx, d_in[i & 1], ROUND_BYTES(i), blocksize, d_out[i & 1], bound, NULL, &out_len, NULL));
+        done_in = (i + 1 < nr) ? (i + 1) * R : length;                                       /* (what a failed round has consumed, too) */
+        if (err != HUF_ERROR_SUCCESS) break;
+        err = mem_reserve_behind(wmem, P, out_total, out_len);
+        if (err != HUF_ERROR_SUCCESS) break;
+        const uint64_t id = dx_publish(P, 1, (char *)*wmem->buf + wmem->len + out_total, d_out[i & 1], out_len);
+        if (i == 0) out0 = id;
+        out_total += out_len;
+        if (i + 2 < nr) (void)dx_publish(P, 0, src + (i + 2) * R, d_in[i & 1], ROUND_BYTES(i + 2), direct);   /* its kernels are done: the buffer is free */
+    }
+#undef ROUND_BYTES
+    DX_T(t_end, dx_drain(P));
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); if (err == HUF_ERROR_SUCCESS) err = HUF_ERROR_FATAL; }   /* (copies of rounds a failure left behind) */
+    dx_unregister_input(reg);
+    if (dx_trace())
+        fprintf(stderr, "encode_duplex: %llu rounds of %llu MiB, %.2f ms: waiting for input %.2f, for an output buffer %.2f, kernels (+ their wait) %.2f, the last copies %.2f; input registered=%d lanes %d/%d\n",
+                (unsigned long long)nr, (unsigned long long)(R >> 20), (dx_now() - t_start) * 1e3, t_in * 1e3, t_out * 1e3, t_k * 1e3, t_end * 1e3, direct, P->nl[0], P->nl[1]);
+    if (err == HUF_ERROR_SUCCESS && P->err) err = HUF_ERROR_FATAL;
+    rmem->off += done_in;
+    wmem->len += out_total;
+    *result = err;
+    return 1;
+}
+
 static huf_error_t encode_locked(huf_encoder_t *enc)
 {
     const uint64_t length = enc->config->length;
@@ -1609,7 +1981,7 @@ static huf_error_t encode_locked(huf_encoder_t *enc)
     const int wfd = (wmem || !zero_copy_enabled()) ? -1 : own_fd_of(enc->config->writer, 1);
     {
         huf_error_t fan = HUF_ERROR_SUCCESS;
-        if (encode_fanout(enc, rmem, wmem, &fan))
+        if (encode_fanout(enc, rmem, wmem, &fan) || encode_duplex(enc, rmem, wmem, &fan))
             return fan != HUF_ERROR_SUCCESS ? fan : huf_bufio_read_writer_flush(enc->bufio_writer);
     }
 
@@ -1994,6 +2366,96 @@ static int decode_fanout(huf_decoder_t *dec, membuf_t *rmem, membuf_t *wmem, uin
     return done;
 }
 
+/* huf_decode() between two memory streams, the same way: the stream goes to the device segment by segment, is decoded in
+ * rounds of HUF_GPU_ROUND_MB compressed bytes cut at block boundaries (decode_rounds_fd's loop: the block loop of
+ * src/decoder.c:218 with more check points) and every round's output leaves while the next is decoded.  Returns 1 when
+ * it took the call.  ANYTHING unusual - an error in any round, a last block that wants bytes beyond `length`, an output
+ * that does not fit - leaves the call to the ordinary path (returns 0 with nothing committed), which reports what the
+ * reference reports. */
+static int decode_duplex(huf_decoder_t *dec, membuf_t *rmem, membuf_t *wmem, uint32_t flags, huf_error_t *result)
+{
+    if (!rmem || !wmem || !duplex_enabled()) return 0;
+    const uint64_t length = dec->config->length;
+    const uint64_t left = rmem->len - rmem->off;
+    const uint64_t total = length < left ? length : left;
+    const uint64_t R = dx_round_bytes(total);
+    if (total < DX_MIN_BYTES || total <= R + R / 2) return 0;
+    dx_pool_t *P = dx_get();
+    if (!P) return 0;
+    const uint64_t margin = 4u << 20;                /* what a round may look ahead (its last block's end) */
+    const uint64_t out_cap = ((R + margin) * 8 + (1u << 20) + 255u) & ~(uint64_t)255;
+    if (grow_dev(&g_stage.d_a, &g_stage.d_a_cap, total + 16) != HUF_ERROR_SUCCESS ||
+        grow_dev(&g_stage.d_b, &g_stage.d_b_cap, 2 * out_cap) != HUF_ERROR_SUCCESS ||
+        grow_dev(&g_stage.d_c, &g_stage.d_c_cap, R + margin + 16) != HUF_ERROR_SUCCESS) return 0;
+    if (!wmem->fixed && mem_reserve(wmem, total + total / 4 + (1u << 20)) != HUF_ERROR_SUCCESS) return 0;
+    char *src = (char *)*rmem->buf + rmem->off;
+    char *d_out[2] = {(char *)g_stage.d_b, (char *)g_stage.d_b + out_cap};
+    void *const reg = dx_register_input(P, src, total);
+    const int direct = reg != NULL;
+    const uint64_t nseg = (total + R - 1) / R;
+    uint64_t pub = 0, waited = 0, loaded = 0, in0 = 0;   /* input segments published / the kernels' stream waits for / their bytes */
+    uint64_t pos = 0, out_total = 0, out0 = 0, rounds = 0;
+    int ok = 1;
+    double t_in = 0, t_out = 0, t_k = 0, t_cp = 0, t_end = 0;
+    const double t_start = dx_trace() ? dx_now() : 0.0;
+    while (ok && pos < total) {
+        const uint64_t round_len = (total - pos < R) ? total - pos : R;
+        uint64_t need = pos + round_len + margin;
+        if (need > total) need = total;
+        uint64_t raw = 0, used = 0;
+        for (;;) {
+            while (ok && loaded < need) {            /* (at most three segments ahead of what has been asked for) */
+                while (pub < nseg && pub < waited + 3) {
+                    const uint64_t n = (pub + 1) * R <= total ? R : total - pub * R;
+                    const uint64_t id = dx_publish(P, 0, src + pub * R, (char *)g_stage.d_a + pub * R, n, direct);
+                    if (pub == 0) in0 = id;
+                    pub++;
+                }
+                huf_error_t we = HUF_ERROR_SUCCESS;
+                DX_T(t_in, we = dx_wait_issued(P, in0 + waited));
+                if (we != HUF_ERROR_SUCCESS) { ok = 0; break; }
+                waited++;
+                loaded = waited * R < total ? waited * R : total;
+            }
+            if (!ok) break;
+            const uint64_t avail = (loaded - pos < R + margin) ? loaded - pos : R + margin;   /* (whole segments arrive: more than was asked for) */
+            /* the round's bytes at an aligned address (the parallel block discovery wants that); the buffer two rounds back is free */
+            int rc = HUF_ERROR_SUCCESS;
+            DX_T(t_cp, rc = hufgpu_memcpy_d2d(g_ctx, g_stage.d_c, (const char *)g_stage.d_a + pos, avail));
+            if (rc != HUF_ERROR_SUCCESS) { ok = 0; break; }
+            if (rounds >= 2) DX_T(t_out, rc = dx_wait_done(P, 1, out0 + rounds - 2));
+            if (rc != HUF_ERROR_SUCCESS) { ok = 0; break; }
+            DX_T(t_k, rc = hufgpu_decode_stream(g_ctx, g_stage.d_c, avail, round_len, d_out[rounds & 1], out_cap, flags, &raw, &used, NULL));
+            if (rc == HUF_ERROR_READ_WRITE && loaded < total) {                                /* the last block wants more of the stream: it is on its way */
+                need = loaded + R < total ? loaded + R : total;
+                continue;
+            }
+            if (rc != HUF_ERROR_SUCCESS || used == 0) ok = 0;
+            break;
+        }
+        if (!ok) break;
+        if (raw) {
+            if (mem_reserve_behind(wmem, P, out_total, raw) != HUF_ERROR_SUCCESS) { ok = 0; break; }
+            const uint64_t id = dx_publish(P, 1, (char *)*wmem->buf + wmem->len + out_total, d_out[rounds & 1], raw);
+            if (rounds == 0) out0 = id;
+            out_total += raw;
+            rounds++;
+        }
+        pos += used;
+    }
+    DX_T(t_end, dx_drain(P));
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); ok = 0; }           /* (input segments still on their way) */
+    dx_unregister_input(reg);
+    if (dx_trace())
+        fprintf(stderr, "decode_duplex: %llu rounds of %llu MiB, %.2f ms: waiting for input %.2f, for an output buffer %.2f, the round's copy %.2f, kernels (+ their waits) %.2f, the last copies %.2f; ok=%d\n",
+                (unsigned long long)rounds, (unsigned long long)(R >> 20), (dx_now() - t_start) * 1e3, t_in * 1e3, t_out * 1e3, t_cp * 1e3, t_k * 1e3, t_end * 1e3, ok);
+    if (!ok || P->err) return 0;                                                               /* nothing committed: the ordinary path takes the call */
+    rmem->off += pos;
+    wmem->len += out_total;
+    *result = huf_bufio_read_writer_flush(dec->bufio_writer);
+    return 1;
+}
+
 static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
 {
     const uint64_t length = dec->config->length;
@@ -2011,7 +2473,7 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
     membuf_t *wmem = zero_copy_enabled() ? own_memstream_writer(dec->config->writer) : NULL;
     if (!pieces) {
         huf_error_t fan = HUF_ERROR_SUCCESS;
-        if (decode_fanout(dec, rmem, wmem, flags, &fan)) return fan;
+        if (decode_fanout(dec, rmem, wmem, flags, &fan) || decode_duplex(dec, rmem, wmem, flags, &fan)) return fan;
     }
     size_t avail = 0;
     const char *in_ptr = NULL;              /* host bytes [0, avail) of the input */

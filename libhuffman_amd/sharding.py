@@ -31,7 +31,10 @@ def _all_to_all(out, inp, out_split, in_split, group, timeout: Optional[float]):
     try:
         work.wait(timeout=timedelta(seconds=timeout))          # (the backends raise when the time is up; they do not return False)
     except RuntimeError as e:                                  # torch.distributed.DistBackendError is a RuntimeError
-        raise TimeoutError("variable-size all-to-all did not complete in %.0f s: %s" % (timeout, e)) from e
+        text = str(e).lower()
+        if "timeout" in text or "timed out" in text:
+            raise TimeoutError("variable-size all-to-all did not complete in %.0f s: %s" % (timeout, e)) from e
+        raise                                                  # (an invalid split, a peer's abort, out of memory: as the backend says it)
 
 
 def shard_range(n_total: int, blocksize: int, rank: int, world: int) -> Tuple[int, int]:

@@ -219,7 +219,7 @@ def kernel_source_digest() -> str:
 
 
 def measured_traffic(workload: str, kernel: str, n: int, bs: int):
-    """HBM bytes per launch of `kernel` from the TCC counters (tools/gpu_traffic.sh: separate
+    """HBM bytes per launch of `kernel` from the TCC counters (tools/gpu_round_profile.sh: separate
     rocprofv3 --pmc passes of this same command, FETCH_SIZE doubled per the gfx950 correction).
     Null unless the committed table was collected for exactly these kernel sources."""
     try:

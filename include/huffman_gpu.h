@@ -128,9 +128,18 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
 int hufgpu_encode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t n, uint64_t blocksize, void *d_in,
                         void *d_out, uint64_t out_cap, void *h_out_pinned, uint64_t h_out_cap, uint64_t *out_len);
 
+/* The decode's twin of hufgpu_encode_small(): a raw stream of `avail` bytes in PINNED host memory (of which the reference's
+ * loop takes blocks while fewer than `length` bytes are consumed, src/decoder.c:218), decoded in order by one workgroup,
+ * output and outcome back in pinned host memory, one synchronisation.  d_in: avail bytes of device memory; d_out /
+ * out_cap: the device output buffer; h_out_pinned / h_out_cap: min(out_cap, 8 avail + 64) rounded up to 8, + 48 bytes.
+ * Returns what hufgpu_decode_stream() returns for the same stream; *raw_len bytes at h_out_pinned are the result. */
+int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t avail, uint64_t length, uint32_t flags,
+                        void *d_in, void *d_out, uint64_t out_cap, void *h_out_pinned, uint64_t h_out_cap,
+                        uint64_t *raw_len, uint64_t *consumed);
+
 /* Of the last enqueued hufgpu_decode() / hufgpu_decode_sub(): blocks that went through a slower decoder -
  * counters[0] = decoded again by the exact in-order-equivalent decoder (a damaged block, an unusual tree, a stale
- * sub-index), counters[1] = handed on by the one-pass decoder of index-only streams (starts that did not settle).
+ * sub-index), counters[1] = 0 (reserved: it counted the blocks round 4's one-pass decoder handed on).
  * Results never depend on these; they say what a slow decode was slow for.  Synchronises the stream. */
 int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters);
 

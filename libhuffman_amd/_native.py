@@ -67,7 +67,7 @@ hufgpu_block_count hufgpu_encode_bound hufgpu_histogram hufgpu_encode hufgpu_dec
 hufgpu_decode_result hufgpu_decode_stream hufgpu_fill hufgpu_malloc hufgpu_free
 hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_set_profiling
 hufgpu_get_profile hufgpu_sub_index_bytes hufgpu_encode_sub hufgpu_decode_sub
-hufgpu_decode_stream_complete hufgpu_block_index hufgpu_decode_counters hufgpu_calib_bandwidth hufgpu_encode_small huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_memwrap_out huf_gpu_decode_blocks huf_gpu_sessions huf_gpu_fanouts huf_gpu_copy_out""".split()
+hufgpu_decode_stream_complete hufgpu_block_index hufgpu_decode_counters hufgpu_calib_bandwidth hufgpu_encode_small hufgpu_decode_small huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_memwrap_out huf_gpu_decode_blocks huf_gpu_sessions huf_gpu_fanouts huf_gpu_copy_out""".split()
 
 
 def so_path() -> str:

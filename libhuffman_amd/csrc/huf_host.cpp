@@ -2475,6 +2475,27 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
         huf_error_t fan = HUF_ERROR_SUCCESS;
         if (decode_fanout(dec, rmem, wmem, flags, &fan) || decode_duplex(dec, rmem, wmem, flags, &fan)) return fan;
     }
+    /* a small call between two memory streams: one synchronisation instead of three (hufgpu_decode_small).  Anything but
+     * a clean decode - an error, a last block that wants bytes behind `length` - goes on below as if nothing had happened */
+    if (!pieces && rmem && wmem && length <= SMALL_CALL_BYTES && rmem->len - rmem->off >= length) {
+        const uint64_t out_cap = (uint64_t)length * 8 + 64;
+        const uint64_t h_need = ((out_cap + 7u) & ~7ull) + 64u;
+        if (grow_host(&g_stage.h_a, &g_stage.h_a_cap, (size_t)length) == HUF_ERROR_SUCCESS &&
+            grow_host(&g_stage.h_b, &g_stage.h_b_cap, (size_t)h_need) == HUF_ERROR_SUCCESS &&
+            grow_dev(&g_stage.d_a, &g_stage.d_a_cap, (size_t)length + 16) == HUF_ERROR_SUCCESS &&
+            grow_dev(&g_stage.d_b, &g_stage.d_b_cap, (size_t)out_cap) == HUF_ERROR_SUCCESS) {
+            memcpy(g_stage.h_a, (const char *)*rmem->buf + rmem->off, (size_t)length);
+            uint64_t raw = 0, used = 0;
+            const int rc = hufgpu_decode_small(g_ctx, g_stage.h_a, length, length, flags, g_stage.d_a, g_stage.d_b, out_cap,
+                                               g_stage.h_b, g_stage.h_b_cap, &raw, &used);
+            if (rc == HUF_ERROR_FATAL) return HUF_ERROR_FATAL;
+            if (rc == HUF_ERROR_SUCCESS) {
+                rmem->off += (size_t)(used < length ? used : length);
+                if (raw) TRY(memwrite(wmem, g_stage.h_b, (size_t)raw));
+                return huf_bufio_read_writer_flush(dec->bufio_writer);
+            }
+        }
+    }
     size_t avail = 0;
     const char *in_ptr = NULL;              /* host bytes [0, avail) of the input */
     const size_t start_off = rmem ? rmem->off : 0;

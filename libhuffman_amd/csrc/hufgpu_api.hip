@@ -60,7 +60,6 @@ struct hufgpu_ctx {
     uint32_t *d_fix_count;        /* decode_sub_kernel: blocks its sub-index could not verify */
     uint32_t *d_fix_blocks;
     uint32_t *d_fix_flag;
-    uint32_t *d_lean_blocks;      /* decode_lean_kernel: blocks it leaves to decode_fast_list_kernel (their count: d_fix_count[1]) */
 
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
@@ -247,8 +246,8 @@ static void free_decode_ws(hufgpu_ctx *c)
     (void)hipFree(c->d_dmeta);
     (void)hipFree(c->d_out_offsets);
     (void)hipFree(c->d_status);
-    (void)hipFree(c->d_fix_count); (void)hipFree(c->d_fix_blocks); (void)hipFree(c->d_fix_flag); (void)hipFree(c->d_lean_blocks);
-    c->d_fix_count = NULL; c->d_fix_blocks = NULL; c->d_fix_flag = NULL; c->d_lean_blocks = NULL;
+    (void)hipFree(c->d_fix_count); (void)hipFree(c->d_fix_blocks); (void)hipFree(c->d_fix_flag);
+    c->d_fix_count = NULL; c->d_fix_blocks = NULL; c->d_fix_flag = NULL;
     c->d_dmeta = NULL; c->d_out_offsets = NULL; c->d_status = NULL;
     c->dws_blocks = 0;
 }
@@ -343,7 +342,6 @@ static int ensure_decode_ws(hufgpu_ctx *c, uint64_t nblocks)
     HIP_OK(c, hipMalloc((void **)&c->d_fix_count, 2 * sizeof(uint32_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_fix_blocks, cap * sizeof(uint32_t)));
     HIP_OK(c, hipMalloc((void **)&c->d_fix_flag, cap * sizeof(uint32_t)));
-    HIP_OK(c, hipMalloc((void **)&c->d_lean_blocks, cap * sizeof(uint32_t)));
     HIP_OK(c, hipMemset(c->d_fix_count, 0, 2 * sizeof(uint32_t)));
     HIP_OK(c, hipMemset(c->d_fix_flag, 0, cap * sizeof(uint32_t)));
     int rc2 = alloc_two_level(c, &c->dec_lens, cap, true);
@@ -674,7 +672,7 @@ extern "C" int hufgpu_encode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, u
 }
 
 /* How many blocks of the last enqueued decode were handed on: counters[0] = to the exact decoder
- * (decode_fix_kernel), counters[1] = by decode_lean_kernel to round 3's decoder.  Synchronises. */
+ * (decode_fix_kernel), counters[1] = 0 (round 4's one-pass decoder, gone with round 5's clean-up).  Synchronises. */
 extern "C" int hufgpu_decode_counters(hufgpu_ctx_t *ctx, uint32_t *counters)
 {
     if (!ctx || !counters) return HUFE_ARGUMENT;
@@ -717,16 +715,6 @@ extern "C" int hufgpu_calib_bandwidth(hufgpu_ctx_t *ctx, int kind, int variant, 
     else per = calib_launch<2>(variant, (const uint8_t *)d_a, (uint8_t *)d_b, bytes, flag + 6, s);
     HIP_OK(ctx, hipGetLastError());
     return per ? HUFE_OK : HUFE_ARGUMENT;
-}
-
-/* (tooling) the first `cap` block numbers decode_lean_kernel handed on in the last decode */
-extern "C" int hufgpu_debug_lean_blocks(hufgpu_ctx_t *ctx, uint32_t *out, uint32_t cap)
-{
-    if (!ctx || !out || !ctx->d_lean_blocks) return HUFE_ARGUMENT;
-    HIP_OK(ctx, hipSetDevice(ctx->device));
-    HIP_OK(ctx, hipDeviceSynchronize());
-    HIP_OK(ctx, hipMemcpy(out, ctx->d_lean_blocks, cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return HUFE_OK;
 }
 
 static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_len,
@@ -780,19 +768,7 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
             fix.count = ctx->d_fix_count;
             fix.blocks = ctx->d_fix_blocks;
             fix.flag = ctx->d_fix_flag;
-            /* HUF_GPU_LEAN_DECODE=1: the one-pass decoder of kernels/decode_lean.hpp first (round 4's experiment: every
-             * symbol decoded once after a speculative run-in; bit-exact, but 2.1 ms per GiB where this path takes 1.6 -
-             * DESIGN.md 3.4 says why - so it is not the default) */
-            static const bool lean = getenv("HUF_GPU_LEAN_DECODE") && atoi(getenv("HUF_GPU_LEAN_DECODE")) != 0;
             const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
-            if (lean) {
-                /* every symbol once (kernels/decode_lean.hpp); what that cannot settle goes through round 3's decoder */
-                LeanTodo todo;
-                todo.count = ctx->d_fix_count + 1;
-                todo.blocks = ctx->d_lean_blocks;
-                decode_lean_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, todo);
-                decode_fast_list_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix, todo.count, todo.blocks);
-            } else
             decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
             decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
         }
@@ -855,6 +831,39 @@ static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint
     *good_used = ctx->h_result[4];
     *good_raw = ctx->h_result[5];
     return (int)ctx->h_result[0];
+}
+
+/* One small decode with ONE synchronisation (include/huffman_gpu.h), hufgpu_encode_small's twin: the raw stream from pinned
+ * host memory, the in-order chain (decode_chain_kernel: the block loop of src/decoder.c:218-276 as it stands, one
+ * workgroup - what hufgpu_decode_stream runs for streams of less than 64 KiB anyway), the output and the kernel's six
+ * result words back into pinned host memory behind one another.  A call through the general entry points waits three
+ * times (stream up, the result words, the output back): 62-140 microseconds where the kernel takes twenty. */
+extern "C" int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t avail, uint64_t length, uint32_t flags,
+                                   void *d_in, void *d_out, uint64_t out_cap, void *h_out_pinned, uint64_t h_out_cap,
+                                   uint64_t *raw_len, uint64_t *consumed)
+{
+    if (!ctx || !h_in_pinned || !d_in || !d_out || !h_out_pinned || !raw_len || !consumed || avail == 0) return HUFE_ARGUMENT;
+    const uint64_t copy = out_cap < avail * 8u + 64u ? out_cap : avail * 8u + 64u;          /* (a symbol takes a bit at least) */
+    const uint64_t res_at = (copy + 7u) & ~7ull;
+    if (h_out_cap < res_at + 6u * sizeof(uint64_t)) return HUFE_ARGUMENT;
+    *raw_len = *consumed = 0;
+    if (length == 0) return HUFE_OK;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
+    HIP_OK(ctx, hipMemcpyAsync(d_in, h_in_pinned, avail, hipMemcpyHostToDevice, s));
+    decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_in, avail, length, max_tree, (uint8_t *)d_out, out_cap, ctx->d_result, NULL, 0);
+    HIP_OK(ctx, hipGetLastError());
+    HIP_OK(ctx, hipMemcpyAsync(h_out_pinned, d_out, copy, hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipMemcpyAsync((char *)h_out_pinned + res_at, ctx->d_result, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(ctx, hipStreamSynchronize(s));
+    const uint64_t *r = (const uint64_t *)((const char *)h_out_pinned + res_at);
+    *raw_len = r[1];
+    *consumed = r[2];
+    ctx->complete_used = r[4];
+    ctx->complete_raw = r[5];
+    if (r[1] > copy) return HUFE_FATAL;                                                       /* (cannot be: more symbols than bits) */
+    return (int)r[0];
 }
 
 /* Leading blocks of HUF_BIG_BLOCK symbols and more (blocksize = 0 makes the whole input ONE block,
@@ -1307,18 +1316,6 @@ extern "C" int hufgpu_synchronize(hufgpu_ctx_t *ctx)
 }
 
 #ifdef DEC_PHASE_PROF
-/* diagnostic builds only: why decode_lean_kernel handed blocks on (kernels/decode_lean.hpp, LEAN_FAIL) */
-extern "C" int hufgpu_debug_lean_fail(hufgpu_ctx_t *ctx, unsigned long long *out16, int reset)
-{
-    if (!ctx || !out16) return HUFE_ARGUMENT;
-    HIP_OK(ctx, hipDeviceSynchronize());
-    HIP_OK(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(hufgpu::g_lean_fail), (reset & 2 ? 80 : 16) * sizeof(unsigned long long)));
-    if (reset & 1) {
-        unsigned long long z[80] = {0};
-        HIP_OK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(hufgpu::g_lean_fail), z, sizeof(z)));
-    }
-    return HUFE_OK;
-}
 /* diagnostic builds only: cycle sums of the decode phases (thread 0 of every workgroup) */
 extern "C" int hufgpu_debug_phase_cycles(hufgpu_ctx_t *ctx, unsigned long long *out16, int reset)
 {

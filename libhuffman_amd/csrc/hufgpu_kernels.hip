@@ -31,7 +31,6 @@
 #include "kernels/decode.hpp"
 #include "kernels/decode_sub.hpp"
 #include "kernels/decode_fast.hpp"
-#include "kernels/decode_lean.hpp"
 #include "kernels/spec_index.hpp"
 #include "kernels/discover.hpp"
 #include "kernels/fill.hpp"

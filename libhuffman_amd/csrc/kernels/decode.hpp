@@ -67,7 +67,7 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
     __shared__ uint64_t s_part[SCAN_GROUP / 64];
     __shared__ unsigned long long s_bad;
     if (threadIdx.x == 0) s_bad = ~0ull;
-    if (fix_count && blockIdx.x == 0 && threadIdx.x == 0) { fix_count[0] = 0; fix_count[1] = 0; }   /* the work lists of decode_sub / decode_lean start empty */
+    if (fix_count && blockIdx.x == 0 && threadIdx.x == 0) { fix_count[0] = 0; fix_count[1] = 0; }   /* the work list of decode_sub / decode_fast starts empty */
     const uint64_t b = (uint64_t)blockIdx.x * SCAN_GROUP + threadIdx.x;
     HufDecodeMeta m;
     m.block_len = 0;
@@ -157,7 +157,6 @@ __global__ __launch_bounds__(SCAN_GROUP) void decode_prepare_kernel(const uint8_
 
 #ifdef DEC_PHASE_PROF
 __device__ unsigned long long g_dec_prof[16];
-__device__ unsigned long long g_lean_fail[16 + 64];     /* decode_lean_kernel: blocks handed on, by reason */
 #define DPROF_T() (__builtin_readcyclecounter())
 #define DPROF_ADD(slot, t0) do { if (threadIdx.x == 0) atomicAdd(&g_dec_prof[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
 #else
@@ -859,7 +858,6 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
             for (int h = (N >> 8) - 1; h >= 1; h--) s_min[h] = (uint16_t)dmin<uint32_t>(s_min[2 * h], s_min[2 * h + 1]);
         }
         __syncthreads();
-#ifndef DTAB_ABLATE_SEARCH     /* (diagnostic builds: instruction counts of the table build's parts) */
         for (int j = tid; j < eff; j += THREADS) {
             if (sh.ent[j] == -1) continue;
             const int l = j + 1;
@@ -879,7 +877,6 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
             if ((int)p < eff && sh.ent[p] != -1) links = (links & 0xffffu) | (p << 16);
             sh.lr[j] = links;
         }
-#endif
     }
     __syncthreads();
     /* tree_len == 0 or a tree that starts with -1 is a NULL root: the reference crashes,
@@ -946,14 +943,9 @@ __device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int
         }
 #pragma unroll
         for (int k = 0; k < PERL; k++) wlr[k] = wdone[k] ? DEC_LEAF_LR : sh.lr[wnode[k]];
-#ifndef DTAB_ABLATE_WALK
 #pragma unroll
         for (int b = HALF; b < DEC_LUT_BITS; b++)
-#endif
         {
-#ifdef DTAB_ABLATE_WALK
-            const int b = HALF;
-#endif
 #pragma unroll
             for (int k = 0; k < PERL; k++) {
                 const int idx = tid + k * THREADS;
@@ -1059,21 +1051,12 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
                 sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
         }
         __syncthreads();
-#if defined(DEC_DUP) && DEC_DUP == 1     /* cost of a phase = time with the phase done twice - time */
-        for (int i = tid; i < DEC_SUB_WORDS * COLS; i += THREADS)
-            sh.pay[pay_slot<COLS>((uint32_t)i)] = load_be32(pay, byte0 + 4ull * i, pay_bytes);
-        __syncthreads();
-#endif
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
         const uint32_t first_start = (uint32_t)(true_start - seg0);
         DPROF_ADD(2, pt); pt = DPROF_T();
 
         LaneTrack tr;
         dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
-#if defined(DEC_DUP) && DEC_DUP == 2
-        __syncthreads();
-        dec_scan<THREADS, false>(sh, tr, tid == 0 ? first_start : sub_lo, sub_lo, pay_rel);
-#endif
         if ((tid & 63) == 63) sh.wend[tid >> 6] = tr.end;
         __syncthreads();
         DPROF_ADD(3, pt); pt = DPROF_T();
@@ -1117,9 +1100,6 @@ __device__ int decode_block(DecShared<THREADS> &sh, const uint8_t *tree, int tre
         DPROF_ADD(5, pt); pt = DPROF_T();
         if (STORE) {
             if (quota) {
-#if defined(DEC_DUP) && DEC_DUP == 3
-                (void)dec_write<THREADS, true>(sh, tr.start, pay_rel, quota, gout + produced + ex);
-#endif
                 const uint32_t qe = dec_write<THREADS, true>(sh, tr.start, pay_rel, quota, gout + produced + ex);
                 if (ex + quota == take && remaining <= good) sh.qend = qe;   /* block's last symbol */
             }

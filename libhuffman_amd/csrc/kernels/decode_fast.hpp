@@ -210,7 +210,6 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
     const uint32_t hiQ = hi - 1u + qbase;
     uint32_t c = 0;
     DFAST_DBGW(8, 1);
-#ifndef DFAST_CHECKED_SCAN
     if (MODE == DFAST_SINGLES) {
         /* the same with the table of single codewords (blocks whose codes are too long for pairs, small blocks): two
          * look-ups, two codewords and 17 vector instructions per window */
@@ -295,7 +294,6 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
         *cnt = c;
         return;
     }
-#endif
     for (;;) {
         const bool act = Q < hiQ;
         if (!__any(act)) break;
@@ -446,11 +444,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
             acc = __builtin_amdgcn_alignbit(e2, acc, 8);
             Q += l1 + ((e2 >> 8) & 31u);
         }
-#ifdef DFAST_ABLATE_STORE       /* (timing experiment: what the scattered 32-bit stores of the write pass cost) */
-        if (acc == 0x12345678u) gw[k] = acc;
-#else
         gw[k] = acc;
-#endif
     }
     uint32_t p1 = Q + 1u - qbase;
     if (__builtin_expect(__ballot((special & 0xC000u) != 0u) != 0ull, 0)) {
@@ -489,9 +483,6 @@ __device__ __forceinline__ void dfast_stage(uint32_t *stage, const uint8_t *pay,
             struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
             const uint64_t byte0 = seg0 >> 3;
             constexpr uint32_t STEPS = (L::STAGE_WORDS + 4u * THREADS - 1u) / (4u * THREADS);
-#ifdef DFAST_ABLATE_STAGE
-            if (produced != 0) { } else
-#endif
             if (byte0 + 4ull * (4ull * THREADS * STEPS) + 24ull <= readable) {
                 const uintptr_t a = (uintptr_t)uni64((uint64_t)(uintptr_t)(pay + byte0));
                 const uint32_t m = (uint32_t)(a & 3u);
@@ -547,7 +538,6 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         const uint32_t any = (t0 | t1 | t2 | t3) & 0x80008000u;            /* bit 15: long (bad entries have bit 14 only) */
         static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && DEC_E_LONG == 0xC000u && DEC_E_BAD == 0x4000u, "eight entries per thread");
         longs = __syncthreads_or(any != 0u) != 0;
-#ifndef DFAST_CHECKED_SCAN
         /* the table of pairs pays for itself (its build, the longer look at a scan's last window) when codewords are short
          * enough to come in pairs - one of six bits or less: it fits the 12 bits twice - and the block is long enough
          * (1 GiB: zipf255 1.63 -> 1.54 ms, log text 1.53 -> 1.47; uniform bytes, without a pair, 1.03 -> 1.08 with it, zipf255 in
@@ -557,7 +547,6 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
                                               dmin<uint32_t>(dmin<uint32_t>(t2 & 0xffffu, t2 >> 16), dmin<uint32_t>(t3 & 0xffffu, t3 >> 16)));
             pairs = __syncthreads_or(m < 0x0700u) != 0;                     /* a leaf is (bits << 8) | byte */
         }
-#endif
     }
     const uint32_t pair_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)L::pairs(sh);
     if (pairs) dfast_pair_table<THREADS>(sh);                          /* (read behind the stage's first barrier) */
@@ -572,7 +561,6 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
          * 64 KiB: 3.2 segments of 288-bit shares -> 4 of 232).  The raw-stream probe does not know the end: 288 as before. */
         uint32_t sb = DFAST_SUB_BITS;
         const bool hinted = uni32((end_bits && trust && hint_bytes * 8ull > seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
-#ifndef DFAST_FIXED_SHARES
         if (!end_bits || hinted) {
             const uint64_t rem = (hinted ? hint_bytes * 8ull : pay_bits) - seg0;
             const uint64_t nseg = (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
@@ -580,7 +568,6 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
             sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), DFAST_SUB_BITS);
         }
         sb = uni32(sb);
-#endif
         const uint32_t need_words = uni32(dmin<uint32_t>(((uint32_t)THREADS * sb + 31u) / 32u + DFAST_SLACK_WORDS, L::STAGE_WORDS));
         __syncthreads();                                               /* the previous segment's readers are done */
         unsigned long long pt = DPROF_T();
@@ -688,17 +675,9 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         }
         DPROF_ADD(4, pt); pt = DPROF_T();
         bool lane_ok = true;
-#ifdef DFAST_ABLATE_WRITE          /* (timing experiments: no write pass; the output is wrong) */
-        if (false) {
-#else
         if (quota) {
-#endif
-#ifndef DFAST_EXACT_TAILS
             /* (all of the lane's symbols, and the whole last word still inside this block's output) */
             const bool whole = quota == cnt && produced + ex + ((quota + 3u) & ~3u) <= block_len;
-#else
-            const bool whole = false;
-#endif
             uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok, whole);
             if (whole) qe = end;
 #ifdef DFAST_DEBUG
@@ -720,478 +699,21 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     return ok;
 }
 
-/* ======================================================================================
- * Round 4, TWO shares a lane.  Taken off a CU workgroup by workgroup the kernel's time is a + b / n with b / 4 about half
- * of it (profiles/r04/dfast_two_chains.txt): what a workgroup does is a chain of dependent LDS reads - a window, a look-up,
- * a look-up, the next window - and four workgroups a CU, the most the register file holds, do not fill the gaps.  A lane
- * therefore owns two neighbouring shares of half the size (1 024 shares a segment instead of 512) and walks both in the
- * SAME loop: two independent chains whose reads are in flight together.  The work is the same but for a second look at
- * a scan's last window; the starts settle as 1 024 lanes' would (a share's start is its left neighbour's end: the lane's
- * own first share for its second).  Blocks with `long` codes walk their two shares one after the other.
- *
- * MEASURED, NOT THE DEFAULT (DFAST_CHAINS = 1).  Bit-exact on the whole GPU suite, and slower: shares of half the size
- * are too short for the speculation - 116 bits are 18 codewords of zipf255, a track needs 13.5 on average to fall into step, so
- * half of all waves scan a third time (0.05 of 8 waves a segment before, 4.4 now) - and uniform bytes, whose shares never
- * move, take exactly as long as with one chain: the chains of LDS reads were not what the workgroups wait for.
- * ==================================================================================== */
-template <int THREADS, int MODE>
-__device__ __forceinline__ void dfast_scan2(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr, uint32_t pair_addr,
-                                            const uint32_t (&start)[2], const uint32_t (&hi)[2], uint32_t lim, uint32_t (&end)[2], uint32_t (&cnt)[2])
-{
-    if (MODE == DFAST_LONGS) {
-        dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, start[0], hi[0], lim, &end[0], &cnt[0]);
-        dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, start[1], hi[1], lim, &end[1], &cnt[1]);
-        return;
-    }
-    DFAST_DBGW(8, 1);
-    uint32_t Q0[2], hiQ[2], Q[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        Q0[j] = start[j] - 1u + qbase;
-        hiQ[j] = hi[j] - 1u + qbase;
-        Q[j] = Q0[j];
-    }
-    if (MODE == DFAST_PAIRS) {
-        /* (Stage by stage, not chain by chain, with the scheduler told to keep the stages apart: hipcc 7.2 otherwise emits one
-         *  chain behind the other, each read waited for at once.  A share that is done walks on with its wave - what it reads
-         *  is ignored -, so that nothing in the loop is under a branch.) */
-        uint32_t S[2] = {0u, 0u}, Sg[2] = {~0u, ~0u};                   /* Sg: the entries met before the last window that began in the share (~0: none did) */
-        for (;;) {
-            const bool act[2] = {Q[0] < hiQ[0], Q[1] < hiQ[1]};
-            if (!__any(act[0] || act[1])) break;
-            DFAST_DBGW(9, 1);
-            uint32_t w0[2], w1[2], d1[2], e1[2], e2[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q[j] >> 3) & ~3u);
-                w0[j] = wp[0];
-                w1[j] = wp[1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                d1[j] = __builtin_amdgcn_alignbit(w0[j], w1[j], ~Q[j]);
-                e1[j] = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d1[j] >> 19) & 0x1ffeu));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t d2 = d1[j] << (e1[j] & 31u);
-                e2[j] = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d2 >> 19) & 0x1ffeu));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                Sg[j] = act[j] ? S[j] : Sg[j];
-                S[j] += e1[j] + e2[j];
-                Q[j] = Q0[j] + (S[j] & 0xfffu);
-            }
-        }
-        if (__ballot(Sg[0] != ~0u || Sg[1] != ~0u)) {
-            uint32_t Qg[2], w0[2], w1[2], d1[2], i1[2], e1[2], a1[2], i2[2], e2[2], a2[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                Qg[j] = Q0[j] + (Sg[j] & 0xfffu);
-                dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg[j] >> 3) & ~3u);
-                w0[j] = wp[0];
-                w1[j] = wp[1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                d1[j] = __builtin_amdgcn_alignbit(w0[j], w1[j], ~Qg[j]);
-                i1[j] = (d1[j] >> 19) & 0x1ffeu;
-                e1[j] = *(dfast_lds_halves)(uintptr_t)(pair_addr + i1[j]);
-                a1[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + i1[j]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                i2[j] = ((d1[j] << (e1[j] & 31u)) >> 19) & 0x1ffeu;
-                e2[j] = *(dfast_lds_halves)(uintptr_t)(pair_addr + i2[j]);
-                a2[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + i2[j]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t l1 = (a1[j] >> 8) & 31u, l2 = (a2[j] >> 8) & 31u;
-                const uint32_t b1 = Qg[j] + l1, b2 = Qg[j] + (e1[j] & 31u), b3 = b2 + l2, b4 = b2 + (e2[j] & 31u);
-                const bool in1 = b1 < hiQ[j], in2 = b2 < hiQ[j], in3 = b3 < hiQ[j];
-                const uint32_t endQ = !in1 ? b1 : !in2 ? b2 : !in3 ? b3 : b4;
-                const uint32_t cn = (Sg[j] >> 12) + 1u + ((in1 && (e1[j] & 0x2000u)) ? 1u : 0u) + (in2 ? 1u : 0u) + ((in3 && (e2[j] & 0x2000u)) ? 1u : 0u);
-                const bool any = Sg[j] != ~0u;
-                end[j] = (any ? endQ : Q0[j]) + 1u - qbase;
-                cnt[j] = any ? cn : 0u;
-            }
-        } else {
-            end[0] = start[0]; end[1] = start[1];
-            cnt[0] = 0; cnt[1] = 0;
-        }
-        return;
-    }
-    /* DFAST_SINGLES */
-    uint32_t Qg[2] = {Q[0], Q[1]}, ng[2] = {0u, 0u};
-    for (;;) {
-        const bool act[2] = {Q[0] < hiQ[0], Q[1] < hiQ[1]};
-        if (!__any(act[0] || act[1])) break;
-        DFAST_DBGW(9, 1);
-        uint32_t w0[2], w1[2], d1[2], e1[2], e2[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            Qg[j] = act[j] ? Q[j] : Qg[j];
-            ng[j] += act[j] ? 1u : 0u;
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q[j] >> 3) & ~3u);
-            w0[j] = wp[0];
-            w1[j] = wp[1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            d1[j] = __builtin_amdgcn_alignbit(w0[j], w1[j], ~Q[j]);
-            e1[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1[j] >> 19) & 0x1ffeu));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t d2 = d1[j] << ((e1[j] >> 8) & 31u);
-            e2[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) Q[j] += ((e1[j] >> 8) & 31u) + ((e2[j] >> 8) & 31u);
-    }
-    {
-        uint32_t w0[2], w1[2], d1[2], e1[2], e2[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg[j] >> 3) & ~3u);
-            w0[j] = wp[0];
-            w1[j] = wp[1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            d1[j] = __builtin_amdgcn_alignbit(w0[j], w1[j], ~Qg[j]);
-            e1[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1[j] >> 19) & 0x1ffeu));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) e2[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + (((d1[j] << ((e1[j] >> 8) & 31u)) >> 19) & 0x1ffeu));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t l1 = (e1[j] >> 8) & 31u, l2 = (e2[j] >> 8) & 31u;
-            const uint32_t t1 = Qg[j] + l1;
-            const bool take2 = t1 < hiQ[j] && l2 != 0u;
-            const bool any = ng[j] != 0u;
-            cnt[j] = any ? 2u * (ng[j] - 1u) + 1u + (take2 ? 1u : 0u) : 0u;
-            end[j] = (any ? t1 + (take2 ? l2 : 0u) : Q0[j]) + 1u - qbase;
-        }
-    }
-}
-
-/* Write pass of a lane's two shares: quota[j] symbols from start[j] to g[j][0 .. quota[j]), the words both chains have in the same
- * loop, what one has more than the other behind it.  p1[j] = the position behind the last symbol (not for a chain whose last
- * word went out whole: the caller has its end); *ok_out as dfast_write. */
-template <int THREADS>
-__device__ __forceinline__ void dfast_write2(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
-                                             const uint32_t (&start)[2], const uint32_t (&quota)[2], uint32_t lim, uint8_t *const (&g)[2],
-                                             const bool (&whole)[2], uint32_t (&p1)[2], bool *ok_out)
-{
-    typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
-    bool ok = true;
-    uint32_t words[2], Q[2], special[2] = {0u, 0u};
-    unaligned_u32 *gw[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        words[j] = whole[j] ? (quota[j] + 3u) >> 2 : quota[j] >> 2;
-        Q[j] = start[j] - 1u + qbase;
-        gw[j] = reinterpret_cast<unaligned_u32 *>(g[j]);
-    }
-    const uint32_t both = dmin<uint32_t>(words[0], words[1]);
-    for (uint32_t k = 0; k < both; k++) {
-        uint32_t acc[2] = {0u, 0u};
-#pragma unroll
-        for (int w = 0; w < 2; w++) {
-            uint32_t w0[2], w1[2], d1[2], e1[2], e2[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q[j] >> 3) & ~3u);
-                w0[j] = wp[0];
-                w1[j] = wp[1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                d1[j] = __builtin_amdgcn_alignbit(w0[j], w1[j], ~Q[j]);
-                e1[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1[j] >> 19) & 0x1ffeu));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t d2 = d1[j] << ((e1[j] >> 8) & 31u);
-                e2[j] = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                special[j] |= e1[j] | e2[j];
-                acc[j] = __builtin_amdgcn_alignbit(e1[j], acc[j], 8);
-                acc[j] = __builtin_amdgcn_alignbit(e2[j], acc[j], 8);
-                Q[j] += ((e1[j] >> 8) & 31u) + ((e2[j] >> 8) & 31u);
-            }
-        }
-        gw[0][k] = acc[0];
-        gw[1][k] = acc[1];
-    }
-    /* (what one chain has more than the other: written out twice - a loop over j with a loop inside is not unrolled, and its
-     *  arrays would live in scratch memory) */
-#define DFAST_WRITE_TAIL(j)                                                                                              \
-    for (uint32_t k = both; k < words[j]; k++) {                                                                         \
-        uint32_t acc = 0;                                                                                                \
-        _Pragma("unroll") for (int w = 0; w < 2; w++) {                                                                  \
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q[j] >> 3) & ~3u);                                         \
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q[j]);                                           \
-            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));                        \
-            const uint32_t l1 = (e1 >> 8) & 31u;                                                                         \
-            const uint32_t d2 = d1 << l1;                                                                                \
-            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));                        \
-            special[j] |= e1 | e2;                                                                                       \
-            acc = __builtin_amdgcn_alignbit(e1, acc, 8);                                                                 \
-            acc = __builtin_amdgcn_alignbit(e2, acc, 8);                                                                 \
-            Q[j] += l1 + ((e2 >> 8) & 31u);                                                                              \
-        }                                                                                                                \
-        gw[j][k] = acc;                                                                                                  \
-    }                                                                                                                    \
-    p1[j] = Q[j] + 1u - qbase;
-    DFAST_WRITE_TAIL(0)
-    DFAST_WRITE_TAIL(1)
-#undef DFAST_WRITE_TAIL
-    LinReader rd;
-    rd.st = stage;
-#define DFAST_WRITE_RARE(j)                                                                                              \
-    if (__builtin_expect(__ballot((special[j] & 0xC000u) != 0u) != 0ull, 0)) {                                           \
-        if (special[j] & 0xC000u) {                  /* a long code (or worse) among them: the words again, step by step */ \
-            rd.load(start[j]);                                                                                           \
-            for (uint32_t c = 0; c < 4u * words[j]; c++) {                                                               \
-                g[j][c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);                                                 \
-                if (rd.avail <= 32) rd.refill();                                                                         \
-            }                                                                                                            \
-            p1[j] = rd.pos();                                                                                            \
-        }                                                                                                                \
-    }                                                                                                                    \
-    if (__ballot(!whole[j] && (quota[j] & 3u) != 0u)) {                                                                  \
-        if (!whole[j] && (quota[j] & 3u) != 0u) {                                                                        \
-            rd.load(p1[j]);                                                                                              \
-            for (uint32_t c = 4u * words[j]; c < quota[j]; c++) {                                                        \
-                g[j][c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);                                                 \
-                if (rd.avail <= 32) rd.refill();                                                                         \
-            }                                                                                                            \
-            p1[j] = rd.pos();                                                                                            \
-        }                                                                                                                \
-    }
-    DFAST_WRITE_RARE(0)
-    DFAST_WRITE_RARE(1)
-#undef DFAST_WRITE_RARE
-    *ok_out = ok;
-}
-
-template <int THREADS>
-__device__ __forceinline__ bool decode_payload_fast2(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
-                                    uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
-{
-    typedef DfastLds<THREADS> L;
-    constexpr int WAVES = THREADS / 64;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    uint32_t *stage = sh.pay;
-    const uint32_t qbase = 8u * (uint32_t)(uintptr_t)(dfast_lds_words)stage;
-    const uint32_t lut_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)sh.lut;
-    const uint64_t pay_bits = pay_bytes * 8ull;
-    const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;
-    bool longs, pairs = false;
-    {
-        const uint32_t *t = reinterpret_cast<const uint32_t *>(sh.lut) + 4 * tid;
-        const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        const uint32_t any = (t0 | t1 | t2 | t3) & 0x80008000u;
-        longs = __syncthreads_or(any != 0u) != 0;
-#ifndef DFAST_CHECKED_SCAN
-        if (!longs && block_len >= DFAST_PAIRS_FROM) {
-            const uint32_t m = dmin<uint32_t>(dmin<uint32_t>(dmin<uint32_t>(t0 & 0xffffu, t0 >> 16), dmin<uint32_t>(t1 & 0xffffu, t1 >> 16)),
-                                              dmin<uint32_t>(dmin<uint32_t>(t2 & 0xffffu, t2 >> 16), dmin<uint32_t>(t3 & 0xffffu, t3 >> 16)));
-            pairs = __syncthreads_or(m < 0x0700u) != 0;
-        }
-#endif
-    }
-    const uint32_t pair_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)L::pairs(sh);
-    if (pairs) dfast_pair_table<THREADS>(sh);
-    uint64_t true_start = 0, produced = 0;
-    bool ok = true;
-    bool trust = true;
-    while (produced < block_len) {
-        if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }
-        const uint64_t seg0 = true_start & ~31ull;
-        uint32_t sb = DFAST_SUB_BITS;
-        const bool hinted = uni32((end_bits && trust && hint_bytes * 8ull > seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
-        if (!end_bits || hinted) {
-            const uint64_t rem = (hinted ? hint_bytes * 8ull : pay_bits) - seg0;
-            const uint64_t nseg = (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
-            const uint64_t even = (rem + nseg * THREADS - 1u) / (nseg * THREADS);
-            sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), DFAST_SUB_BITS);
-        }
-        const uint32_t sbh = uni32((sb + 1u) >> 1);                        /* a share: half of what a lane holds */
-        sb = 2u * sbh;
-        const uint32_t need_words = uni32(dmin<uint32_t>(((uint32_t)THREADS * sb + 31u) / 32u + DFAST_SLACK_WORDS, L::STAGE_WORDS));
-        __syncthreads();
-        unsigned long long pt = DPROF_T();
-        dfast_stage<THREADS>(stage, pay, seg0, readable, need_words, produced);
-        __syncthreads();
-        DPROF_ADD(1, pt); pt = DPROF_T();
-        const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);
-        const uint32_t first = (uint32_t)(true_start - seg0);
-        uint32_t hi[2], start[2], end[2], cnt[2] = {0u, 0u};
-        bool dead[2];
-        hi[0] = (2u * (uint32_t)tid + 1u) * sbh;
-        hi[1] = hi[0] + sbh;
-        start[0] = tid == 0 ? first : hi[0] - sbh;
-        start[1] = hi[0];
-        dead[0] = hi[0] - sbh >= pay_rel;
-        dead[1] = hi[0] >= pay_rel;
-        const uint64_t remaining = block_len - produced;
-        bool guessed = false;
-        if (hinted) {
-            const uint32_t bound = (uint32_t)dmin<uint64_t>(hint_bytes * 8ull - seg0, 0xfffffff0ull);
-            if (hi[0] - sbh >= bound) dead[0] = true;
-            if (hi[0] >= bound) dead[1] = true;
-            guessed = (uint32_t)(2 * THREADS - 1) * sbh >= bound;
-        } else if (end_bits && trust && produced != 0) {
-            const float est = (float)remaining * ((float)true_start / (float)produced);
-            const float lim_f = (float)first + est * 1.0625f + 1024.0f;
-            const uint32_t bound = lim_f < 4.0e9f ? (uint32_t)lim_f : 0xffffffffu;
-            if (hi[0] - sbh >= bound) dead[0] = true;
-            if (hi[0] >= bound) dead[1] = true;
-            guessed = (uint32_t)(2 * THREADS - 1) * sbh >= bound;
-        }
-        end[0] = hi[0]; end[1] = hi[1];
-        if (__ballot(!dead[0] || !dead[1])) {
-            const uint32_t st[2] = {dead[0] ? hi[0] : start[0], dead[1] ? hi[1] : start[1]};
-            if (longs) dfast_scan2<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, end, cnt);
-            else if (pairs) dfast_scan2<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, end, cnt);
-            else dfast_scan2<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, end, cnt);
-#pragma unroll
-            for (int j = 0; j < 2; j++) if (dead[j]) { end[j] = hi[j]; cnt[j] = 0; }
-        }
-        if (end_bits && trust && !hinted) {
-            uint32_t spec_total;
-            const uint32_t exs = block_excl_scan_u32<THREADS>(cnt[0] + cnt[1], sh.part, spec_total);
-            if (!dead[0] && (uint64_t)exs >= remaining + 128u + ((uint32_t)tid >> 2)) { dead[0] = true; end[0] = hi[0]; cnt[0] = 0; }
-            if (!dead[1] && (uint64_t)exs + cnt[0] >= remaining + 128u + ((uint32_t)tid >> 2)) { dead[1] = true; end[1] = hi[1]; cnt[1] = 0; }
-            guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
-        }
-        if (lane == 63) sh.wend[wave] = end[1];
-        __syncthreads();
-        DPROF_ADD(2, pt); pt = DPROF_T();
-        int rounds = 0;
-        for (;;) {
-            /* a share's start is its left neighbour's end: the lane's own first share for its second, the lane below's second for its first */
-            uint32_t ns0 = wave_up1_u32(end[1]);
-            if (lane == 0) ns0 = (tid == 0) ? first : sh.wend[wave - 1];
-            const uint32_t ns1 = end[0];
-            const bool ch[2] = {ns0 != start[0] && !dead[0], ns1 != start[1] && !dead[1]};
-            const int changed = (ch[0] || ch[1]) ? 1 : 0;
-            __syncthreads();                                           /* everyone has read sh.wend */
-            if (__ballot(changed != 0)) {
-                DFAST_DBGW(rounds == 0 ? 6 : rounds == 1 ? 7 : 14, 1);
-                if (ch[0]) start[0] = ns0;
-                if (ch[1]) start[1] = ns1;
-                const uint32_t st[2] = {ch[0] ? start[0] : hi[0], ch[1] ? start[1] : hi[1]};
-                uint32_t e2[2] = {end[0], end[1]}, c2[2] = {cnt[0], cnt[1]};
-                if (longs) dfast_scan2<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, e2, c2);
-                else if (pairs) dfast_scan2<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, e2, c2);
-                else dfast_scan2<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, st, hi, lim, e2, c2);
-#pragma unroll
-                for (int j = 0; j < 2; j++) if (ch[j]) { end[j] = e2[j]; cnt[j] = c2[j]; }
-            }
-            /* ---- runs of one byte value: the lanes' first shares among themselves, then their second ones (a share in between that
-             *      does not hold the run is found out by its neighbour's end, like any wrong start) ---- */
-            int jumped = 0;
-            if (rounds >= DFAST_JUMP_FROM_ROUND && __ballot(changed != 0)) {
-                DFAST_DBGW(15, 1);
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const uint4 r = dfast_run_jump(qbase, lut_addr, ch[j], dead[j], hi[j], sbh, pay_rel, start[j], end[j], cnt[j]);
-                    start[j] = r.x; end[j] = r.y; cnt[j] = r.z; jumped |= (int)r.w;
-                }
-            }
-            if (lane == 63) sh.wend[wave] = end[1];
-            if (!__syncthreads_or(changed | jumped)) break;
-            DFAST_DBG(10, 1);
-            if (++rounds > DFAST_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }
-        }
-        if (!ok) break;
-        DPROF_ADD(3, pt); pt = DPROF_T();
-        uint32_t seg_total;
-        const uint32_t ex = block_excl_scan_u32<THREADS>(cnt[0] + cnt[1], sh.part, seg_total);
-        seg_total = uni32(seg_total);
-        if (guessed) DFAST_DBG(12, 1);
-        if (guessed && (uint64_t)seg_total < remaining) {
-            DFAST_DBG(13, 1);
-            trust = false;
-            continue;
-        }
-        trust = true;
-        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
-        uint32_t quota[2] = {0u, 0u};
-        if (ex < take) quota[0] = dmin<uint32_t>(take - ex, cnt[0]);
-        if (ex + cnt[0] < take) quota[1] = dmin<uint32_t>(take - ex - cnt[0], cnt[1]);
-        DPROF_ADD(4, pt); pt = DPROF_T();
-        bool lane_ok = true;
-        if (quota[0] | quota[1]) {
-            uint8_t *const g[2] = {gout + produced + ex, gout + produced + ex + cnt[0]};
-            const bool whole[2] = {quota[0] == cnt[0] && produced + ex + ((quota[0] + 3u) & ~3u) <= block_len,
-                                   quota[1] == cnt[1] && produced + ex + cnt[0] + ((quota[1] + 3u) & ~3u) <= block_len};
-            uint32_t p1[2];
-            dfast_write2<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, g, whole, p1, &lane_ok);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t qe = whole[j] ? end[j] : p1[j];
-                if (quota[j] && qe > pay_rel) lane_ok = false;             /* a codeword of the block needs bits past the payload */
-                const uint32_t upto = ex + (j ? cnt[0] : 0u) + quota[j];
-                if (end_bits && quota[j] && upto == take && (uint64_t)take == remaining) sh.qend = qe;      /* behind the block's last symbol */
-            }
-        }
-        const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
-        if (!__syncthreads_and(lane_ok ? 1 : 0)) { ok = false; DFAST_DBG(2, 1); break; }
-        DPROF_ADD(5, pt);
-        DFAST_DBG(11, 1);
-        produced += take;
-        if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }
-        if (end_bits && produced == block_len) *end_bits = seg0 + (uint64_t)uni32(sh.qend);
-        true_start = seg0 + last_end;
-    }
-    return ok;
-}
-
-#ifndef DFAST_CHAINS
-#define DFAST_CHAINS 1                               /* shares a lane walks side by side.  2 (decode_payload_fast2) is bit-exact and slower:
-                                                       zipf255 1.58 -> 2.18 ms per GiB, uniform bytes 1.12 -> 1.12 (profiles/r04/dfast_two_chains.txt) */
-#endif
+/* (Round 4 also walked TWO shares a lane side by side - two chains of dependent LDS reads in flight together: bit-exact and
+ * slower, zipf255 1.58 -> 2.18 ms per GiB, uniform bytes unchanged; profiles/r04/dfast_two_chains.txt and notebook_r04.md have
+ * the numbers, the code went with round 5's clean-up.) */
 template <int THREADS>
 __device__ __forceinline__ bool decode_payload_dfast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
                                     uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
 {
-#if DFAST_CHAINS == 2
-    return decode_payload_fast2<THREADS>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes);
-#else
     return decode_payload_fast<THREADS>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes);
-#endif
 }
 
 /* ======================================================================================
  * Round 4: the table of an ENCODER-MADE tree without walking it.  dec_build_tables finds every node's right child by a
  * search and walks the tree twelve levels deep for each of the 4 096 entries - about 1 150 vector instructions per thread
  * and block, a seventh of this kernel's.  For the trees an encoder writes (4K + 1 entries, K leaves, a root with a left
- * child only, every other node two children) the depths follow from two facts (decode_lean.hpp has the long form): in
+ * child only, every other node two children) the depths follow from two facts: in
  * preorder a leaf's depth is (left turns on its path) + (right turns), the left turns are a prefix sum over the entries
  * (+1 node, -1 marker), the right turns are the one bits of the leaf's code, and code(k + 1) = code(k) + 2^-depth(k) -
  * one chain of four scalar instructions per leaf, walked by ONE wave; the claimed depths are then checked against the
@@ -1386,7 +908,7 @@ __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tr
     return true;
 }
 
-/* One indexed block (the body of decode_fast_kernel and of decode_fast_list_kernel). */
+/* One indexed block (the body of decode_fast_kernel). */
 template <int THREADS>
 __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64_t blk,
     const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
@@ -1418,14 +940,10 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     int leaf = m.leaf;
     int rc = HUFE_OK;
     unsigned long long kt = DPROF_T();
-#ifndef DFAST_WALKED_TABLES      /* (-DDFAST_WALKED_TABLES: round 3's tables for every block, for measurements) */
     /* (from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide next to a long
      *  payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05, log text
      *  1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
     if (leaf < 0 && !(m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, tree, m.tree_len)))
-#else
-    if (leaf < 0)
-#endif
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
     DPROF_ADD(6, kt);
     bool good;
@@ -1437,9 +955,6 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     } else {
         good = decode_payload_dfast<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase);
     }
-#if defined(DFAST_ABLATE_WRITE) || defined(DFAST_ABLATE_STAGE) || defined(DFAST_ABLATE_SCANS)
-    good = true;
-#endif
     if (!good && tid == 0) {
         if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
     }
@@ -1453,28 +968,7 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kerne
     unsigned long long *__restrict__ result, DecFixList fix)
 {
     __shared__ DecShared<THREADS> sh;
-#ifdef DFAST_LDS_PAD            /* (occupancy experiments: fewer workgroups per CU) */
-    __shared__ uint32_t lds_pad[DFAST_LDS_PAD / 4];
-    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
-#endif
     decode_fast_block<THREADS>(sh, blockIdx.x, stream, stream_len, offsets, dmeta, out_offsets, lens, out, out_cap, status, result, fix);
-}
-
-/* The blocks decode_lean_kernel (decode_lean.hpp) could not vouch for, with the decoder above: runs of one byte
- * value, codes that never fall into step inside a run-in, trees that are not an encoder's. */
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_list_kernel(
-    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
-    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
-    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ result, DecFixList fix, const uint32_t *__restrict__ todo_count, const uint32_t *__restrict__ todo_blocks)
-{
-    __shared__ DecShared<THREADS> sh;
-    const uint32_t n = uni32(*todo_count);
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        __syncthreads();                                               /* the previous block's readers of sh are done */
-        decode_fast_block<THREADS>(sh, (uint64_t)uni32(todo_blocks[i]), stream, stream_len, offsets, dmeta, out_offsets, lens, out, out_cap, status, result, fix);
-    }
 }
 
 }  // namespace hufgpu

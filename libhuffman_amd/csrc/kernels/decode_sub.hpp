@@ -693,9 +693,6 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
      * code lengths, checked against the tree; any other tree leaves the block to the exact decoder */
     {
         unsigned long long kt = DPROF_T();
-#ifdef DSUB_TABLES_TWICE        /* (what one table build costs where it stands: the kernel with two of them) */
-        dsub_fast_tables<THREADS>(sh, tree_len, tw);
-#endif
         if (!dsub_fast_tables<THREADS>(sh, tree_len, tw)) return false;          /* (workgroup-uniform) */
         DPROF_ADD(3, kt);
     }
@@ -920,9 +917,6 @@ void decode_sub_kernel(
                                            sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL, out + obase);
     }
     DPROF_ADD(11, kt);              /* (the workgroup's life, thread 0) */
-#ifdef DSUB_ABLATE_VERIFY       /* (diagnostic builds with a phase removed produce garbage: do not decode it again) */
-    good = true;
-#endif
     if (!good && tid == 0) {
         if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
     }

@@ -274,7 +274,6 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
     uint64_t end_bits = 0, produced = 0;
     int err;
     const bool store = uni64(spec_off[gridDim.x]) <= out_cap;
-#ifndef PROBE_EXACT_ONLY
     if (store && block_len != 0 && tl >= 9 && pay0 <= avail) {
         int leaf = -1;
         /* (round 4) the tables from the tree's shape where decode_fast_kernel takes them from it, and the next candidate's
@@ -292,7 +291,6 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
         }
         __syncthreads();
     }
-#endif
     if (store)
         err = decode_block<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
                                           out + spec_off[blockIdx.x], &end_bits, &produced);

@@ -21,6 +21,11 @@ namespace hufgpu {
                                            without work when a GiB is only a few hundred blocks (pack at 2 / 3 MiB blocks: 0.81 / 1.19 ms per
                                            GiB, chunked 0.57; at 1 MiB both forms take 0.64) */
 
+/* hist_lanes.hpp counts with 16-bit counters, one per lane and byte value: a counter sees a 64th of what a workgroup counts
+ * (+ 32 bytes of head and tail) - whole blocks below HUF_CHUNKED_FROM, chunks of HUF_CHUNK_SYMS above it */
+static_assert(HUF_CHUNKED_FROM / 64 + 32 <= HL_MAX_PER_COUNTER && HUF_CHUNK_SYMS / 64 + 32 <= HL_MAX_PER_COUNTER,
+              "a lane's 16-bit counter would overflow into its neighbour's");
+
 struct ChunkGeom {
     uint64_t n, blocksize;
     uint32_t cpb;

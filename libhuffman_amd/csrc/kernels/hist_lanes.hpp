@@ -37,9 +37,6 @@ namespace hufgpu {
  * sum (the registers, not the LDS, then decide: three workgroups).  A counter sees lane l of all eight waves: 1 024 bytes of a 64 KiB block, 32 768 of the largest block that
  * comes here (below 2 MiB; chunks of 256 KiB above that) - 16 bits hold it.  The address is byte << 7 | (lane & 31) << 2:
  * the v_perm puts the byte over twice the column, one shift halves both. */
-#ifndef HL_COUNTER16
-#define HL_COUNTER16 1
-#endif
 #ifndef HL_AHEAD
 #define HL_AHEAD 8                /* 16-byte vectors a thread requests before it counts the first */
 #endif
@@ -47,10 +44,11 @@ namespace hufgpu {
 #define HL_WAVES_PER_SIMD 4       /* (the least the compiler has to leave room for: 8 waves a workgroup, two workgroups per CU; with 72 registers
                                      it is three) */
 #endif
-#define HL_LDS_BYTES (HL_COUNTER16 ? HUF_NSYM * 32 * 4 : HUF_NSYM * 64 * 4)
-#define HL_MAX_PER_COUNTER 65535u
+#define HL_LDS_BYTES (HUF_NSYM * 32 * 4)
+#define HL_MAX_PER_COUNTER 65535u      /* what a 16-bit counter holds: a counter sees the bytes of one lane of all the waves - a 64th of what a
+                                          workgroup counts, + the up to 31 bytes a lane takes in front of and behind the vectors (asserted
+                                          at the kernels: hufgpu_api.hip's block sizes for them) */
 
-#if HL_COUNTER16
 /* col = (lane & 31) << 3 (twice the column's byte offset), one = 1 or 1 << 16 (the lane's half of the word) */
 __device__ __forceinline__ void hl_add_dword(uint8_t *hl_lds, uint32_t w, uint32_t col, uint32_t one)
 {
@@ -64,20 +62,6 @@ __device__ __forceinline__ void hl_add_byte(uint8_t *hl_lds, uint32_t byte, uint
 {
     atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + (((byte << 8) | col) >> 1)), one);
 }
-#else
-__device__ __forceinline__ void hl_add_dword(uint8_t *hl_lds, uint32_t w, uint32_t col, uint32_t one)
-{
-    /* D.byte0 = col.byte0 (lane << 2), D.byte1 = w.byte k, D.byte2 = D.byte3 = 0 */
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0400u)), one);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0500u)), one);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0600u)), one);
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + __builtin_amdgcn_perm(w, col, 0x0c0c0700u)), one);
-}
-__device__ __forceinline__ void hl_add_byte(uint8_t *hl_lds, uint32_t byte, uint32_t col, uint32_t one)
-{
-    atomicAdd(reinterpret_cast<uint32_t *>(hl_lds + ((byte << 8) | col)), one);
-}
-#endif
 
 __device__ __forceinline__ void hl_add_vec(uint8_t *hl_lds, uint4 v, uint32_t col, uint32_t one)
 {
@@ -92,13 +76,8 @@ template <int THREADS>
 __device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restrict__ p, uint64_t len, uint32_t *__restrict__ out)
 {
     const int tid = (int)threadIdx.x;
-#if HL_COUNTER16
     const uint32_t col = (uint32_t)(tid & 31) << 3;
     const uint32_t one = (tid & 32) ? 0x10000u : 1u;
-#else
-    const uint32_t col = (uint32_t)(tid & 63) << 2;
-    const uint32_t one = 1u;
-#endif
 
     {
         uint4 *z = reinterpret_cast<uint4 *>(hl_lds);
@@ -140,7 +119,6 @@ __device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restr
      * four words and then the sixteen lanes of the row (DPP row_shr 1, 2, 4, 8: the sum ends in the row's lane 15) */
     constexpr int WAVES = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
-#if HL_COUNTER16
     /* a row is 32 words of two 16-bit counters: lane l reads words 2 (l % 16), + 1 of row (l / 16) - a wave four rows a step */
 #pragma unroll
     for (int it = 0; it < HUF_NSYM / (4 * WAVES); it++) {
@@ -153,19 +131,6 @@ __device__ __forceinline__ void hl_count(uint8_t *hl_lds, const uint8_t *__restr
         s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
         if ((lane & 15) == 15) out[row] = s;
     }
-#else
-#pragma unroll
-    for (int it = 0; it < HUF_NSYM / (4 * WAVES); it++) {
-        const int row = (it * WAVES + wave) * 4 + (lane >> 4);
-        const uint4 x = *reinterpret_cast<const uint4 *>(hl_lds + row * 256 + (lane & 15) * 16);
-        uint32_t s = x.x + x.y + x.z + x.w;
-        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
-        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
-        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
-        s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, true);    /* row_shr:8 */
-        if ((lane & 15) == 15) out[row] = s;
-    }
-#endif
 }
 
 template <int THREADS>

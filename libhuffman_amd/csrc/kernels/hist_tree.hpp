@@ -123,9 +123,6 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
             if ((second >> 8) >= 256u) hot1 = second & 0xffu;
         }
     }
-#ifdef HT_ABLATE_COUNT         /* (diagnostic builds: the tree alone - counts of the first 4 KiB per wave only) */
-    i = nvec;
-#endif
     if (hot < 0x100u) {
         for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {
             const uint4 v0 = load_stream16(q + i), v1 = load_stream16(q + i + THREADS),
@@ -161,21 +158,11 @@ __global__ __launch_bounds__(THREADS) void hist_tree_kernel(const uint8_t *__res
         s_tot[b] = sum;
     }
     __syncthreads();                     /* copies are dead from here on; s_tot is complete */
-#ifdef HT_TREE_WAVE_ROT
-    /* the wave that builds the tree rotates with the block index: a workgroup's wave w sits on SIMD w of its
-     * CU, so "always wave 0" would put every tree of a CU on one SIMD */
-    if ((uint32_t)(tid >> 6) != ((uint32_t)blk & (uint32_t)(WAVES - 1))) return;
-#else
     if (tid >= 64) return;               /* ended waves do not take part in anything below */
-#endif
     uint32_t rate[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) rate[j] = s_tot[(tid & 63) + 64 * j];
-#ifdef HT_ABLATE_TREE          /* (diagnostic builds: the counting alone) */
-    const uint64_t bytes = rate[0] + rate[1] + rate[2] + rate[3] + 100;
-#else
     const uint64_t bytes = tree_fast_wave(rate, *reinterpret_cast<TreeLds *>(s_union), blk, codetab, treebuf, meta);
-#endif
     /* stream offsets (the reference's running file position): summed here, see two_level_arrive */
     two_level_arrive(sizes, blk, gridDim.x, bytes);
 }

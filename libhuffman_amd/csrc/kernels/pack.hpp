@@ -440,7 +440,7 @@ __device__ __forceinline__ uint32_t pack_join(const uint2 *s_ent, const uint32_t
 }
 
 template <int THREADS, int GROUP>
-__device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src, uint64_t len,
+__device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src, uint64_t len64,
                                                  const hufcode_t *__restrict__ codes64,
                                                  const int16_t *__restrict__ tb, uint32_t tree_len,
                                                  uint8_t *__restrict__ out, uint64_t dst0, uint64_t dst1,
@@ -449,8 +449,10 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
 {
     static_assert(GROUP == 2 || GROUP == 3, "two or three codes a push");
     static_assert(HUF_SUB_TILE == 64 * PACK_SPT, "a sub-index tile is one wave of a pack tile");
-    constexpr int TILE = THREADS * PACK_SPT;
+    constexpr uint32_t TILE = THREADS * PACK_SPT;
     constexpr int WAVES = THREADS / 64;
+    const uint32_t len = (uint32_t)len64;                        /* (blocks of this kernel are shorter than 2 MiB: positions inside one are 32-bit, and a
+                                                                    lane's place is ONE register around the tile loop, not an address pair) */
     constexpr int NG = (PACK_SPT + GROUP - 1) / GROUP;           /* pushes a lane: 16 pairs, or 10 triples and a pair */
     typedef __attribute__((address_space(3))) uint32_t *lds_word;
     const int tid = (int)threadIdx.x;
@@ -464,28 +466,39 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
     for (int i = tid; i < HUF_NSYM; i += THREADS) s_ent[i] = pack_ent_of(codes64[i]);
 
     uint32_t hdr_end;
-    if (!pack_header<THREADS>(len, tb, tree_len, g_a0, g_w0, rec_lo, rec_hi, s_tail, &hdr_end)) return;
+    if (!pack_header<THREADS>(len64, tb, tree_len, g_a0, g_w0, rec_lo, rec_hi, s_tail, &hdr_end)) return;
 
     uint64_t bitpos = (uint64_t)hdr_end * 8ull;                  /* relative to A0 bit 0 */
 
-    for (uint64_t t0 = 0; t0 < len; t0 += TILE) {
-        /* ---- load + look up: the codes of a group are joined as they arrive ---- */
-        const uint64_t my0 = t0 + (uint64_t)tid * PACK_SPT;
-        const uint32_t nsym = my0 < len ? (uint32_t)dmin<uint64_t>(PACK_SPT, len - my0) : 0u;
+    /* A tile's input is requested ONE TILE AHEAD: right behind the look-ups of the tile before it, when the eight registers
+     * that held that tile's bytes are free again - the loads then travel while the tile before is summed, placed and
+     * flushed.  (Round 4 measured this at -1.5 %: the kernel was bound by instruction issue then; with half of round 4's
+     * instructions a workgroup's life is mostly the latency of its loads - time = 0.26 + 1.18 / workgroups per CU ms.)
+     * `ahead`: the wave's lanes of the next tile are all whole and aligned (wave-uniform). */
+    uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
+    bool ahead = false;
+#define PACK_REQUEST(T0_)                                                                                      \
+    {                                                                                                         \
+        const uint32_t m0_ = (T0_) + (uint32_t)tid * PACK_SPT;                                                \
+        const uint8_t *q_ = src + m0_;                                                                        \
+        ahead = (T0_) < len && __builtin_amdgcn_ballot_w64(!(m0_ + PACK_SPT <= len && (((uintptr_t)q_) & 15u) == 0)) == 0ull; \
+        if (ahead) {                                                                                          \
+            n0 = load_stream16(reinterpret_cast<const uint4 *>(q_));                                          \
+            n1 = load_stream16(reinterpret_cast<const uint4 *>(q_) + 1);                                      \
+        }                                                                                                     \
+    }
+    PACK_REQUEST(0u)
+    for (uint32_t t0 = 0; t0 < len; t0 += TILE) {
+        /* ---- look up: the codes of a group are joined as they arrive ---- */
+        const uint32_t my0 = t0 + (uint32_t)tid * PACK_SPT;
+        const uint32_t nsym = my0 < len ? dmin<uint32_t>(PACK_SPT, len - my0) : 0u;
         const uint8_t *p = src + my0;
         uint32_t pc[NG], ph[NG];                                 /* a group's joined codes / summed length fields */
         uint32_t mybits;
         /* (one branch for the wave: the tile of whole, aligned lanes - every tile of a 64 KiB block - has no
          *  per-symbol "is it there" in it) */
-        if (__builtin_amdgcn_ballot_w64(!(nsym == PACK_SPT && (((uintptr_t)p) & 15u) == 0)) == 0ull) {
-#ifdef PACK_ABLATE_LOAD             /* (timing experiments: the kernel without its input; the output is garbage) */
-            const uint32_t x_ = (uint32_t)my0 * 2654435761u;
-            const uint4 v0 = make_uint4(x_, x_ >> 3, x_ >> 5, x_ >> 7), v1 = make_uint4(x_ >> 1, x_ >> 2, x_ >> 4, x_ >> 6);
-#else
-            const uint4 v0 = load_stream16(reinterpret_cast<const uint4 *>(p));
-            const uint4 v1 = load_stream16(reinterpret_cast<const uint4 *>(p) + 1);
-#endif
-            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (ahead) {
+            const uint32_t w[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
             mybits = pack_join<GROUP, false>(s_ent, w, nsym, pc, ph);
         } else {
             uint32_t w[8];
@@ -498,6 +511,7 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
             }
             mybits = pack_join<GROUP, true>(s_ent, w, nsym, pc, ph);
         }
+        PACK_REQUEST(t0 + TILE)
         uint32_t tile_bits;
         const uint32_t ex = block_excl_scan_u32<THREADS>(mybits, s_part, tile_bits);
         if (sub_groups) {                                        /* the sub-index: 2 bytes per 32 symbols */
@@ -532,11 +546,7 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
                     const uint32_t word = __builtin_amdgcn_alignbit(pack_pushed_out(ph[g], acc), acc2, tot2);
                     gw += 4;
                     asm volatile("" : "+v"(gw));
-#ifndef PACK_ABLATE_PLACE
                     *(lds_word)(uintptr_t)gw = __builtin_bswap32(word);
-#else
-                    asm volatile("" :: "v"(word));
-#endif
                 }
                 acc = acc2;
                 tot = tot2;
@@ -592,11 +602,7 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
         }
         __syncthreads();                                         /* stage complete; s_tail is rewritten next tile */
         if (tid == THREADS - 1) s_tail[WAVES] = out_tail;        /* carry into the next tile */
-#ifdef PACK_ABLATE_FLUSH            /* (timing experiments: the kernel without its stores; the output is garbage) */
-        if (staged && len == 0x123456789aull) {
-#else
         if (staged) {
-#endif
             uint8_t *const g16 = reinterpret_cast<uint8_t *>(stage_addr);
             for (uint32_t u = tid; 4 * u < i_hi; u += THREADS) {
                 const uint32_t i0 = 4 * u;
@@ -612,6 +618,8 @@ __device__ __forceinline__ void pack_block_multi(const uint8_t *__restrict__ src
         (void)rec_hi;
     }
 }
+
+#undef PACK_REQUEST
 
 /* SHORT = true: the host guarantees that no code of this launch is longer than 24 bits (any
  * Huffman merge order on n <= 121392 symbols gives depth <= 23, plus the wrap-root bit; the

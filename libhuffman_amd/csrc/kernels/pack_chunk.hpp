@@ -197,11 +197,7 @@ __device__ __forceinline__ void pack_segment(const uint8_t *__restrict__ src, ui
         if (MODE != 2) {
 #pragma unroll
             for (int k = 0; k < PACK_SPT; k++) {
-#ifdef PACK_ABLATE_LOOKUP
-                e[k] = (k < (int)nsym) ? ((((w[k >> 2] >> (8 * (k & 3))) & 0xffu) << 8) | 7u) : 0u;
-#else
                 e[k] = (k < (int)nsym) ? (uint32_t)s_code[(w[k >> 2] >> (8 * (k & 3))) & 0xffu] : 0u;
-#endif
                 mybits += e[k] & 0xffu;
             }
         } else {
@@ -221,11 +217,7 @@ __device__ __forceinline__ void pack_segment(const uint8_t *__restrict__ src, ui
 #pragma unroll 1
         for (int part = 0; part < PARTS; part++) {
             const int l0 = part * (THREADS / PARTS), l1 = l0 + THREADS / PARTS;
-#ifdef PACK_ABLATE_PLACE       /* (diagnostic builds: the kernel without its placement / without its flush) */
-            if (false) {
-#else
             if (tid >= l0 && tid < l1 && nsym) {
-#endif
                 StageAcc a;
                 a.start(s_stage, tile_org + ex);
                 if (MODE == 0) {
@@ -260,11 +252,7 @@ __device__ __forceinline__ void pack_segment(const uint8_t *__restrict__ src, ui
              * bytes up to the one the next chunk owns (the block's last chunk: its zero-padded end) */
             const uintptr_t own_hi = base + (final_part ? (last ? (end_bits + 7u) >> 3 : end_bits >> 3) : (end_bits >> 5) * 4u);
             const uint32_t nfull = end_bits >> 5;                /* complete words of the stage */
-#ifdef PACK_ABLATE_FLUSH
-            for (uint32_t g = (uint32_t)tid; 4u * g < nfull + 1u && own_lo == 1; g += THREADS) {
-#else
             for (uint32_t g = (uint32_t)tid; 4u * g < nfull + 1u; g += THREADS) {
-#endif
                 const uintptr_t ga = base + 16u * g;
                 uint4 v = *reinterpret_cast<const uint4 *>(s_stage + 4 * g);
                 if (ga >= own_lo && ga + 16 <= own_hi) {

@@ -40,23 +40,17 @@ __device__ __forceinline__ uint64_t encoded_block_bytes(const HufBlockMeta &m)
 /* streaming accesses: the input of a pass is read once and its output written once */
 __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 {
-#ifndef HUF_NO_NT_LOAD     /* measured: histogram of 1 GiB 0.202 -> 0.169 ms, pack 0.043 -> 0.030 ms */
+    /* (non-temporal - measured: histogram of 1 GiB 0.202 -> 0.169 ms, pack 0.043 -> 0.030 ms) */
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
 __device__ __forceinline__ void store_stream16(uint4 *p, uint4 v)
 {
-#ifndef HUF_NO_NT_STORE    /* measured: one-symbol decode (a fill) 0.260 -> 0.204 ms per GiB */
+    /* (non-temporal - measured: one-symbol decode (a fill) 0.260 -> 0.204 ms per GiB) */
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
-#else
-    *p = v;
-#endif
 }
 /* The compressed stream is written with the default policy: it is what a decode that follows
  * reads, and a stream that fits the 256 MiB Infinity Cache is then served from there (measured on

@@ -107,12 +107,3 @@ def test_the_short_code_accumulator_has_no_64_bit_shift_left():
     table = build.check_isa(extra_flags=["-DPACK_WAVES_PER_SIMD=7"])
     (vg,) = [r["vgprs"] for n, r in table.items() if "pack_kernelILi256ELb1" in n]
     assert vg <= 72
-
-
-def test_the_two_chain_decoder_still_builds_clean():
-    """decode_payload_fast2 (-DDFAST_CHAINS=2: two shares a lane walked in one loop; measured, slower, not the default - DESIGN.md 3.5)
-    stays in the source as a measured alternative: it has to keep compiling, within the registers of four workgroups per CU, and pass
-    the hazard check like the build that ships."""
-    table = build.check_isa(["-DDFAST_CHAINS=2"])
-    fast = [v for k, v in table.items() if "decode_fast_kernel" in k]
-    assert len(fast) == 1 and fast[0]["vgprs"] <= 64 and fast[0]["lds"] <= 40960

@@ -48,7 +48,7 @@ namespace hufgpu {
  * ==================================================================================== */
 #define DSUB_SPL 32                         /* symbols per lane = HUF_SUB_GROUP */
 #define DSUB_L2_BITS 6u                     /* a second-level table takes codes of up to 12 + 6 bits */
-#define DSUB_L2_ENTRIES 960u                /* it lives in DsubShared::ent */
+#define DSUB_L2_ENTRIES 768u                /* it lives in DsubShared::ent */
 #define DSUB_SLACK_WORDS 16                 /* (step-by-step path) staged behind the last needed word: what a lane that runs wild (32 look-ups of at most 18 bits) or a long code's walk may look at */
 #define DSUB_MAX_GROUP_BITS (DSUB_SPL * HUF_CODE_MAXBITS)
 #define DSUB_CHUNK_SYMS 65536u               /* symbols one workgroup decodes: 32 wave tiles */
@@ -166,6 +166,9 @@ struct DsubShared {
     uint32_t fastk;                                              /* leaves of the tables */
     uint32_t l2n;                                                /* entries of the second-level tables (0: none) */
     uint32_t firstone;                                           /* decode_single_leaf */
+    uint8_t redo[THREADS];                                       /* per lane: bit i = the group of the wave's i-th tile is to be decoded again, step by step */
+    uint64_t late[4];                                            /* what only the step-by-step path behind the tile loop needs - the payload's address and bytes,
+                                                                    the chunk's output, the tile starts as told - parked here, not in scalar registers around the loop */
     __attribute__((aligned(256))) uint32_t pay[WAVES * SLICE_WORDS];  /* the waves' slices (the table build's scratch before that); a ROW - 256 bytes -
                                                                     at a multiple of 256: a row's number and a lane's offset in it are bit fields of an LDS address */
 };
@@ -541,8 +544,7 @@ __device__ __noinline__ bool dsub_tile_slow(const DsubShared<THREADS> &sh, uint3
  * Returns true (workgroup-uniform) when everything was verified.  told = the first payload bit of the chunk's wave
  * tiles as the sub-index has them (told[q] for the chunk's tile q; told[ntiles] is looked at only when the block goes
  * on behind the chunk), grp = the chunk's group bit counts; readable = bytes that may be loaded from `pay` on (to the
- * end of the stream); safe = an address with 64 readable bytes behind it (the block's header and tree: >= 19 bytes,
- * then payload or the next block - see the caller).
+ * end of the stream).
  *
  * Wave w takes tiles w, w + 8, ...: the lanes' bit counts, one scan, the check against the next tile's start, and
  * every lane requests the twelve dwords from the one that holds its first bit on.  The words of the wave's NEXT tile
@@ -550,7 +552,7 @@ __device__ __noinline__ bool dsub_tile_slow(const DsubShared<THREADS> &sh, uint3
  * No barrier after the table build. */
 template <int THREADS>
 __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, const uint8_t *tree, int tree_len, const uint8_t *lens_g,
-                                   const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, const uint8_t *safe,
+                                   const uint8_t *pay, uint64_t pay_bytes, uint64_t readable,
                                    uint64_t sym0, uint64_t sym1, bool block_goes_on, const uint64_t *__restrict__ told,
                                    const uint16_t *__restrict__ grp, uint8_t *gout)
 {
@@ -594,7 +596,6 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     const uintptr_t cout_a = (uintptr_t)uni64((uint64_t)(uintptr_t)(gout + sym0));           /* the chunk's first output byte */
     const global_out cout = (global_out)cout_a;
     const uint64_t end_a = uni64((uint64_t)pay_a + readable);                                 /* the stream's end */
-    const uintptr_t safe_a = ((uintptr_t)uni64((uint64_t)(uintptr_t)safe) + 3u) & ~(uintptr_t)3;
 
     /* A tile's set-up.  The lane's column starts with the aligned 32-bit word of MEMORY that holds the lane's first
      * bit (the staged words are then byte-swapped dwords, whatever the payload's alignment).
@@ -625,8 +626,11 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         const bool more_ = valid_ && (qq_ + 1u < ntiles || block_goes_on);                                    \
         t_f = told_c[qq_];                                                                                    \
         tn_f = told_c[more_ ? qq_ + 1u : qq_];                                                                \
-        const uint32_t g_ = qq_ * 64u + (uint32_t)lane;                                                       \
-        gb_f = (valid_ && g_ < ngrp) ? (uint32_t)grp[g_] : 0u;                                                \
+        /* (through a buffer resource over the chunk's counts: a lane without a group reads beyond it and gets 0 - no        \
+         *  condition, no clamp, and a 32-bit offset instead of an address pair) */                                            \
+        uint32_t l2_;                      /* (2 * lane from 4 * lane, which the windows keep: not one more register held) */ \
+        asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(l2_) : "v"(lane4));                                     \
+        gb_f = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(grp_rsrc, valid_ ? (qq_ << 7) | l2_ : 0xfffffffeu, 0, 0); \
     }
 /* (Everything about a tile relative to the chunk's first, in 32-bit scalar arithmetic: a chunk's payload is less
  * than 2^22 bits long; a told start that is not inside that is wrong.  The fetch for the tile after the next
@@ -645,7 +649,9 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         const uint32_t nsym_n = (valid_ && g_ < ngrp) ? dmin<uint32_t>(DSUB_SPL, nchunk - g_ * DSUB_SPL) : 0u; \
         const uint32_t incl_ = wave_incl_scan_u32(gb_n);                                                      \
         const uint32_t tb_ = wave_lane_u32(incl_, 63);                                                        \
-        const bool fine_ = valid_ && chunk_fine && uni32((uint32_t)(d_ >> 32)) == 0u && rel_t_ <= room0 && tb_ <= room0 - rel_t_;   /* (b) */ \
+        uint32_t dhi_ = uni32((uint32_t)(d_ >> 32));                                                          \
+        asm volatile("" : "+s"(dhi_));     /* (a 32-bit scalar compare: not d_ < 2^32 with the constant in a register pair) */ \
+        const bool fine_ = valid_ && chunk_fine && dhi_ == 0u && rel_t_ <= room0 && tb_ <= room0 - rel_t_;   /* (b) */ \
         if (valid_ && !fine_) ok = false;                                                                     \
         if (fine_ && more_ && t_f + tb_ != tn_f) ok = false;                             /* (c) */              \
         const uint32_t rel_ = uni32(lead0 + (fine_ ? rel_t_ : 0u)) + (incl_ - gb_n);     /* my first bit from the chunk's aligned first word */ \
@@ -653,28 +659,43 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         /* one register a lane and tile: where the position register starts (13 bits), where (b) wants it to stand  \
          * behind the group (13 bits), and 2 = all 32 symbols / 1 = the block's last, short group / 0 = none */       \
         state_n = (r_top - lead_n) | (((r_top - lead_n - gb_n) & 0x1fffu) << 13) | ((nsym_n == DSUB_SPL ? 2u : (nsym_n ? 1u : 0u)) << 26); \
-        uint32_t off_ = (rel_ >> 5) << 2;                                               /* my column's word 0, bytes from that word */ \
-        const uint32_t last_ = wave_lane_u32(off_, 63);                                 /* (offsets grow with the lane) */ \
-        quick_n = fine_ && last_ <= left0 && left0 - last_ >= 4u * ROWS && __ballot(lead_n + gb_n > DSUB_COL_BITS) == 0ull; \
-        global_bytes base_ = (global_bytes)(uintptr_t)uni64((uint64_t)(quick_n ? base0 : safe_a));             \
-        if (!quick_n) off_ = 0;                                                                               \
+        const uint32_t off_ = (rel_ >> 5) << 2;                                         /* my column's word 0, bytes from that word */ \
+        /* (the last lane's twelve dwords inside the stream: then everybody's) */                              \
+        quick_n = fine_ && wave_lane_u32(off_, 63) + 4u * ROWS <= left0 && __ballot(lead_n + gb_n > DSUB_COL_BITS) == 0ull; \
         DSUB_FETCH(FETCH_Q_)                                                                                  \
         _Pragma("unroll")                                                                                     \
         for (int k = 0; k < 3; k++) {                                                                         \
-            const dwords4 v_ = *(global_q4)(base_ + off_ + 16 * k);                                           \
+            const dwords4 v_ = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off_ + 16u * (uint32_t)k, 0, 0); \
             V[k] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                                        \
         }                                                                                                     \
     }
-/* the loaded words into the column: word g (byte-swapped) at row ROWS - 1 - g */
+/* the loaded words into the column: word g (byte-swapped) at row ROWS - 1 - g.  (The words are waited for and swapped for
+ * every tile, also one that stages nothing: a wait under a condition leaves the compiler with "maybe pending" registers at
+ * the top of the loop, and its wait for THOSE - before it overwrites them - is s_waitcnt vmcnt(0): the previous tile's
+ * stores and the fetch just issued as well.) */
 #define DSUB_TO_SLICE()                                                                                        \
-    if (quick_n) {                                                                                            \
+    {                                                                                                         \
         lds_words_w col_ = (lds_words_w)(uintptr_t)(slice_a + lane4);   /* row 0 of my column */               \
-        const uint32_t wv_[12] = {V[0].x, V[0].y, V[0].z, V[0].w, V[1].x, V[1].y, V[1].z, V[1].w, V[2].x, V[2].y, V[2].z, V[2].w}; \
+        uint32_t wv_[12] = {V[0].x, V[0].y, V[0].z, V[0].w, V[1].x, V[1].y, V[1].z, V[1].w, V[2].x, V[2].y, V[2].z, V[2].w}; \
         _Pragma("unroll")                                                                                     \
-        for (int g = 0; g < (int)ROWS; g++) col_[64 * ((int)ROWS - 1 - g)] = __builtin_bswap32(wv_[g]);       \
+        for (int g = 0; g < (int)ROWS; g++) {                                                                 \
+            wv_[g] = __builtin_bswap32(wv_[g]);                                                               \
+            asm volatile("" : "+v"(wv_[g]));                                                                  \
+        }                                                                                                     \
+        if (quick_n) {                                                                                        \
+            _Pragma("unroll")                                                                                 \
+            for (int g = 0; g < (int)ROWS; g++) col_[64 * ((int)ROWS - 1 - g)] = wv_[g];                      \
+        }                                                                                                     \
     }
     static_assert(DSUB_ROWS == 12, "three 16-byte loads a lane");
 
+    sh.redo[tid] = 0;                                               /* (the lane's own byte: no barrier) */
+    if (tid == 0) {                                                  /* (read behind the tile loop: the table build's barriers lie in between) */
+        sh.late[0] = (uint64_t)(uintptr_t)pay;
+        sh.late[1] = pay_bytes;
+        sh.late[2] = (uint64_t)(uintptr_t)(gout + sym0);
+        sh.late[3] = (uint64_t)(uintptr_t)told;
+    }
     /* the chunk's first tile, as told: (a), and where its first bit lies */
     const uint64_t T0 = told_c[0];
     uint64_t room64;
@@ -686,6 +707,13 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     const uintptr_t base0 = a0 & ~(uintptr_t)3;                     /* (may begin up to 3 bytes in front of the payload: header and tree lie there) */
     const uint64_t left64 = end_a - (uint64_t)base0;                /* readable bytes from there on */
     const uint32_t left0 = (uint32_t)(left64 >> 32) != 0u ? 0xffffffffu : (uint32_t)left64;
+    /* The words come through a buffer resource from that word to the stream's end: a tile that stages nothing loads
+     * whatever its offsets say and gets zeros where that is beyond the end - no safe address to point idle loads at,
+     * and 32-bit offsets instead of address pairs.  A tile whose loads reach beyond the end - the stream's last - is
+     * not quick: what a load that lies across the end returns (the hardware zeroes at least the dword that does, bytes
+     * of the stream among them) is not relied upon. */
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base0, (short)0, (int)left0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)grp, (short)0, (int)(2u * ngrp), 0x00020000);
     uint32_t q = (uint32_t)wave;
     DSUB_FETCH(q)
     DSUB_SETUP(q, q + WAVES)
@@ -701,104 +729,108 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     /* what the loop leaves for later (bit i = the wave's i-th tile): tiles that are not `quick`, and - per lane -
      * groups to be decoded again step by step.  Those go through dsub_tile_slow BEHIND the loop: a call inside
      * it would have the loop's registers saved and restored around a path that is next to never taken. */
-    uint32_t slow_tiles = 0, redo_tiles = 0;
+    uint32_t slow_tiles = 0;
+    /* The lane's 32 bytes leave through a buffer resource over the chunk's output: a lane that has nothing to store
+     * (a tile that is not quick, the block's last, short group, lanes behind the block's end) stores at an offset beyond
+     * the resource and the hardware drops it.  No branch around the stores - and that is the point: between the
+     * request of the next tile's words and the wait for them lie the same two stores on every path, so the wait is
+     * s_waitcnt vmcnt(2), not a wait for the stores' acknowledgement. */
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)cout_a, (short)0, (int)nchunk, 0x00020000);
+    const bool out_ok = (cout_a & 3u) == 0;                          /* (dword stores: any other output address takes the step-by-step path) */
 
 #pragma unroll 1
     for (uint32_t ti = 0; q < ntiles; q += WAVES, ti++) {
         pt = DPROF_T();
         const uint32_t my0 = (q * 64u + (uint32_t)lane) * DSUB_SPL;     /* relative to the chunk: 32-bit arithmetic, one offset register */
         const uint32_t state = state_n;                                 /* this tile's */
-        const bool cur_quick = quick_n;
+        const bool cur_quick = quick_n && out_ok;
         /* the next tile's words are requested now and arrive while this one is decoded (what the sub-index says
          * about the tile behind it, too) */
         DSUB_SETUP(q + WAVES, q + 2 * WAVES)
         DPROF_ADD(9, pt); pt = DPROF_T();
-        if (!cur_quick) {
-            slow_tiles |= 1u << ti;
-        } else if (state >> 26) {
-            bool redo = (state >> 26) != 2u;                    /* the block's last, short group */
-            bool group_ok = false;
-            if ((state >> 26) == 2u) {
-                /* The common case has no branch.  Every two symbols the 32 bits at the position are read
-                 * again from the column (one ds_read2st64_b32, one v_alignbit_b32) - no bit buffer to refill -
-                 * and looked up twice; the entries' low five bits shift the window and their sum moves the
-                 * position as they stand.  An entry that is not a leaf has length 0: the lane stands still
-                 * from then on (a `long` code, a walk that leaves the tree: the low byte is 0) and its last
-                 * look-up tells; such a lane decodes its group again behind the loop, step by step.
-                 * The lane's 32 bytes leave as two 16-byte stores back to back, DEFAULT cache policy: one whole
-                 * 32-byte sector (a store per 16 symbols left half-written sectors in L2 for a round, and one in
-                 * nine of them was evicted like that and written twice; streaming stores reach HBM as partial
-                 * writes altogether).
-                 * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per
-                 * symbol; a lane decoding the two halves of its group side by side.) */
-                const bool aligned = (cout_a & 15u) == 0;             /* (the offset is a multiple of 32) */
-                uint32_t R = state & 0x1fffu;
-                uint32_t special = 0, e_last = 0, firsts = 0;
+        if (!cur_quick) slow_tiles |= 1u << ti;
+        {
+            /* Every lane runs the loop, whatever its state (a lane without a whole group reads stale columns and its
+             * result goes nowhere).  Every two symbols the 32 bits at the position are read again from the column
+             * (one ds_read2st64_b32, one v_alignbit_b32) - no bit buffer to refill - and looked up twice; the
+             * entries' low five bits shift the window and their sum moves the position as they stand.  An entry that
+             * is not a leaf has length 0: the lane stands still from then on (a `long` code, a walk that leaves the
+             * tree: the low byte is 0) and its last look-up tells; such a lane decodes its group again behind the
+             * loop, step by step.  The lane's 32 bytes leave as two 16-byte stores back to back, DEFAULT cache
+             * policy: one whole 32-byte sector (a store per 16 symbols left half-written sectors in L2 for a round,
+             * and one in nine of them was evicted like that and written twice; streaming stores reach HBM as partial
+             * writes altogether).
+             * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per symbol; a lane
+             * decoding the two halves of its group side by side.) */
+            const bool whole = (state >> 26) == 2u;
+            uint32_t R = state & 0x1fffu;
+            uint32_t special = 0, e_last = 0, firsts = 0;
+            const uint32_t o_ = (cur_quick && whole) ? my0 : 0x7fffff00u;
 /* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
  * wave by a ballot - goes on to the second table with the bits behind the 12-bit prefix; one that cannot
  * (too few bits left in the window) stays what it is and is remembered in `special`.  Blocks
  * without such codes (zipf255, uniform bytes) run the loop without the ballots. */
 #define DSUB_WINDOW(PAIR, L2)                                                                                 \
-                {                                                                                             \
-                    lds_words wp_ = (lds_words)(uintptr_t)(((R << 3) & 0xffffff00u) | lane4);                  \
-                    const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[64], wp_[0], R);                        \
-                    uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0xffeu));               \
-                    if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
-                        if (DSE_IS_L2(e1_)) e1_ = dsub_l2(sh, e1_, d1_);                                      \
-                    }                                                                                         \
-                    const uint32_t d2_ = d1_ << (e1_ & 31u);                                                  \
-                    uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0xffeu));               \
-                    if (L2 && __ballot(DSE_IS_L2(e2_))) {                                                     \
-                        /* (the window has 32 - len bits left) */                                             \
-                        if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
-                            e2_ = dsub_l2(sh, e2_, d2_);                                                      \
-                    }                                                                                         \
-                    if (L2) {                                                                                 \
-                        special |= e1_ | e2_;                                                                 \
-                        asm volatile("" : "+v"(special));     /* (now: not 32 entries kept for one big OR at the end) */ \
-                    }                                                                                         \
-                    firsts |= d1_ | d2_;          /* (one v_or3_b32: every codeword's first bit, at bit 31) */   \
-                    asm volatile("" : "+v"(firsts));     /* (now: not 32 windows kept for one big OR at the end) */    \
-                    R -= (e1_ + e2_) & 0xffu;                                                                 \
-                    PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
-                    e_last = e2_;                                                                             \
-                }
+            {                                                                                             \
+                lds_words wp_ = (lds_words)(uintptr_t)(((R << 3) & 0xff00u) | lane4);                      \
+                const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[64], wp_[0], R);                        \
+                uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0xffeu));               \
+                if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
+                    if (DSE_IS_L2(e1_)) e1_ = dsub_l2(sh, e1_, d1_);                                      \
+                }                                                                                         \
+                const uint32_t d2_ = d1_ << (e1_ & 31u);                                                  \
+                uint32_t e2_ = *(lds_halves)(uintptr_t)(lut_addr + ((d2_ >> 19) & 0xffeu));               \
+                if (L2 && __ballot(DSE_IS_L2(e2_))) {                                                     \
+                    /* (the window has 32 - len bits left) */                                             \
+                    if (DSE_IS_L2(e2_) && DSE_LEN(e1_) + DEC_LUT_BITS + DSUB_L2_BITS <= 32u)              \
+                        e2_ = dsub_l2(sh, e2_, d2_);                                                      \
+                }                                                                                         \
+                if (L2) {                                                                                 \
+                    special |= e1_ | e2_;                                                                 \
+                    asm volatile("" : "+v"(special));     /* (now: not 32 entries kept for one big OR at the end) */ \
+                }                                                                                         \
+                firsts |= d1_ | d2_;          /* (one v_or3_b32: every codeword's first bit, at bit 31) */   \
+                asm volatile("" : "+v"(firsts));     /* (now: not 32 windows kept for one big OR at the end) */    \
+                R -= (e1_ + e2_) & 0xffu;                                                                 \
+                PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
+                e_last = e2_;                                                                             \
+                /* (the windows of this form one after the other: interleaved they hold forty registers, and \
+                 *  what lives around the tile loop is spilled for them - in the other form's path as well) */ \
+                if (L2) __builtin_amdgcn_sched_barrier(0);                                                \
+            }
 #define DSUB_ROUNDS(L2)                                                                                        \
-                {                                                                                             \
-                    uint32_t w[8];                                                                            \
-                    _Pragma("unroll")                                                                         \
-                    for (int k = 0; k < 8; k++) {                                                             \
-                        uint32_t p01, p23;                                                                    \
-                        DSUB_WINDOW(p01, L2)                                                                  \
-                        DSUB_WINDOW(p23, L2)                                                                  \
-                        w[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                  \
-                    }                                                                                         \
-                    /* (the address from the 32-bit offset right here: scalar base + offset register, not a   \
-                     *  64-bit address kept in two registers around the loop) */                             \
-                    uint32_t o_ = my0;                                                                        \
-                    asm volatile("" : "+v"(o_));                                                              \
-                    if (aligned) {                                                                            \
-                        dwords4 a4_, b4_;                                                                     \
-                        a4_.x = w[0]; a4_.y = w[1]; a4_.z = w[2]; a4_.w = w[3];                               \
-                        b4_.x = w[4]; b4_.y = w[5]; b4_.z = w[6]; b4_.w = w[7];                               \
-                        *(global_out4)(cout + o_) = a4_;                                                      \
-                        *(global_out4)(cout + o_ + 16) = b4_;                                                 \
-                    } else {                                                                                  \
-                        _Pragma("unroll")                                                                     \
-                        for (int k = 0; k < 32; k++) (cout + o_)[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));  \
-                    }                                                                                         \
-                }
-                /* (two loops, whole: the compiler otherwise moves their common first look-up in front of the branch
-                 *  and spills the position register around it) */
-                if (use_l2) { asm volatile("; codes in a second-level table" : "+v"(R)); DSUB_ROUNDS(true) }
-                else { asm volatile("; every code in the first table" : "+v"(R)); DSUB_ROUNDS(false) }
+            {                                                                                             \
+                uint32_t w[8];                                                                            \
+                _Pragma("unroll")                                                                         \
+                for (int k = 0; k < 8; k++) {                                                             \
+                    uint32_t p01, p23;                                                                    \
+                    DSUB_WINDOW(p01, L2)                                                                  \
+                    DSUB_WINDOW(p23, L2)                                                                  \
+                    w[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                  \
+                }                                                                                         \
+                a4_.x = w[0]; a4_.y = w[1]; a4_.z = w[2]; a4_.w = w[3];                                   \
+                b4_.x = w[4]; b4_.y = w[5]; b4_.z = w[6]; b4_.w = w[7];                                   \
+            }
+            /* (two loops, whole: the compiler otherwise moves their common first look-up in front of the branch
+             *  and spills the position register around it) */
+            dwords4 a4_, b4_;
+            if (use_l2) { asm volatile("; codes in a second-level table" : "+v"(R)); DSUB_ROUNDS(true) }
+            else { asm volatile("; every code in the first table" : "+v"(R)); DSUB_ROUNDS(false) }
+            /* (the stores behind the two forms, not in each: every path to the wait for the next tile's words then
+             *  has the same two stores behind those loads, and the wait is s_waitcnt vmcnt(4..2) - in the forms, the
+             *  compiler sees a path around them and waits for the stores' acknowledgement, vmcnt(0)) */
+            __builtin_amdgcn_raw_buffer_store_b128(a4_, out_rsrc, o_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(b4_, out_rsrc, o_ + 16u, 0, 0);
 #undef DSUB_ROUNDS
 #undef DSUB_WINDOW
-                redo = DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u || (firsts >> 31) != 0u;     /* (a first bit of 1: the step-by-step path says what the reference says) */
-                group_ok = R == ((state >> 13) & 0x1fffu);      /* (b): exactly the bits of the group */
+            /* a group to be decoded again: the block's last, short one; one that met a code the tables do not hold; a
+             * first bit of 1 (the step-by-step path says what the reference says).  Else (b): exactly the group's bits */
+            const bool redo = cur_quick && (state >> 26) != 0u &&
+                              (!whole || DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u || (firsts >> 31) != 0u);
+            if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
+                if (redo) sh.redo[tid] |= (uint8_t)(1u << ti);
             }
-            if (redo) redo_tiles |= 1u << ti;
-            else if (!group_ok) ok = false;
+            if (cur_quick && whole && !redo && R != ((state >> 13) & 0x1fffu)) ok = false;
         }
         DPROF_ADD(10, pt);
         /* the columns are free: the next tile's words (the wait for them counts the stores behind them out) */
@@ -807,7 +839,12 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
 #undef DSUB_TO_SLICE
 #undef DSUB_SETUP
 #undef DSUB_FETCH
+    const uint32_t redo_tiles = sh.redo[tid];
     if (__builtin_expect(slow_tiles != 0u || __ballot(redo_tiles != 0u) != 0ull, 0)) {
+        const uint8_t *const pay_l = (const uint8_t *)(uintptr_t)uni64(sh.late[0]);
+        const uint64_t pay_bytes_l = uni64(sh.late[1]), pay_bits_l = pay_bytes_l * 8ull;
+        uint8_t *const out_l = (uint8_t *)(uintptr_t)uni64(sh.late[2]);
+        const uint64_t *const told_l = (const uint64_t *)(uintptr_t)uni64(sh.late[3]);
 #pragma unroll 1
         for (uint32_t ti = 0; ti * WAVES + (uint32_t)wave < ntiles; ti++) {
             const bool whole = ((slow_tiles >> ti) & 1u) != 0u;
@@ -822,10 +859,10 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                 gb = dmin<uint32_t>((uint32_t)grp[g], DSUB_MAX_GROUP_BITS);
             }
             const uint32_t incl = wave_incl_scan_u32(gb);
-            const uint64_t tfirst = uni64(told[q]);
+            const uint64_t tfirst = uni64(told_l[q]);
             /* (a tile whose told start or bits lie outside the payload was counted out by its set-up: ok is false) */
-            if (tfirst <= pay_bits && (uint64_t)wave_lane_u32(incl, 63) <= pay_bits - tfirst) {
-                if (!dsub_tile_slow<THREADS>(sh, top, pay, pay_bytes, tfirst, incl - gb, incl, nsym, mine, gout + sym0 + my0)) ok = false;
+            if (tfirst <= pay_bits_l && (uint64_t)wave_lane_u32(incl, 63) <= pay_bits_l - tfirst) {
+                if (!dsub_tile_slow<THREADS>(sh, top, pay_l, pay_bytes_l, tfirst, incl - gb, incl, nsym, mine, out_l + my0)) ok = false;
             }
         }
     }
@@ -906,13 +943,8 @@ void decode_sub_kernel(
                                                  pay_bytes - (sym0 >> 3), out + obase + sym0, &eb, &produced) == HUFE_OK;
     } else {
         DPROF_ADD(2, kt);
-        /* `safe`: where a tile with nothing to load points its loads - 64 readable bytes if the stream has them
-         * behind the block's start, else none are issued against it (a stream that short has no quick tile and
-         * its loads go to ... the same place: the test below makes that place the stream's last 64 bytes) */
-        const uint8_t *safe = stream + (stream_len >= o0 + 64 ? o0 : (stream_len >= 64 ? stream_len - 64 : 0));
-        good = stream_len >= 64 + 3 &&
-               decode_payload_sub<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM, pay, pay_bytes,
-                                           stream_len - (uint64_t)(pay - stream), safe, sym0, sym1, sym1 < m.block_len,
+        good = decode_payload_sub<THREADS>(sh, tree, m.tree_len, sub.lens + blk * HUF_NSYM, pay, pay_bytes,
+                                           stream_len - (uint64_t)(pay - stream), sym0, sym1, sym1 < m.block_len,
                                            sub.tile_bits + blk * sub.tpb + sym0 / HUF_SUB_TILE,
                                            sub.group_bits + blk * sub.gpb + sym0 / DSUB_SPL, out + obase);
     }

@@ -581,13 +581,20 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     typedef const __attribute__((address_space(1))) dwords4_a4 *global_q4;
     typedef __attribute__((address_space(1))) uint8_t *global_out;
     typedef __attribute__((address_space(1))) dwords4 *global_out4;
-    /* The position register of a lane: R = 32 * (number of the slice's last row) - position, position = bits from
-     * the first bit of the lane's word 0, rows numbered from LDS address 0 in units of 256 bytes (the slices lie at
-     * multiples of that).  Word g lies at row last - g, so R >> 5 IS the row of word g + 1 - the lower of the two
-     * rows that hold the 32 bits at the position: its address is (R << 3) & ~255 | 4 * lane, one shift and one
-     * v_and_or_b32 - and the low five bits of R are the amount v_alignbit_b32 shifts that pair by (0..31; at amount
-     * 0 the position is the first bit of the LOWER row's word and the upper row is not looked at) - no negation,
-     * and a codeword is R -= len. */
+    /* The position of a lane: R = 32 * (number of the slice's last row) - position, position = bits from the first
+     * bit of the lane's word 0, rows numbered from LDS address 0 in units of 256 bytes (the slices lie at multiples of
+     * that).  Word g lies at row last - g, so R >> 5 IS the row of word g + 1 - the lower of the two rows that hold
+     * the 32 bits at the position - and the low five bits of R are the amount v_alignbit_b32 shifts that pair by
+     * (0..31; at amount 0 the position is the first bit of the LOWER row's word and the upper row is not looked at) -
+     * no negation, and a codeword is R -= len.
+     * The position REGISTER holds R with a gap: P = (R >> 5) << 8 | (R & 31), bits 5..7 zero.  The row's LDS address is
+     * then P & 0xff00 | 4 * lane - one v_and_or_b32, no shift - and v_alignbit_b32 takes P as it stands.  P -= n for
+     * n <= 32 is an ordinary subtraction and the gap cleared: a borrow out of the low five bits runs through the gap
+     * (it becomes 111) into the row.  (Round 5, tools/calib/valu_rate.hip: on this chip v_add/sub/and/or/xor/mov and
+     * v_lshrrev with VGPR or literal operands issue in 2.5 cycles a wave, everything else - three-operand forms, SDWA,
+     * DPP, left shifts, an SGPR operand - in 4; a look-up pair was 12.5 instructions of which 7.5 slow, and is 11.5
+     * with 6.5 slow.) */
+#define DSUB_GAP(R_) ((((R_) << 3) & 0xff00u) | ((R_) & 31u))
     const uint32_t lane4 = 4u * (uint32_t)lane;
     const uint32_t slice_a = uni32((uint32_t)(uintptr_t)(lds_words)slice);                             /* LDS byte address of the wave's slice */
     const uint32_t r_top = 32u * ((slice_a >> 8) + ROWS - 1u);                                           /* R of position 0 */
@@ -656,9 +663,9 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
         if (fine_ && more_ && t_f + tb_ != tn_f) ok = false;                             /* (c) */              \
         const uint32_t rel_ = uni32(lead0 + (fine_ ? rel_t_ : 0u)) + (incl_ - gb_n);     /* my first bit from the chunk's aligned first word */ \
         const uint32_t lead_n = rel_ & 31u;                                                                   \
-        /* one register a lane and tile: where the position register starts (13 bits), where (b) wants it to stand  \
-         * behind the group (13 bits), and 2 = all 32 symbols / 1 = the block's last, short group / 0 = none */       \
-        state_n = (r_top - lead_n) | (((r_top - lead_n - gb_n) & 0x1fffu) << 13) | ((nsym_n == DSUB_SPL ? 2u : (nsym_n ? 1u : 0u)) << 26); \
+        /* one register a lane and tile: where the position register starts (15 bits), where (b) wants it to stand  \
+         * behind the group (15 bits), and 2 = all 32 symbols / 1 = the block's last, short group / 0 = none */       \
+        state_n = DSUB_GAP(r_top - lead_n) | (DSUB_GAP((r_top - lead_n - gb_n) & 0xfffu) << 15) | ((nsym_n == DSUB_SPL ? 2u : (nsym_n ? 1u : 0u)) << 30); \
         const uint32_t off_ = (rel_ >> 5) << 2;                                         /* my column's word 0, bytes from that word */ \
         /* (the last lane's twelve dwords inside the stream: then everybody's) */                              \
         quick_n = fine_ && wave_lane_u32(off_, 63) + 4u * ROWS <= left0 && __ballot(lead_n + gb_n > DSUB_COL_BITS) == 0ull; \
@@ -762,8 +769,8 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
              * writes altogether).
              * (Measured and dropped: a 64-bit buffer with refills, 14 instead of 8 instructions per symbol; a lane
              * decoding the two halves of its group side by side.) */
-            const bool whole = (state >> 26) == 2u;
-            uint32_t R = state & 0x1fffu;
+            const bool whole = (state >> 30) == 2u;
+            uint32_t R = state & 0x7fffu;                               /* (with the gap: see above) */
             uint32_t special = 0, e_last = 0, firsts = 0;
             const uint32_t o_ = (cur_quick && whole) ? my0 : 0x7fffff00u;
 /* L2 = the block has second-level entries (sh.l2n): a lookup that meets one - decided for the whole
@@ -772,7 +779,7 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
  * without such codes (zipf255, uniform bytes) run the loop without the ballots. */
 #define DSUB_WINDOW(PAIR, L2)                                                                                 \
             {                                                                                             \
-                lds_words wp_ = (lds_words)(uintptr_t)(((R << 3) & 0xff00u) | lane4);                      \
+                lds_words wp_ = (lds_words)(uintptr_t)((R & 0xff00u) | lane4);                            \
                 const uint32_t d1_ = __builtin_amdgcn_alignbit(wp_[64], wp_[0], R);                        \
                 uint32_t e1_ = *(lds_halves)(uintptr_t)(lut_addr + ((d1_ >> 19) & 0xffeu));               \
                 if (L2 && __ballot(DSE_IS_L2(e1_))) {                                                     \
@@ -791,8 +798,16 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
                 }                                                                                         \
                 firsts |= d1_ | d2_;          /* (one v_or3_b32: every codeword's first bit, at bit 31) */   \
                 asm volatile("" : "+v"(firsts));     /* (now: not 32 windows kept for one big OR at the end) */    \
-                R -= (e1_ + e2_) & 0xffu;                                                                 \
-                PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x0c0c0501u);                                      \
+                /* the two bytes, and behind them the two lengths: R -= len1 + len2 is then ONE v_dot4c_i32_i8 with \
+                 * the bytes (0, 0, -1, -1) - not an addition and an SDWA subtraction.  Codes of the first table are  \
+                 * at most 12 bits: one step; with second-level codes (up to 18 bits) a length at a time. */         \
+                PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x04000501u);                                      \
+                if (L2) {                                                                                 \
+                    R = (uint32_t)__builtin_amdgcn_sdot4((int)PAIR, (int)0x00ff0000, (int)R, false) & 0xff1fu; \
+                    R = (uint32_t)__builtin_amdgcn_sdot4((int)PAIR, (int)0xff000000, (int)R, false) & 0xff1fu; \
+                } else {                                                                                  \
+                    R = (uint32_t)__builtin_amdgcn_sdot4((int)PAIR, (int)0xffff0000, (int)R, false) & 0xff1fu; \
+                }                                                                                         \
                 e_last = e2_;                                                                             \
                 /* (the windows of this form one after the other: interleaved they hold forty registers, and \
                  *  what lives around the tile loop is spilled for them - in the other form's path as well) */ \
@@ -825,12 +840,12 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
 #undef DSUB_WINDOW
             /* a group to be decoded again: the block's last, short one; one that met a code the tables do not hold; a
              * first bit of 1 (the step-by-step path says what the reference says).  Else (b): exactly the group's bits */
-            const bool redo = cur_quick && (state >> 26) != 0u &&
+            const bool redo = cur_quick && (state >> 30) != 0u &&
                               (!whole || DSE_LEN(e_last) == 0u || (special & DSE_L2) != 0u || (firsts >> 31) != 0u);
             if (__builtin_expect(__ballot(redo) != 0ull, 0)) {
                 if (redo) sh.redo[tid] |= (uint8_t)(1u << ti);
             }
-            if (cur_quick && whole && !redo && R != ((state >> 13) & 0x1fffu)) ok = false;
+            if (cur_quick && whole && !redo && R != ((state >> 15) & 0x7fffu)) ok = false;
         }
         DPROF_ADD(10, pt);
         /* the columns are free: the next tile's words (the wait for them counts the stores behind them out) */

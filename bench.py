@@ -600,9 +600,95 @@ class Bench:
         return rec
 
     def root_placement(self, workload: str, steps: int) -> dict:
-        """The path with the data starting and ending on rank 0 (north_star: "RCCL scatter/gather of
-        block buffers over xGMI"): scatter input shards -> encode -> gather compressed shards (+ the
-        size all-gather that places them) -> scatter them again -> decode -> gather the output.  Each
+        """The path with the data starting and ending on rank 0 (north_star: "RCCL scatter/gather of block buffers
+        over xGMI"), through the C library's own entry points - hufgpu_encode_sharded / hufgpu_decode_sharded
+        (include/huffman_gpu.h): grouped ncclSend / ncclRecv to computed offsets on a communicator of the library's
+        own.  Those calls have no timeout, so they run on a thread this one gives up on after BENCH_LEG_TIMEOUT x 8
+        seconds: the line is then printed without the figure.  If RCCL cannot be had from C (no library), the same
+        movements through torch.distributed (`root_placement_torch`)."""
+        import threading
+        from libhuffman_amd import sharding
+        a, torch, dist, codec = self.a, self.torch, self.dist, self.codec
+        world, rank, dev = self.world, self.rank, self.dev
+        try:
+            group = sharding.ShardGroup(codec, group=self.ctl)
+            made = 1
+        except Exception as e:
+            group, made, why = None, 0, repr(e)
+        if int(self.ctl_reduce(made, dist.ReduceOp.MIN)) == 0:
+            if group is not None:
+                group.close()
+            rec = self.root_placement_torch(workload, steps)
+            if rec is not None:
+                rec["mover"] = "torch.distributed all_to_all_single (the C library could not load RCCL)"
+            return rec
+        bs = a.blocksize or ((1 << 20) if workload == "logtext" else 65536)
+        n_total = a.bytes_per_gpu * world
+        relaxed = workload == "uniform256"
+        alloc_ok, alloc_err = 1, None
+        full = stream = result = None
+        try:
+            if rank == 0:
+                full = self.make_input(workload, n_total, 0)
+                stream = torch.empty(codec.encode_bound(n_total, bs), dtype=torch.uint8, device=dev)
+                result = torch.empty(n_total, dtype=torch.uint8, device=dev)
+        except Exception as e:
+            alloc_ok, alloc_err = 0, repr(e)
+        if int(self.ctl_reduce(alloc_ok, dist.ReduceOp.MIN)) == 0:
+            group.close()
+            return {"error": "allocation failed on some rank: %s" % alloc_err} if rank == 0 else None
+        names = ("scatter_in", "encode", "sizes_allgather", "gather_stream", "plan", "scatter_stream", "decode", "gather_out")
+        box = {"legs": {k: 0.0 for k in names}, "total": 0.0, "error": None, "stream_bytes": 0, "lens": None}
+
+        def run():
+            try:
+                torch.cuda.set_device(dev)
+                for k in range(steps + 1):
+                    if k == 1:                          # step 0 is the warm-up (RCCL sets its channels up)
+                        box["legs"] = {key: 0.0 for key in names}
+                        box["total"] = 0.0
+                    torch.cuda.synchronize()
+                    self.ctl_barrier()
+                    t0 = time.perf_counter()
+                    total, lens, l1 = group.encode(full, n_total, bs, stream, root=0, legs=True)
+                    _, l2 = group.decode(stream, total, n_total, bs, result, root=0, own_layout=True, relaxed=relaxed, legs=True)
+                    torch.cuda.synchronize()
+                    self.ctl_barrier()
+                    box["total"] += time.perf_counter() - t0
+                    for name, ms in zip(names, list(l1) + list(l2)):
+                        box["legs"][name] += ms * 1e-3
+                    box["stream_bytes"], box["lens"] = total, lens
+            except Exception as e:
+                box["error"] = repr(e)
+
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("BENCH_LEG_TIMEOUT", "120")) * 8)
+        if th.is_alive():
+            raise TimeoutError("hufgpu_encode_sharded / hufgpu_decode_sharded did not come back")
+        if box["error"]:
+            raise RuntimeError(box["error"])
+        group.close()
+        legs_all = [None] * world
+        dist.all_gather_object(legs_all, {k: round(v / max(steps, 1) * 1e3, 3) for k, v in box["legs"].items()}, group=self.ctl)
+        tmax_s = self.ctl_reduce(box["total"], dist.ReduceOp.MAX)
+        ok = True
+        if rank == 0 and not a.no_verify:
+            ok = bool(torch.equal(result, full))
+        if rank != 0:
+            return None
+        sec = tmax_s / steps
+        return {"value": round(n_total / GIB / sec, 3), "unit": "GiB/s", "ms_per_step": round(sec * 1e3, 3),
+                "steps": steps, "bit_exact_roundtrip": ok, "stream_bytes": int(box["stream_bytes"]),
+                "mover": "hufgpu_encode_sharded + hufgpu_decode_sharded (C ABI: grouped ncclSend/ncclRecv on the library's own communicator)",
+                "legs_ms_rank0": {key: round(v / steps * 1e3, 3) for key, v in box["legs"].items()},
+                "legs_ms_per_rank": legs_all,
+                "note": "input and output live on rank 0; every leg is synchronised (no overlap between legs); decode with "
+                        "the block index and sub-index every rank kept from the encode (HUFGPU_SHARD_OWN_LAYOUT)"}
+
+    def root_placement_torch(self, workload: str, steps: int) -> dict:
+        """The same movements through torch.distributed: scatter input shards -> encode -> gather compressed shards
+        (+ the size all-gather that places them) -> scatter them again -> decode -> gather the output.  Each
         movement is ONE variable-size all-to-all (grouped send/recv inside RCCL; RCCL has no gatherv)."""
         from libhuffman_amd import sharding
         a, torch, dist, codec = self.a, self.torch, self.dist, self.codec

@@ -57,6 +57,7 @@ int hufgpu_device_count(void);
 /* Create/destroy a context bound to `device`. HUF_ERROR_FATAL when there is no such GPU. */
 int hufgpu_ctx_create(hufgpu_ctx_t **ctx, int device);
 int hufgpu_ctx_destroy(hufgpu_ctx_t *ctx);
+int hufgpu_ctx_device(const hufgpu_ctx_t *ctx);      /* the device ordinal the context was made for (-1: no context) */
 
 /* Text of the last failure on this context (or of the last global failure if ctx == NULL). */
 const char *hufgpu_last_error(const hufgpu_ctx_t *ctx);
@@ -121,6 +122,57 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
                       const uint64_t *d_block_offsets, uint64_t raw_size, uint64_t blocksize,
                       const void *d_sub_index, void *d_out, uint64_t out_cap, uint32_t flags,
                       uint64_t *raw_len, void *stream);
+
+/*
+ * One logical input over the GPUs of a node: RCCL scatter / gather of block buffers.
+ * Blocks are independent (src/encoder.c:288-374 resets all state between blocks), so rank r of G owns a contiguous range
+ * of ceil(nblocks / G) blocks (hufgpu_shard_range) and the codec needs no collective; the data starts and ends on ONE
+ * rank, the root.  Every rank of the communicator makes the same call with the same n_total, blocksize, root and flags;
+ * the pointers count on the root only (NULL elsewhere).  Each movement is one group of ncclSend / ncclRecv of exactly-sized
+ * buffers to computed offsets (RCCL has no scatterv / gatherv) on the object's own stream, plus all-gathers of one or two
+ * words a rank: who is ready, every shard's compressed size (rank order = stream order: shard r starts at the sum of the
+ * sizes in front of it), every rank's decode result.  The gathered stream is the reference's, byte for byte - the one a
+ * single hufgpu_encode() of the whole input writes.  RCCL is looked up with dlopen at the first call (HUF_GPU_RCCL_LIB,
+ * else librccl.so.1): without it these entry points return HUF_ERROR_FATAL and hufgpu_shard_last_error(NULL) says why.
+ * No call here has a timeout: a rank that never arrives holds the others inside RCCL.
+ *
+ *   hufgpu_shard_create   : nccl_comm = an existing ncclComm_t of the ranks (not destroyed with the object; nranks and rank
+ *                           are the communicator's), or NULL: then the object makes its own from `id`
+ *                           (HUFGPU_SHARD_ID_BYTES from hufgpu_shard_unique_id() on one rank, handed to all by the caller),
+ *                           nranks and rank.  ctx = this rank's context: its device is the rank's GPU, and no other work
+ *                           may be in flight on it during a sharded call.
+ *   hufgpu_encode_sharded : d_in (root: n_total bytes) -> d_stream (root: room for hufgpu_encode_bound(n_total, blocksize)
+ *                           bytes); *stream_len and shard_lens[nranks] (host, optional) are filled on EVERY rank.
+ *                           HUFGPU_SHARD_INDEX: d_block_offsets (root: hufgpu_block_count(n_total, blocksize) + 1 words)
+ *                           receives the block index of the whole stream.
+ *   hufgpu_decode_sharded : d_stream + d_block_offsets (root) -> d_out (root: n_total bytes).  The stream is cut into
+ *                           nranks shares of about equal compressed BYTES at block borders (hufgpu_shard_plan_decode);
+ *                           a rank decodes its blocks from the block index alone.  HUFGPU_SHARD_OWN_LAYOUT: the stream is
+ *                           the one this object's last hufgpu_encode_sharded (same root, n_total, blocksize) produced -
+ *                           the shards are cut as they were then and every rank uses the block index and the sub-index
+ *                           it kept (d_block_offsets is not read).  Errors: the first failing rank's in stream order,
+ *                           returned on every rank; *raw_len = bytes in front of it (as hufgpu_decode()).
+ *   legs_ms               : optional, 4 doubles: host milliseconds of the call's four legs (scatter, codec, control words,
+ *                           gather; decode: plan, scatter, codec + results, gather), each synchronised.
+ */
+typedef struct hufgpu_shard hufgpu_shard_t;
+#define HUFGPU_SHARD_ID_BYTES   128      /* sizeof(ncclUniqueId) */
+#define HUFGPU_SHARD_INDEX      0x100u
+#define HUFGPU_SHARD_OWN_LAYOUT 0x200u
+int hufgpu_shard_unique_id(void *id);
+int hufgpu_shard_create(hufgpu_shard_t **sh, hufgpu_ctx_t *ctx, void *nccl_comm, const void *id, int nranks, int rank);
+int hufgpu_shard_destroy(hufgpu_shard_t *sh);
+int hufgpu_shard_info(const hufgpu_shard_t *sh, int *nranks, int *rank);
+const char *hufgpu_shard_last_error(const hufgpu_shard_t *sh);
+int hufgpu_shard_range(uint64_t n_total, uint64_t blocksize, int rank, int nranks, uint64_t *lo, uint64_t *hi);
+/* first_block[nranks + 1] from a host copy of the block index (nblocks + 1 offsets, the last = the stream's length) */
+int hufgpu_shard_plan_decode(const uint64_t *block_offsets, uint64_t nblocks, int nranks, uint64_t *first_block);
+int hufgpu_encode_sharded(hufgpu_shard_t *sh, int root, const void *d_in, uint64_t n_total, uint64_t blocksize,
+                          uint32_t flags, void *d_stream, uint64_t stream_cap, uint64_t *d_block_offsets,
+                          uint64_t *stream_len, uint64_t *shard_lens, double *legs_ms);
+int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d_stream, uint64_t stream_len,
+                          const uint64_t *d_block_offsets, uint64_t n_total, uint64_t blocksize, uint32_t flags,
+                          void *d_out, uint64_t out_cap, uint64_t *raw_len, double *legs_ms);
 
 /* A small encode with one synchronisation instead of three: h_in_pinned (n bytes, pinned host memory) -> d_in ->
  * encode -> h_out_pinned: the stream's first hufgpu_encode_bound(n, blocksize) bytes and, 8-byte aligned behind them,

@@ -17,7 +17,7 @@ import tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 SO_PATH = os.environ.get("HUF_LIB_PATH") or os.path.join(PKG, "libhuffman.so")   # override: tooling experiments only
-SOURCES = ["hufgpu_api.hip", "huf_host.cpp"]
+SOURCES = ["hufgpu_api.hip", "huf_host.cpp", "hufgpu_sharded.hip"]
 KERNEL_PARTS = ["util", "histogram", "tree", "offsets", "hist_tree", "hist_lanes", "pack", "hist_chunk", "pack_chunk", "decode", "decode_sub", "decode_fast", "spec_index", "discover", "fill"]
 DEPENDS = SOURCES + ["hufgpu_kernels.hip", "hufgpu_common.h",
                      os.path.join("..", "..", "include", "huffman.h"),
@@ -70,7 +70,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-Wall", "-Wno-unused-function"] + os.environ.get("HUF_EXTRA_FLAGS", "").split() + [   # tooling experiments only
            "-x", "hip", os.path.join(CSRC, "hufgpu_api.hip"),
            "-x", "hip", os.path.join(CSRC, "huf_host.cpp"),
-           "-o", SO_PATH + ".tmp", "-lpthread"]
+           "-x", "hip", os.path.join(CSRC, "hufgpu_sharded.hip"),
+           "-o", SO_PATH + ".tmp", "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     main = subprocess.Popen(cmd, start_new_session=True)        # own process group: hipcc's children die with it

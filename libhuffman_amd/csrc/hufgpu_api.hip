@@ -1256,6 +1256,8 @@ extern "C" int hufgpu_fill(hufgpu_ctx_t *ctx, void *d_out, uint64_t n, int kind,
     return HUFE_OK;
 }
 
+extern "C" int hufgpu_ctx_device(const hufgpu_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
 extern "C" int hufgpu_malloc(hufgpu_ctx_t *ctx, void **d_ptr, uint64_t bytes)
 {
     if (!ctx || !d_ptr) return HUFE_ARGUMENT;

@@ -575,12 +575,7 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     typedef const __attribute__((address_space(3))) uint32_t *lds_words;
     typedef __attribute__((address_space(3))) uint32_t *lds_words_w;
     typedef const __attribute__((address_space(3))) uint16_t *lds_halves;
-    typedef const __attribute__((address_space(1))) uint8_t *global_bytes;
     typedef uint32_t dwords4 __attribute__((ext_vector_type(4)));
-    typedef dwords4 dwords4_a4 __attribute__((aligned(4)));                       /* 16 bytes at a 4-byte aligned address */
-    typedef const __attribute__((address_space(1))) dwords4_a4 *global_q4;
-    typedef __attribute__((address_space(1))) uint8_t *global_out;
-    typedef __attribute__((address_space(1))) dwords4 *global_out4;
     /* The position of a lane: R = 32 * (number of the slice's last row) - position, position = bits from the first
      * bit of the lane's word 0, rows numbered from LDS address 0 in units of 256 bytes (the slices lie at multiples of
      * that).  Word g lies at row last - g, so R >> 5 IS the row of word g + 1 - the lower of the two rows that hold
@@ -601,7 +596,6 @@ __device__ __forceinline__ bool decode_payload_sub(DsubShared<THREADS> &sh, cons
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(lds_halves)sh.lut;
     const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
     const uintptr_t cout_a = (uintptr_t)uni64((uint64_t)(uintptr_t)(gout + sym0));           /* the chunk's first output byte */
-    const global_out cout = (global_out)cout_a;
     const uint64_t end_a = uni64((uint64_t)pay_a + readable);                                 /* the stream's end */
 
     /* A tile's set-up.  The lane's column starts with the aligned 32-bit word of MEMORY that holds the lane's first

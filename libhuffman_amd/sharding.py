@@ -8,8 +8,12 @@ sizes of ranks < r).  Moving whole shards (scatter of the input from a root, gat
 compressed shards to a root) is offered for callers whose data starts or ends on one GPU; RCCL
 has no gatherv, so it is grouped send/recv of exactly-sized buffers.
 
-Everything here works with any torch.distributed backend: "nccl" (= RCCL over xGMI) on the
-GPUs, "gloo" in the CPU tests.
+The functions of this module work with any torch.distributed backend: "nccl" (= RCCL over xGMI) on the
+GPUs, "gloo" in the CPU tests.  On the GPUs the movements themselves are the C library's
+(`ShardGroup` = hufgpu_encode_sharded / hufgpu_decode_sharded, include/huffman_gpu.h: grouped
+ncclSend / ncclRecv to computed offsets and the size all-gather, on a communicator of its own); the
+range and plan arithmetic here and there is the same (`shard_range` = hufgpu_shard_range,
+`plan_decode_ranges` = hufgpu_shard_plan_decode; tests/test_sharding.py holds them against each other).
 """
 from __future__ import annotations
 
@@ -35,6 +39,90 @@ def _all_to_all(out, inp, out_split, in_split, group, timeout: Optional[float]):
         if "timeout" in text or "timed out" in text:
             raise TimeoutError("variable-size all-to-all did not complete in %.0f s: %s" % (timeout, e)) from e
         raise                                                  # (an invalid split, a peer's abort, out of memory: as the backend says it)
+
+
+SHARD_INDEX, SHARD_OWN_LAYOUT = 0x100, 0x200          # include/huffman_gpu.h
+
+
+class ShardGroup:
+    """The ranks of one node as the C library sees them: a communicator of the library's own (its
+    unique id travels through the torch.distributed group that is there anyway, as 128 bytes) and
+    this rank's scratch shards.  `codec` = this rank's GpuCodec; every rank of `group` makes one."""
+
+    def __init__(self, codec, group=None, id_bytes: Optional[bytes] = None, nranks: Optional[int] = None,
+                 rank: Optional[int] = None):
+        import ctypes as C
+        self._C, self.codec, self.lib = C, codec, codec.lib
+        self._sh = C.c_void_p()
+        if id_bytes is None:                              # through torch.distributed: rank 0 makes the id
+            rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+            box = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                err = self.lib.hufgpu_shard_unique_id(buf)
+                box[0] = (err, buf.raw, self.lib.hufgpu_shard_last_error(None).decode())
+            dist.broadcast_object_list(box, src=0, group=group)
+            err, id_bytes, why = box[0]
+            if err:
+                raise RuntimeError("RCCL is not available to the C library: %s" % why)
+        self.nranks, self.rank = int(nranks), int(rank)
+        err = self.lib.hufgpu_shard_create(C.byref(self._sh), codec._ctx, None, id_bytes, self.nranks, self.rank)
+        if err:
+            raise RuntimeError("hufgpu_shard_create failed (%d): %s" % (err, self.lib.hufgpu_shard_last_error(None).decode()))
+
+    def close(self):
+        if self._sh:
+            self.lib.hufgpu_shard_destroy(self._sh)
+            self._sh = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, err: int, what: str):
+        if err:
+            from .codec import HuffmanGpuError
+            raise HuffmanGpuError(err, what, self.lib.hufgpu_shard_last_error(self._sh).decode())
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else t.data_ptr()
+
+    def encode(self, data: Optional[torch.Tensor], n_total: int, blocksize: int, stream: Optional[torch.Tensor],
+               root: int = 0, index: Optional[torch.Tensor] = None, with_index: bool = False, legs: bool = False):
+        """data / stream / index: the root's tensors (None elsewhere); with_index (the same on every rank): the
+        root's `index` (int64, block count + 1) receives the block index of the whole stream.  Returns (stream
+        length, shard lengths[, legs in ms]) on every rank."""
+        C = self._C
+        total = C.c_uint64()
+        lens = (C.c_uint64 * self.nranks)()
+        ms = (C.c_double * 4)() if legs else None
+        torch.cuda.current_stream(self.codec.tdev).synchronize()         # (the call works on its own stream)
+        err = self.lib.hufgpu_encode_sharded(self._sh, root, self._ptr(data), n_total, blocksize,
+                                             SHARD_INDEX if with_index else 0,
+                                             self._ptr(stream), stream.numel() if stream is not None else 0,
+                                             self._ptr(index), C.byref(total), lens, ms)
+        self._check(err, "hufgpu_encode_sharded")
+        return (int(total.value), [int(x) for x in lens]) + ((list(ms),) if legs else ())
+
+    def decode(self, stream: Optional[torch.Tensor], stream_len: int, n_total: int, blocksize: int,
+               out: Optional[torch.Tensor], root: int = 0, index: Optional[torch.Tensor] = None,
+               own_layout: bool = False, relaxed: bool = False, legs: bool = False):
+        """own_layout (the same on every rank): the stream is the one this object's last encode made - every rank
+        kept its block index and sub-index; else `index` = the root's block index of the stream.  Returns bytes
+        decoded[, legs in ms]."""
+        C = self._C
+        raw = C.c_uint64()
+        ms = (C.c_double * 4)() if legs else None
+        flags = (1 if relaxed else 0) | (SHARD_OWN_LAYOUT if own_layout else 0)
+        torch.cuda.current_stream(self.codec.tdev).synchronize()
+        err = self.lib.hufgpu_decode_sharded(self._sh, root, self._ptr(stream), stream_len, self._ptr(index), n_total,
+                                             blocksize, flags, self._ptr(out), out.numel() if out is not None else 0,
+                                             C.byref(raw), ms)
+        self._check(err, "hufgpu_decode_sharded")
+        return (int(raw.value), list(ms)) if legs else int(raw.value)
 
 
 def shard_range(n_total: int, blocksize: int, rank: int, world: int) -> Tuple[int, int]:

@@ -964,6 +964,8 @@ def test_bench_runs_over_rccl_with_one_rank(torch_mod):
     rp = d["root_placement"]
     assert "error" not in rp, rp
     assert rp["bit_exact_roundtrip"] is True and rp["value"] > 0
+    assert rp["mover"].startswith("hufgpu_encode_sharded"), rp["mover"]      # the C library's own RCCL calls, not torch's
+    assert set(rp["legs_ms_rank0"]) >= {"scatter_in", "encode", "gather_stream", "scatter_stream", "decode", "gather_out"}
 
 
 def test_bench_configs3_share_over_rccl_with_one_rank(torch_mod):

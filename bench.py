@@ -603,21 +603,16 @@ class Bench:
         """The path with the data starting and ending on rank 0 (north_star: "RCCL scatter/gather of block buffers
         over xGMI"), through the C library's own entry points - hufgpu_encode_sharded / hufgpu_decode_sharded
         (include/huffman_gpu.h): grouped ncclSend / ncclRecv to computed offsets on a communicator of the library's
-        own.  Those calls have no timeout, so they run on a thread this one gives up on after BENCH_LEG_TIMEOUT x 8
+        own.  Those calls have no timeout, so they run on a thread this one gives up on after BENCH_LEG_TIMEOUT x 1.5
         seconds: the line is then printed without the figure.  If RCCL cannot be had from C (no library), the same
         movements through torch.distributed (`root_placement_torch`)."""
         import threading
         from libhuffman_amd import sharding
         a, torch, dist, codec = self.a, self.torch, self.dist, self.codec
         world, rank, dev = self.world, self.rank, self.dev
-        try:
-            group = sharding.ShardGroup(codec, group=self.ctl)
-            made = 1
-        except Exception as e:
-            group, made, why = None, 0, repr(e)
+        import ctypes
+        made = 1 if codec.lib.hufgpu_shard_unique_id(ctypes.create_string_buffer(128)) == 0 else 0     # can the C library reach RCCL?
         if int(self.ctl_reduce(made, dist.ReduceOp.MIN)) == 0:
-            if group is not None:
-                group.close()
             rec = self.root_placement_torch(workload, steps)
             if rec is not None:
                 rec["mover"] = "torch.distributed all_to_all_single (the C library could not load RCCL)"
@@ -635,7 +630,6 @@ class Bench:
         except Exception as e:
             alloc_ok, alloc_err = 0, repr(e)
         if int(self.ctl_reduce(alloc_ok, dist.ReduceOp.MIN)) == 0:
-            group.close()
             return {"error": "allocation failed on some rank: %s" % alloc_err} if rank == 0 else None
         names = ("scatter_in", "encode", "sizes_allgather", "gather_stream", "plan", "scatter_stream", "decode", "gather_out")
         box = {"legs": {k: 0.0 for k in names}, "total": 0.0, "error": None, "stream_bytes": 0, "lens": None}
@@ -643,6 +637,7 @@ class Bench:
         def run():
             try:
                 torch.cuda.set_device(dev)
+                group = sharding.ShardGroup(codec, group=self.ctl)       # (ncclCommInitRank: every rank, or nobody comes back)
                 for k in range(steps + 1):
                     if k == 1:                          # step 0 is the warm-up (RCCL sets its channels up)
                         box["legs"] = {key: 0.0 for key in names}
@@ -658,17 +653,17 @@ class Bench:
                     for name, ms in zip(names, list(l1) + list(l2)):
                         box["legs"][name] += ms * 1e-3
                     box["stream_bytes"], box["lens"] = total, lens
+                group.close()
             except Exception as e:
                 box["error"] = repr(e)
 
         th = threading.Thread(target=run, daemon=True)
         th.start()
-        th.join(float(os.environ.get("BENCH_LEG_TIMEOUT", "120")) * 8)
+        th.join(float(os.environ.get("BENCH_LEG_TIMEOUT", "120")) * 1.5)     # (six steps of 8 GiB each way take seconds)
         if th.is_alive():
             raise TimeoutError("hufgpu_encode_sharded / hufgpu_decode_sharded did not come back")
         if box["error"]:
             raise RuntimeError(box["error"])
-        group.close()
         legs_all = [None] * world
         dist.all_gather_object(legs_all, {k: round(v / max(steps, 1) * 1e3, 3) for k, v in box["legs"].items()}, group=self.ctl)
         tmax_s = self.ctl_reduce(box["total"], dist.ReduceOp.MAX)
@@ -814,14 +809,18 @@ def c_api_by_size(lib, sizes, blocksize: int, budget_s: float = 6.0, relaxed_set
                 lib.huf_memclose(C.byref(r))
             for b in (bin_, bout, bback):
                 libc.free(b)
-            if calls >= 1 or n >= (64 << 20):          # (the first call of a size warms buffers and pages: not counted below 64 MiB)
+            # the first call of a size warms buffers and pages and is not counted - unless a call takes seconds (the
+            # reference on one core from 64 MiB on: two calls, both counted, the warm-up is nothing beside them)
+            if calls == 0:
+                skip_first = n < (64 << 20) or (t1 - t0) + (t3 - t2) < 0.5
+            if calls >= 1 or not skip_first:
                 t_enc += t1 - t0
                 t_dec += t3 - t2
             ok = ok and good
             calls += 1
-            if n >= (64 << 20) and calls >= 2:
+            if n >= (64 << 20) and calls >= (4 if skip_first else 2):
                 break
-        timed = calls if n >= (64 << 20) else calls - 1
+        timed = calls - 1 if skip_first else calls
         out[str(n)] = {"encode_us": round(t_enc / timed * 1e6, 1), "decode_us": round(t_dec / timed * 1e6, 1),
                        "GiBps": round(n * timed / GIB / (t_enc + t_dec), 5), "calls": timed, "roundtrip_ok": bool(ok)}
     return out

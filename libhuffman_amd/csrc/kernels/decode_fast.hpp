@@ -429,23 +429,45 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
      * not a leaf advances like one and is only remembered */
     uint32_t Q = p0 - 1u + qbase;
     uint32_t special = 0;
-    for (uint32_t k = 0; k < words; k++) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
-            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
-            const uint32_t l1 = (e1 >> 8) & 31u;
-            const uint32_t d2 = d1 << l1;
-            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));
-            special |= e1 | e2;
-            acc = __builtin_amdgcn_alignbit(e1, acc, 8);
-            acc = __builtin_amdgcn_alignbit(e2, acc, 8);
-            Q += l1 + ((e2 >> 8) & 31u);
-        }
+    /* four symbols = one word: two windows of two look-ups */
+#define DFAST_WORD(ACC)                                                                                        \
+    {                                                                                                         \
+        uint32_t pr_[2];                                                                                      \
+        _Pragma("unroll")                                                                                     \
+        for (int j = 0; j < 2; j++) {                                                                         \
+            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);                                 \
+            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);                                   \
+            const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));            \
+            const uint32_t l1 = (e1 >> 8) & 31u;                                                               \
+            const uint32_t d2 = d1 << l1;                                                                     \
+            const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d2 >> 19) & 0x1ffeu));            \
+            special |= e1 | e2;                                                                               \
+            pr_[j] = __builtin_amdgcn_perm(e2, e1, 0x0c0c0400u);          /* the two bytes */                  \
+            Q += l1 + ((e2 >> 8) & 31u);                                                                      \
+        }                                                                                                     \
+        ACC = __builtin_amdgcn_perm(pr_[1], pr_[0], 0x05040100u);                                             \
+    }
+    /* Round 5: sixteen symbols a store.  A wave's store instruction is 64 addresses in 64 different cache lines whatever
+     * its width, and the address path takes them one by one: with a dword a lane and store the write pass was four
+     * times as long as the scan that walks the same bits (tools/phase_fast.py: 40 % of the kernel). */
+    typedef uint32_t unaligned_q4 __attribute__((ext_vector_type(4), aligned(1)));
+    uint32_t k = 0;
+    for (; k + 4u <= words; k += 4u) {
+        uint32_t w0, w1, w2, w3;
+        DFAST_WORD(w0)
+        DFAST_WORD(w1)
+        DFAST_WORD(w2)
+        DFAST_WORD(w3)
+        unaligned_q4 v4;
+        v4.x = w0; v4.y = w1; v4.z = w2; v4.w = w3;
+        *reinterpret_cast<unaligned_q4 *>(g + head + 4u * k) = v4;
+    }
+    for (; k < words; k++) {
+        uint32_t acc;
+        DFAST_WORD(acc)
         gw[k] = acc;
     }
+#undef DFAST_WORD
     uint32_t p1 = Q + 1u - qbase;
     if (__builtin_expect(__ballot((special & 0xC000u) != 0u) != 0ull, 0)) {
         if (special & 0xC000u) {                     /* a long code (or worse) among them: the words again, step by step */

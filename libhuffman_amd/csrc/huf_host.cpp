@@ -1341,7 +1341,7 @@ static void dx_unregister_input(void *base)
 
 /* bytes a round: HUF_GPU_ROUND_MB, else an eighth of the call between 8 and 32 MiB (a call of 64 MiB in eight rounds
  * still overlaps seven of them; a round much below 8 MiB is a piece or two for ten lanes) */
-static uint64_t dx_round_bytes(uint64_t total)
+static uint64_t dx_round_bytes(uint64_t total, uint64_t blocksize)
 {
     static long env = -1;
     if (env < 0) { const char *e = getenv("HUF_GPU_ROUND_MB"); env = (e && atoi(e) > 0) ? atoi(e) : 0; }
@@ -1351,6 +1351,14 @@ static uint64_t dx_round_bytes(uint64_t total)
     uint64_t r = (total / 4) & ~(((uint64_t)1 << 20) - 1);
     if (r < ((uint64_t)16 << 20)) r = (uint64_t)16 << 20;
     if (r > ((uint64_t)32 << 20)) r = (uint64_t)32 << 20;
+    /* A block is one workgroup's work up to 2 MiB (encode) / 4 MiB (decode): a round of 32 MiB in blocks of 1 MiB - the Python
+     * layer's default - is 32 workgroups on 256 CUs, and a round then takes as long as ONE block does (1 GiB of log text: 16-20 ms
+     * of an encode's 30 and 25 ms of a decode's 42 were that).  Rounds of at least 128 blocks, 256 MiB at most. */
+    if (blocksize > ((uint64_t)128 << 10) && blocksize < ((uint64_t)4 << 20)) {
+        uint64_t want = 128 * blocksize;
+        if (want > ((uint64_t)256 << 20)) want = (uint64_t)256 << 20;
+        if (want > r) r = want;
+    }
     return r;
 }
 #define DX_MIN_BYTES ((uint64_t)32 << 20)      /* below this the rounds are too few to overlap anything */
@@ -1914,7 +1922,7 @@ static int encode_duplex(huf_encoder_t *enc, membuf_t *rmem, membuf_t *wmem, huf
 {
     const uint64_t length = enc->config->length, blocksize = enc->config->blocksize;
     if (!rmem || !wmem || !duplex_enabled() || length < DX_MIN_BYTES || rmem->len - rmem->off < length || blocksize == 0) return 0;
-    uint64_t R = dx_round_bytes(length);
+    uint64_t R = dx_round_bytes(length, blocksize < ((uint64_t)2 << 20) ? blocksize : 0)   /* (from 2 MiB on the encoder cuts blocks into chunks itself) */;
     if (R < blocksize) R = blocksize;
     R -= R % blocksize;
     if (length <= R + R / 2) return 0;
@@ -2380,7 +2388,10 @@ static int decode_duplex(huf_decoder_t *dec, membuf_t *rmem, membuf_t *wmem, uin
     const uint64_t length = dec->config->length;
     const uint64_t left = rmem->len - rmem->off;
     const uint64_t total = length < left ? length : left;
-    const uint64_t R = dx_round_bytes(total);
+    /* (the first block's length field stands for the stream's block size: a hint for the rounds' size, nothing else) */
+    uint64_t first_len = 0;
+    if (total >= 8) memcpy(&first_len, (const char *)*rmem->buf + rmem->off, 8);
+    const uint64_t R = dx_round_bytes(total, first_len);
     if (total < DX_MIN_BYTES || total <= R + R / 2) return 0;
     dx_pool_t *P = dx_get();
     if (!P) return 0;

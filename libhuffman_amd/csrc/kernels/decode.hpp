@@ -168,13 +168,15 @@ template <int THREADS>
 struct DecShared {
     static constexpr int ENT = HUF_TREE_MAX + 1;
     static constexpr int COLS = THREADS + DEC_XCOLS;
-    uint32_t lr[ENT];                    /* children of entry i: left in the low half, right in the high half, DEC_NULL = none */
     uint16_t lut[1 << DEC_LUT_BITS];
     __attribute__((aligned(16))) uint32_t pay[DEC_SUB_WORDS * COLS];  /* segment word i at pay[(i % W) * COLS + i / W]: lane-consecutive = bank-consecutive
                                             (a padded linear layout has a cheaper address but costs 2 KiB = one workgroup per CU) */
     uint16_t mark[DEC_SUB_WORDS][THREADS];  /* (codewords before << 5 | offset) of lane l's first visit to each word */
     int16_t ent[ENT];                    /* the tree's entries (behind the marks: decode_fast_kernel's table of pairs runs on into it when the
                                             block has no codes that need the entries, decode_fast.hpp) */
+    __attribute__((aligned(4))) uint32_t lr[ENT];   /* children of entry i: left in the low half, right in the high half, DEC_NULL = none.  (Behind `ent`
+                                            since round 5: blocks without `long` codes need neither after the tables are built, and decode_fast's
+                                            column stage + table of pairs run on into both.) */
     __attribute__((aligned(16))) uint32_t wend[THREADS / 64];   /* end position of the last lane of each wave (neighbours use shuffles).  (Aligned: `ent` in
                                             front of it is not a multiple of 16 bytes, and decode_sub reads wtile[] sixteen bytes at a time.) */
     uint32_t part[THREADS / 64];

@@ -19,6 +19,9 @@ namespace hufgpu {
  * the HBM roofline).  This is the same idea without the bookkeeping, verified instead of proven, with
  * decode_fix_kernel (= the exact decoder) behind it for every block where anything is off:
  *
+ *   - (round 5: blocks without codes of more than 12 bits whose payload the shorter shares do not cut into more segments
+ *     stage every lane's share in a COLUMN of its own - DFAST_COL_ROWS below; what follows describes the linear stage, the
+ *     passes are the same on both: decode_payload_fast_impl<THREADS, COL>)
  *   - the payload is staged LINEARLY in segments of 512 x 288 bits; lane i owns the codewords that start
  *     in its 288 bits.  288 = 9 words: lanes that read "their" word k touch words 9 i + k - 64 different
  *     banks' worth of addresses, no conflicts, no interleaved layout, and the 32 bits at a position are one
@@ -43,6 +46,15 @@ namespace hufgpu {
                                                        rescans as long as its slowest lane - zipf255 1.87 -> 2.12 ms; codes of one length,
                                                        uniform bytes, never fall into step at all) */
 #define DFAST_MAX_ROUNDS 64
+/* Round 5: blocks without `long` codes stage every lane's share in a COLUMN of its own (decode_sub.hpp's layout: word r of the
+ * lane at row r of its wave's slice, a row = the 64 lanes' words side by side): a lane's window read - two dwords at a
+ * data-dependent word - then falls into the lane's own bank whatever the other lanes' positions are (ds_read2st64_b32: 4 LDS
+ * cycles where the linear stage's took ~10).  A lane loads its own words from memory (three 16-byte loads at its 4-byte
+ * aligned address; neighbours overlap by a word, from the vector cache).  Shares are at most 256 bits there: the column holds
+ * the word with the bit in front of the share's first (positions are kept minus one), the share, the window behind its last
+ * codeword start and the up to three symbols a lane decodes beyond its own to store a whole word - eleven rows. */
+#define DFAST_COL_ROWS 11u
+#define DFAST_COL_SUB_BITS 256u
 #ifndef DFAST_PAIRS_FROM
 #define DFAST_PAIRS_FROM 32768u                      /* symbols of a block from which its scans read the table of pairs (dfast_pair_table) */
 #endif
@@ -57,15 +69,20 @@ template <int THREADS>
 struct DfastLds {
     static constexpr uint32_t AREA_WORDS = (uint32_t)((sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark)) / sizeof(uint32_t));
     static constexpr uint32_t SEG_WORDS = (uint32_t)THREADS * DFAST_SUBW;
-    static constexpr uint32_t STAGE_WORDS = SEG_WORDS + DFAST_SLACK_WORDS;
+    static constexpr uint32_t STAGE_WORDS = SEG_WORDS + DFAST_SLACK_WORDS;                     /* the linear stage */
+    static constexpr uint32_t COL_WORDS = (uint32_t)THREADS * DFAST_COL_ROWS;                   /* the column stage: [wave][row][lane] */
+    static constexpr uint32_t AHEAD_WORDS = COL_WORDS > STAGE_WORDS ? COL_WORDS : STAGE_WORDS;  /* what lies in front of the table of pairs */
     static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
     static_assert(STAGE_WORDS + 4u <= AREA_WORDS, "the linear stage fits the area of the interleaved stage and its marks");
     static_assert(offsetof(DecShared<THREADS>, pay) % 16 == 0, "16-byte stage stores");
     /* the table of pairs (dfast_pair_table) behind the stage: the rest of the marks' area and the first entries of `ent` */
-    static constexpr uint32_t PAIR_WORD = STAGE_WORDS + 4u;
+    static constexpr uint32_t PAIR_WORD = AHEAD_WORDS + 4u;
     static constexpr uint32_t PAIR_WORDS = (1u << DEC_LUT_BITS) / 2u;
     static_assert(offsetof(DecShared<THREADS>, ent) == offsetof(DecShared<THREADS>, mark) + sizeof(DecShared<THREADS>::mark), "ent runs on from the marks");
-    static_assert((PAIR_WORD + PAIR_WORDS) * 4u <= sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark) + sizeof(DecShared<THREADS>::ent), "the pairs fit");
+    static_assert(offsetof(DecShared<THREADS>, lr) == offsetof(DecShared<THREADS>, ent) + sizeof(DecShared<THREADS>::ent), "lr runs on from ent");
+    static_assert((PAIR_WORD + PAIR_WORDS) * 4u <= sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark) + sizeof(DecShared<THREADS>::ent) + sizeof(DecShared<THREADS>::lr),
+                  "the pairs fit (they run on into ent and lr: blocks that have pairs have no long codes, and nothing else reads those two once the tables stand)");
+
     static_assert((PAIR_WORD * 4u) % 16u == 0u, "16-byte stores of the pairs");
     __device__ static __forceinline__ uint16_t *pairs(DecShared<THREADS> &sh) { return reinterpret_cast<uint16_t *>(sh.pay + PAIR_WORD); }
 };
@@ -81,16 +98,18 @@ __device__ unsigned long long g_dfast_dbg[16];
 
 /* 64-bit left-aligned bit buffer over the linearly staged payload words (big-endian words): the edges of a
  * lane's output and the step-by-step path */
-struct LinReader {
-    const uint32_t *st;
+template <bool COL>
+struct LinReaderT {
+    const uint32_t *st;  /* linear stage: its word 0; column stage: the lane's word 0 (positions are then the lane's own: bits from that word) */
     uint32_t hi, lo;
     int32_t avail;
     uint32_t gf;         /* next staged word to append */
+    __device__ __forceinline__ uint32_t word(uint32_t g) const { return COL ? st[64u * g] : st[g]; }
 
     __device__ __forceinline__ void load(uint32_t pos)
     {
         const uint32_t g = pos >> 5, off = pos & 31u;
-        const uint64_t b = (((uint64_t)st[g] << 32) | st[g + 1]) << off;
+        const uint64_t b = (((uint64_t)word(g) << 32) | word(g + 1)) << off;
         hi = (uint32_t)(b >> 32);
         lo = (uint32_t)b;
         avail = (int32_t)(64u - off);
@@ -107,13 +126,30 @@ struct LinReader {
     }
     __device__ __forceinline__ void refill()                   /* needs avail <= 32 */
     {
-        const uint64_t t = (uint64_t)st[gf] << (32 - avail);
+        const uint64_t t = (uint64_t)word(gf) << (32 - avail);
         hi |= (uint32_t)(t >> 32);
         lo |= (uint32_t)t;
         avail += 32;
         gf++;
     }
 };
+typedef LinReaderT<false> LinReader;
+
+/* the 32 bits at position register Q (decode_sub.hpp's convention: Q = position - 1 + a bias): linear stage - the bias is 8 x the
+ * stage's LDS byte address, the word pair lies at Q >> 3; column stage - the bias is minus the position of the lane's column
+ * word 0, the pair is rows Q >> 5 and + 1 of the column at LDS byte address cb (one ds_read2st64_b32) */
+typedef const __attribute__((address_space(3))) uint32_t *dfast_lds_words;
+typedef const __attribute__((address_space(3))) uint16_t *dfast_lds_halves;
+template <bool COL>
+__device__ __forceinline__ uint32_t dfast_bits_at(uint32_t Q, uint32_t cb)
+{
+    if (COL) {
+        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)(((Q >> 5) << 8) + cb);
+        return __builtin_amdgcn_alignbit(wp[0], wp[64], ~Q);
+    }
+    dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
+    return __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+}
 
 /* bit-serial walk behind a `long` table entry on the linear stage; result as dec_rare_packed */
 template <int THREADS>
@@ -136,12 +172,15 @@ __device__ __forceinline__ uint64_t dec_rare_lin(const DecShared<THREADS> &sh, c
 
 /* One table step of a lane (tables of dec_build_tables): returns the entry (low byte = symbol); *ok is cleared
  * when the lookup is not a codeword.  The rare paths sit behind one wave-uniform branch. */
-template <int THREADS>
-__device__ __forceinline__ uint32_t dfast_next(const DecShared<THREADS> &sh, LinReader &rd, uint32_t lim, bool &ok)
+template <int THREADS, bool COL>
+__device__ __forceinline__ uint32_t dfast_next(const DecShared<THREADS> &sh, LinReaderT<COL> &rd, uint32_t lim, bool &ok)
 {
     uint32_t e = sh.lut[rd.index()];
     if (__builtin_expect(__ballot(e >= DEC_E_BAD) != 0ull, 0)) {
-        if (e >= DEC_E_LONG) {
+        if (COL && e >= DEC_E_LONG) {                     /* (the column stage is for blocks without such entries) */
+            ok = false;
+            e = 0x0100u;
+        } else if (e >= DEC_E_LONG) {
             const uint64_t r = dec_rare_lin<THREADS>(sh, rd.st, e, rd.pos(), lim);
             if ((int)(r >> 40) == CW_OK) {
                 rd.load((uint32_t)r);
@@ -158,9 +197,6 @@ __device__ __forceinline__ uint32_t dfast_next(const DecShared<THREADS> &sh, Lin
     rd.consume(e >> 8);
     return e;
 }
-
-typedef const __attribute__((address_space(3))) uint32_t *dfast_lds_words;
-typedef const __attribute__((address_space(3))) uint16_t *dfast_lds_halves;
 
 /* Round 4, the table the scans of a block WITHOUT `long` entries read: what the next 12 bits hold as a whole.
  *   P[x] = (bits of the first codeword in the 12 bits x, and of the second if it lies completely inside) | (how many) << 12
@@ -201,10 +237,11 @@ __device__ __forceinline__ void dfast_pair_table(DecShared<THREADS> &sh)
  * - and not the end of whatever window crossed `hi`: two tracks that have met have the same codewords, not the
  * same windows, and an end that depends on the windows moves every lane to the right of a lane that moved.) */
 enum { DFAST_SINGLES = 0, DFAST_LONGS = 1, DFAST_PAIRS = 2 };
-template <int THREADS, int MODE>
-__device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr, uint32_t pair_addr,
+template <int THREADS, int MODE, bool COL>
+__device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t cb, uint32_t lut_addr, uint32_t pair_addr,
                                            uint32_t start, uint32_t hi, uint32_t lim, uint32_t *end, uint32_t *cnt)
 {
+    static_assert(!(COL && MODE == DFAST_LONGS), "long codes are walked on the linear stage");
     constexpr bool LONGS = MODE == DFAST_LONGS;
     uint32_t Q = start - 1u + qbase;                 /* (position - 1) + 8 x stage address: see decode_sub.hpp */
     const uint32_t hiQ = hi - 1u + qbase;
@@ -220,8 +257,7 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             DFAST_DBGW(9, 1);
             Qg = act ? Q : Qg;
             ng += act ? 1u : 0u;
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+            const uint32_t d1 = dfast_bits_at<COL>(Q, cb);
             const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
             const uint32_t l1 = (e1 >> 8) & 31u;
             const uint32_t d2 = d1 << l1;
@@ -231,8 +267,7 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             Q += l1 + ((e2 >> 8) & 31u);
         }
         if (ng != 0u) {
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg >> 3) & ~3u);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Qg);
+            const uint32_t d1 = dfast_bits_at<COL>(Qg, cb);
             const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
             const uint32_t l1 = (e1 >> 8) & 31u;
             const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(lut_addr + (((d1 << l1) >> 19) & 0x1ffeu));
@@ -255,8 +290,7 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             const bool act = Q < hiQ;
             if (!__any(act)) break;
             DFAST_DBGW(9, 1);
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+            const uint32_t d1 = dfast_bits_at<COL>(Q, cb);
             const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d1 >> 19) & 0x1ffeu));
             const uint32_t d2 = d1 << (e1 & 31u);      /* (v_lshlrev_b32 takes the low five bits itself) */
             const uint32_t e2 = *(dfast_lds_halves)(uintptr_t)(pair_addr + ((d2 >> 19) & 0x1ffeu));
@@ -273,8 +307,7 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
             /* the last window again: its codewords start at Qg, b1 (the first entry's second, if it has one), b2, b3 (the
              * second entry's second) and the window ends at b4 >= hi */
             const uint32_t Qg = Q0 + (Sg & 0xfffu);
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Qg >> 3) & ~3u);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Qg);
+            const uint32_t d1 = dfast_bits_at<COL>(Qg, cb);
             const uint32_t i1 = (d1 >> 19) & 0x1ffeu;
             const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(pair_addr + i1);
             const uint32_t a1 = (*(dfast_lds_halves)(uintptr_t)(lut_addr + i1) >> 8) & 31u;
@@ -298,8 +331,7 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
         const bool act = Q < hiQ;
         if (!__any(act)) break;
         DFAST_DBGW(9, 1);
-        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
-        const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+        const uint32_t d1 = dfast_bits_at<COL>(Q, cb);
         const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));
         uint32_t l1 = (e1 >> 8) & 31u;
         const uint32_t d2 = d1 << l1;
@@ -337,15 +369,15 @@ __device__ __forceinline__ void dfast_scan(const DecShared<THREADS> &sh, const u
  * dfast_run_at: does ONE codeword, repeated, fill the stage from bit `pos` to bit `hi` and a codeword further?
  * Returns its length (1..12), or 0.  (The 32 bits at pos + 32 k, k = 0..10; the string is periodic with period L
  * when every one of them, shifted on by L bits, is itself again.) */
-__device__ __forceinline__ uint32_t dfast_run_at(uint32_t qbase, uint32_t lut_addr, uint32_t pos, uint32_t hi)
+template <bool COL>
+__device__ __forceinline__ uint32_t dfast_run_at(uint32_t qbase, uint32_t cb, uint32_t lut_addr, uint32_t pos, uint32_t hi)
 {
     const uint32_t Q0 = pos - 1u + qbase;
     uint32_t w[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const uint32_t Q = Q0 + 32u * (uint32_t)k;
-        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);
-        w[k] = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);
+        w[k] = dfast_bits_at<COL>(Q, cb);
     }
     const uint32_t e = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((w[0] >> 19) & 0x1ffeu));
     const uint32_t L = e >> 8;
@@ -366,11 +398,12 @@ __device__ __forceinline__ uint32_t dfast_run_at(uint32_t qbase, uint32_t lut_ad
  * and a stretch of any length inside the wave settles in this round.  A guess that does not hold is found out like
  * any wrong start: by the neighbour's end in the next round.  Returns (start, end, count, moved) of the lane.
  * (Out of line: it runs in the rounds after the second only, and its registers are its own.) */
-__device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, bool changed, bool dead, uint32_t hi, uint32_t sb, uint32_t pay_rel,
+template <bool COL>
+__device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t cb, uint32_t lut_addr, bool changed, bool dead, uint32_t hi, uint32_t sb, uint32_t pay_rel,
                                              uint32_t start, uint32_t end, uint32_t cnt0)
 {
     const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t myL = (changed && start < hi) ? dfast_run_at(qbase, lut_addr, start, hi) : 0u;
+    const uint32_t myL = (changed && start < hi) ? dfast_run_at<COL>(qbase, cb, lut_addr, start, hi) : 0u;
     /* the nearest such lane to the left (max-scan of lane indices), its start and code length */
     int src = (myL != 0u) ? (int)lane : -1;
 #pragma unroll
@@ -387,7 +420,7 @@ __device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, 
         const uint32_t lo = hi - sb;
         const uint32_t back = (lo - P) % L;
         cand = lo + (back ? L - back : 0u);
-        pass = cand >= hi || (cand < pay_rel && dfast_run_at(qbase, lut_addr, cand, hi) == L);
+        pass = cand >= hi || (cand < pay_rel && dfast_run_at<COL>(qbase, cb, lut_addr, cand, hi) == L);
     }
     /* ... as far as every lane on the way agrees: the last lane that does not, against the source */
     int bad = (src >= 0 && src < (int)lane && !pass) ? (int)lane : -1;
@@ -409,14 +442,17 @@ __device__ __noinline__ uint4 dfast_run_jump(uint32_t qbase, uint32_t lut_addr, 
  * lane's first (the same values from whoever stores them), and they stay inside the block's output.  Its symbols then
  * need no step-by-step tail (up to three look-ups with a bit buffer and byte stores: a third of this pass); the position
  * behind its last symbol is the end its scan found, and the return value is not used. */
-template <int THREADS>
-__device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t lut_addr,
+template <int THREADS, bool COL>
+__device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, const uint32_t *stage, uint32_t qbase, uint32_t cb, uint32_t lut_addr,
                                                 uint32_t start, uint32_t quota, uint32_t lim, uint8_t *g, bool *ok_out, bool whole = false)
 {
+    /* (column stage: `stage` is the lane's column word 0 and org = the position of that word's first bit: the step-by-step
+     *  reader works in the lane's own positions) */
     bool ok = true;
-    LinReader rd;
+    const uint32_t org = COL ? 0u - qbase : 0u;                      /* (qbase = -org there) */
+    LinReaderT<COL> rd;
     rd.st = stage;
-    rd.load(start);
+    rd.load(start - org);
     /* (the words go out from the lane's first symbol on, wherever the output stands: 32-bit stores need no
      * alignment on gfx950, and the symbols in front of a 4-byte boundary, one step-by-step look-up each, cost as
      * much as the two words behind them) */
@@ -435,8 +471,7 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
         uint32_t pr_[2];                                                                                      \
         _Pragma("unroll")                                                                                     \
         for (int j = 0; j < 2; j++) {                                                                         \
-            dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);                                 \
-            const uint32_t d1 = __builtin_amdgcn_alignbit(wp[0], wp[1], ~Q);                                   \
+            const uint32_t d1 = dfast_bits_at<COL>(Q, cb);                                   \
             const uint32_t e1 = *(dfast_lds_halves)(uintptr_t)(lut_addr + ((d1 >> 19) & 0x1ffeu));            \
             const uint32_t l1 = (e1 >> 8) & 31u;                                                               \
             const uint32_t d2 = d1 << l1;                                                                     \
@@ -471,27 +506,60 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
     uint32_t p1 = Q + 1u - qbase;
     if (__builtin_expect(__ballot((special & 0xC000u) != 0u) != 0ull, 0)) {
         if (special & 0xC000u) {                     /* a long code (or worse) among them: the words again, step by step */
-            rd.load(p0);
+            rd.load(p0 - org);
             uint8_t *b = g + head;
             for (uint32_t c = 0; c < 4u * words; c++) {
-                b[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
+                b[c] = (uint8_t)dfast_next<THREADS, COL>(sh, rd, lim, ok);
                 if (rd.avail <= 32) rd.refill();
             }
-            p1 = rd.pos();
+            p1 = rd.pos() + org;
         }
     }
     if (__ballot(!whole)) {
         if (!whole) {
-            rd.load(p1);
+            rd.load(p1 - org);
             for (uint32_t c = head + 4u * words; c < quota; c++) {
-                g[c] = (uint8_t)dfast_next<THREADS>(sh, rd, lim, ok);
+                g[c] = (uint8_t)dfast_next<THREADS, COL>(sh, rd, lim, ok);
                 if (rd.avail <= 32) rd.refill();
             }
-            p1 = rd.pos();
+            p1 = rd.pos() + org;
         }
     }
     *ok_out = ok;
     return p1;
+}
+
+/* The column stage of a segment (blocks without long codes): lane t's column holds the payload words from the one with bit
+ * lo_t - 1 on (lo_t = the first bit of its share; lane 0: the segment's true first bit), DFAST_COL_ROWS of them, big-endian:
+ * twelve dwords at the lane's own 4-byte aligned address (the payload's bytes need not be aligned: one v_perm_b32 per word
+ * puts them right, as the linear stage does).  word0 = the index of the lane's first word among the segment's words (from
+ * seg0; -1 for a lane 0 whose share starts with the segment).  A lane whose words reach beyond `readable` takes them byte by
+ * byte with zeros behind the end (the stream's last segment). */
+template <int THREADS>
+__device__ __forceinline__ void dfast_stage_col(uint32_t *col, const uint8_t *pay, uint64_t seg0, uint64_t readable, int32_t word0, bool wanted)
+{
+    if (!wanted) return;
+    const int64_t first = (int64_t)(seg0 >> 3) + 4 * (int64_t)word0;       /* payload byte of the column's word 0 (-4: the block's tree ends there) */
+    uint32_t w[DFAST_COL_ROWS];
+    if (first + 4 * (int64_t)(DFAST_COL_ROWS + 1u) <= (int64_t)readable) {
+        struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
+        const uintptr_t a = (uintptr_t)((intptr_t)(uintptr_t)pay + (intptr_t)first);
+        const uint32_t m = (uint32_t)(a & 3u);
+        const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
+        const Q4 v0 = *reinterpret_cast<const Q4 *>(qw), v1 = *reinterpret_cast<const Q4 *>(qw + 4), v2 = *reinterpret_cast<const Q4 *>(qw + 8);
+        const uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
+#pragma unroll
+        for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) w[r] = __builtin_amdgcn_perm(d[r + 1], d[r], sel);
+    } else {
+#pragma unroll
+        for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) {
+            const int64_t off = first + 4 * (int64_t)r;
+            w[r] = off >= 0 ? load_be32(pay, (uint64_t)off, readable) : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) col[64u * r] = w[r];
 }
 
 /* The segment that begins at bit seg0 of the payload into the linear stage: need_words words, big-endian. */
@@ -536,9 +604,9 @@ __device__ __forceinline__ void dfast_stage(uint32_t *stage, const uint8_t *pay,
  * when block_len symbols were written and everything the in-order decoder would have checked held.
  * readable = bytes that may be loaded from `pay` on (to the end of the stream: what lies behind the block's
  * payload is never part of a track that passes the checks, so it need not be zeroed). */
-template <int THREADS>
-__device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
-                                    uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
+template <int THREADS, bool COL>
+__device__ __forceinline__ bool decode_payload_fast_impl(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                    uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, const bool longs, const bool pairs)
 {
     /* end_bits: the caller does not know where the payload ends (the raw-stream probe: pay_bytes = the rest of the stream) and
      * wants to be told.  hint_bytes (with end_bits): where it probably ends - the next header candidate; taken for the end
@@ -547,29 +615,14 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t *stage = sh.pay;                                          /* linear, runs on into the marks' area */
-    const uint32_t qbase = 8u * (uint32_t)(uintptr_t)(dfast_lds_words)stage;
+    /* linear stage: runs on into the marks' area; column stage: this lane's column, word 0 (its wave's slice: DFAST_COL_ROWS rows of 64 words) */
+    uint32_t *stage = COL ? sh.pay + (uint32_t)wave * (DFAST_COL_ROWS * 64u) + (uint32_t)lane : sh.pay;
+    const uint32_t cb = (uint32_t)(uintptr_t)(dfast_lds_words)stage;
+    uint32_t qbase = COL ? 0u : 8u * cb;                               /* (column stage: minus the position of the column's word 0, per lane and segment) */
+    constexpr uint32_t SUB_BITS = COL ? DFAST_COL_SUB_BITS : DFAST_SUB_BITS;
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)sh.lut;
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;                  /* bits a walk may look at */
-    /* does the table hold `long` entries at all?  (eight entries per thread) */
-    bool longs, pairs = false;
-    {
-        const uint32_t *t = reinterpret_cast<const uint32_t *>(sh.lut) + 4 * tid;      /* (the table is 4-byte aligned) */
-        const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        const uint32_t any = (t0 | t1 | t2 | t3) & 0x80008000u;            /* bit 15: long (bad entries have bit 14 only) */
-        static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && DEC_E_LONG == 0xC000u && DEC_E_BAD == 0x4000u, "eight entries per thread");
-        longs = __syncthreads_or(any != 0u) != 0;
-        /* the table of pairs pays for itself (its build, the longer look at a scan's last window) when codewords are short
-         * enough to come in pairs - one of six bits or less: it fits the 12 bits twice - and the block is long enough
-         * (1 GiB: zipf255 1.63 -> 1.54 ms, log text 1.53 -> 1.47; uniform bytes, without a pair, 1.03 -> 1.08 with it, zipf255 in
-         * 16 KiB blocks 2.97 -> 3.06: those keep the table of singles) */
-        if (!longs && block_len >= DFAST_PAIRS_FROM) {
-            const uint32_t m = dmin<uint32_t>(dmin<uint32_t>(dmin<uint32_t>(t0 & 0xffffu, t0 >> 16), dmin<uint32_t>(t1 & 0xffffu, t1 >> 16)),
-                                              dmin<uint32_t>(dmin<uint32_t>(t2 & 0xffffu, t2 >> 16), dmin<uint32_t>(t3 & 0xffffu, t3 >> 16)));
-            pairs = __syncthreads_or(m < 0x0700u) != 0;                     /* a leaf is (bits << 8) | byte */
-        }
-    }
     const uint32_t pair_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)L::pairs(sh);
     if (pairs) dfast_pair_table<THREADS>(sh);                          /* (read behind the stage's first barrier) */
     uint64_t true_start = 0, produced = 0;
@@ -581,24 +634,32 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         /* Round 4: the payload left is cut into EQUAL shares (the block index says where it ends): the last segment of a block
          * is as full as the others instead of a quarter full on average, and every scan is that much shorter (zipf255 at
          * 64 KiB: 3.2 segments of 288-bit shares -> 4 of 232).  The raw-stream probe does not know the end: 288 as before. */
-        uint32_t sb = DFAST_SUB_BITS;
+        uint32_t sb = SUB_BITS;
         const bool hinted = uni32((end_bits && trust && hint_bytes * 8ull > seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
         if (!end_bits || hinted) {
             const uint64_t rem = (hinted ? hint_bytes * 8ull : pay_bits) - seg0;
-            const uint64_t nseg = (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
+            const uint64_t nseg = (rem + (uint64_t)THREADS * SUB_BITS - 1u) / ((uint64_t)THREADS * SUB_BITS);
             const uint64_t even = (rem + nseg * THREADS - 1u) / (nseg * THREADS);
-            sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), DFAST_SUB_BITS);
+            sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), SUB_BITS);
         }
         sb = uni32(sb);
         const uint32_t need_words = uni32(dmin<uint32_t>(((uint32_t)THREADS * sb + 31u) / 32u + DFAST_SLACK_WORDS, L::STAGE_WORDS));
-        __syncthreads();                                               /* the previous segment's readers are done */
-        unsigned long long pt = DPROF_T();
-        dfast_stage<THREADS>(stage, pay, seg0, readable, need_words, produced);
-        __syncthreads();
-        DPROF_ADD(1, pt); pt = DPROF_T();
         const uint32_t pay_rel = (uint32_t)dmin<uint64_t>(pay_bits - seg0, 0xfffffff0ull);   /* payload bits from seg0 on */
         const uint32_t first = (uint32_t)(true_start - seg0);
         const uint32_t hi = ((uint32_t)tid + 1u) * sb;
+        __syncthreads();                                               /* the previous segment's readers are done */
+        unsigned long long pt = DPROF_T();
+        if (COL) {
+            /* the column's word 0 is the one that holds the bit in FRONT of the lane's first: positions are kept minus one */
+            const int32_t lo1 = (int32_t)(tid == 0 ? first : hi - sb) - 1;
+            const int32_t word0 = lo1 >> 5;                                /* (-1 for a lane 0 whose share starts with the segment) */
+            qbase = 0u - (uint32_t)(32 * word0);
+            dfast_stage_col<THREADS>(stage, pay, seg0, readable, word0, hi - sb < pay_rel);
+        } else {
+            dfast_stage<THREADS>(stage, pay, seg0, readable, need_words, produced);
+        }
+        __syncthreads();
+        DPROF_ADD(1, pt); pt = DPROF_T();
         /* speculation: every lane but the first starts at its own first bit - a decoder that starts anywhere falls
          * into step within a few codewords, and a lane that has not is found out below */
         uint32_t start = tid == 0 ? first : hi - sb;
@@ -629,9 +690,14 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         }
         uint32_t end = hi, cnt = 0;
         if (__ballot(!dead)) {
-            if (longs) dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
-            else if (pairs) dfast_scan<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
-            else dfast_scan<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            if constexpr (!COL) {
+                if (longs) dfast_scan<THREADS, DFAST_LONGS, false>(sh, stage, qbase, cb, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+                else if (pairs) dfast_scan<THREADS, DFAST_PAIRS, false>(sh, stage, qbase, cb, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+                else dfast_scan<THREADS, DFAST_SINGLES, false>(sh, stage, qbase, cb, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            } else {
+                if (pairs) dfast_scan<THREADS, DFAST_PAIRS, true>(sh, stage, qbase, cb, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+                else dfast_scan<THREADS, DFAST_SINGLES, true>(sh, stage, qbase, cb, lut_addr, pair_addr, dead ? hi : start, hi, lim, &end, &cnt);
+            }
             if (dead) { end = hi; cnt = 0; }
         }
         /*  - after it: the speculative counts are right to a few symbols either way; a lane in front of which they
@@ -660,16 +726,21 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
                 DFAST_DBGW(rounds == 0 ? 6 : rounds == 1 ? 7 : 14, 1);
                 if (changed) start = ns;
                 uint32_t e2 = end, c2 = cnt;
-                if (longs) dfast_scan<THREADS, DFAST_LONGS>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
-                else if (pairs) dfast_scan<THREADS, DFAST_PAIRS>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
-                else dfast_scan<THREADS, DFAST_SINGLES>(sh, stage, qbase, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                if constexpr (!COL) {
+                    if (longs) dfast_scan<THREADS, DFAST_LONGS, false>(sh, stage, qbase, cb, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                    else if (pairs) dfast_scan<THREADS, DFAST_PAIRS, false>(sh, stage, qbase, cb, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                    else dfast_scan<THREADS, DFAST_SINGLES, false>(sh, stage, qbase, cb, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                } else {
+                    if (pairs) dfast_scan<THREADS, DFAST_PAIRS, true>(sh, stage, qbase, cb, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                    else dfast_scan<THREADS, DFAST_SINGLES, true>(sh, stage, qbase, cb, lut_addr, pair_addr, changed ? start : hi, hi, lim, &e2, &c2);
+                }
                 if (changed) { end = e2; cnt = c2; }
             }
             /* ---- runs of one byte value (only when the starts have not settled in two rounds): dfast_run_jump ---- */
             int jumped = 0;
             if (rounds >= DFAST_JUMP_FROM_ROUND && __ballot(changed != 0)) {
                 DFAST_DBGW(15, 1);
-                const uint4 r = dfast_run_jump(qbase, lut_addr, changed != 0, dead, hi, sb, pay_rel, start, end, cnt);
+                const uint4 r = dfast_run_jump<COL>(qbase, cb, lut_addr, changed != 0, dead, hi, sb, pay_rel, start, end, cnt);
                 start = r.x; end = r.y; cnt = r.z; jumped = (int)r.w;
             }
             if (lane == 63) sh.wend[wave] = end;
@@ -700,7 +771,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
         if (quota) {
             /* (all of the lane's symbols, and the whole last word still inside this block's output) */
             const bool whole = quota == cnt && produced + ex + ((quota + 3u) & ~3u) <= block_len;
-            uint32_t qe = dfast_write<THREADS>(sh, stage, qbase, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok, whole);
+            uint32_t qe = dfast_write<THREADS, COL>(sh, stage, qbase, cb, lut_addr, start, quota, lim, gout + produced + ex, &lane_ok, whole);
             if (whole) qe = end;
 #ifdef DFAST_DEBUG
             if (!lane_ok) atomicAdd(&g_dfast_dbg[4], 1ull);
@@ -721,14 +792,56 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     return ok;
 }
 
+/* The block's payload, by the form of stage its tables allow: blocks with `long` entries (codes of more than 12 bits, walked bit
+ * by bit along the staged words) on the linear stage, all others on the column stage. */
+template <int THREADS, bool ALLOW_COL = true>
+__device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                    uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
+{
+    const int tid = (int)threadIdx.x;
+    /* does the table hold `long` entries at all?  (eight entries per thread) */
+    bool longs, pairs = false;
+    {
+        const uint32_t *t = reinterpret_cast<const uint32_t *>(sh.lut) + 4 * tid;      /* (the table is 4-byte aligned) */
+        const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+        const uint32_t any = (t0 | t1 | t2 | t3) & 0x80008000u;            /* bit 15: long (bad entries have bit 14 only) */
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8 && DEC_E_LONG == 0xC000u && DEC_E_BAD == 0x4000u, "eight entries per thread");
+        longs = __syncthreads_or(any != 0u) != 0;
+        /* the table of pairs pays for itself (its build, the longer look at a scan's last window) when codewords are short
+         * enough to come in pairs - one of six bits or less: it fits the 12 bits twice - and the block is long enough
+         * (1 GiB: zipf255 1.63 -> 1.54 ms, log text 1.53 -> 1.47; uniform bytes, without a pair, 1.03 -> 1.08 with it, zipf255 in
+         * 16 KiB blocks 2.97 -> 3.06: those keep the table of singles) */
+        if (!longs && block_len >= DFAST_PAIRS_FROM) {
+            const uint32_t m = dmin<uint32_t>(dmin<uint32_t>(dmin<uint32_t>(t0 & 0xffffu, t0 >> 16), dmin<uint32_t>(t1 & 0xffffu, t1 >> 16)),
+                                              dmin<uint32_t>(dmin<uint32_t>(t2 & 0xffffu, t2 >> 16), dmin<uint32_t>(t3 & 0xffffu, t3 >> 16)));
+            pairs = __syncthreads_or(m < 0x0700u) != 0;                     /* a leaf is (bits << 8) | byte */
+        }
+    }
+#ifdef DFAST_LINEAR_ONLY
+    return decode_payload_fast_impl<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, longs, pairs);
+#else
+    if constexpr (!ALLOW_COL) return decode_payload_fast_impl<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, longs, pairs);
+    if (longs) return decode_payload_fast_impl<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, true, false);
+    /* The column stage's shares are 256 bits at most, the linear stage's 288: a payload that the shorter shares cut into one
+     * segment more keeps the linear stage (uniform bytes in 64 KiB blocks: 589 824 bits = 4 x 512 x 288 exactly - five segments
+     * of columns, 1.12 -> 1.58 ms per GiB, and shares of 288 bits = 32 of its 9-bit codes keep every speculative start right). */
+    const uint64_t est_bits = end_bits ? hint_bytes * 8ull : pay_bytes * 8ull;      /* (the probe: the next candidate's offset, 0 = none) */
+    const uint64_t seg_col = (est_bits + (uint64_t)THREADS * DFAST_COL_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_COL_SUB_BITS);
+    const uint64_t seg_lin = (est_bits + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
+    if (uni32(seg_col != seg_lin ? 1u : 0u) != 0u)
+        return decode_payload_fast_impl<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, false, pairs);
+    return decode_payload_fast_impl<THREADS, true>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, false, pairs);
+#endif
+}
+
 /* (Round 4 also walked TWO shares a lane side by side - two chains of dependent LDS reads in flight together: bit-exact and
  * slower, zipf255 1.58 -> 2.18 ms per GiB, uniform bytes unchanged; profiles/r04/dfast_two_chains.txt and notebook_r04.md have
  * the numbers, the code went with round 5's clean-up.) */
-template <int THREADS>
+template <int THREADS, bool ALLOW_COL = true>
 __device__ __forceinline__ bool decode_payload_dfast(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
                                     uint8_t *gout, uint64_t *end_bits = nullptr, uint64_t hint_bytes = 0)
 {
-    return decode_payload_fast<THREADS>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes);
+    return decode_payload_fast<THREADS, ALLOW_COL>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes);
 }
 
 /* ======================================================================================

@@ -144,7 +144,9 @@ template <bool COL>
 __device__ __forceinline__ uint32_t dfast_bits_at(uint32_t Q, uint32_t cb)
 {
     if (COL) {
-        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)(((Q >> 5) << 8) + cb);
+        uint32_t a_;                                         /* ((Q >> 5) << 8) + cb in two instructions (the compiler makes three of it) */
+        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a_) : "v"(Q & ~31u), "v"(cb));
+        dfast_lds_words wp = (dfast_lds_words)(uintptr_t)a_;
         return __builtin_amdgcn_alignbit(wp[0], wp[64], ~Q);
     }
     dfast_lds_words wp = (dfast_lds_words)(uintptr_t)((Q >> 3) & ~3u);

@@ -1135,7 +1135,15 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
         discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks, ctx->d_cand_end);
         DISC_TRACE("discover write done");
         cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_cand_end, ncand, ctx->d_spec_off);
-        probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap);
+        /* (the list of candidates for the exact decoder lives in d_nxt, which link_kernel writes behind the probes; its count in a spare word of d_walk) */
+        unsigned long long *redo_count = (unsigned long long *)(ctx->d_walk + 6);
+        HIP_OK(ctx, hipMemsetAsync(redo_count, 0, sizeof(unsigned long long), s));
+        probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
+        /* (two forms, each at the lean probe's register budget; the one whose mode it is not leaves at once.  Count-only - every
+         *  candidate on the list: hufgpu_block_index - takes a workgroup per candidate) */
+        const unsigned exact_grid = (unsigned)(ncand < 1024 || !out ? ncand : 1024);
+        probe_exact_kernel<DEC_THREADS, true><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ncand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
+        probe_exact_kernel<DEC_THREADS, false><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ncand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
         DISC_TRACE("probe done");
         link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
         DISC_TRACE("link done");

@@ -53,8 +53,10 @@ namespace hufgpu {
  * aligned address; neighbours overlap by a word, from the vector cache).  Shares are at most 256 bits there: the column holds
  * the word with the bit in front of the share's first (positions are kept minus one), the share, the window behind its last
  * codeword start and the up to three symbols a lane decodes beyond its own to store a whole word - eleven rows. */
-#define DFAST_COL_ROWS 11u
+#define DFAST_COL_ROWS 11u                          /* ... of a block that has a table of pairs behind its stage */
 #define DFAST_COL_SUB_BITS 256u
+#define DFAST_COL_ROWS_WIDE 12u                     /* ... of a block without one (codes too long for pairs, blocks below 32 KiB): the stage runs on into
+                                                       the pairs' place and the shares are the linear stage's 288 bits */
 #ifndef DFAST_PAIRS_FROM
 #define DFAST_PAIRS_FROM 32768u                      /* symbols of a block from which its scans read the table of pairs (dfast_pair_table) */
 #endif
@@ -71,6 +73,7 @@ struct DfastLds {
     static constexpr uint32_t SEG_WORDS = (uint32_t)THREADS * DFAST_SUBW;
     static constexpr uint32_t STAGE_WORDS = SEG_WORDS + DFAST_SLACK_WORDS;                     /* the linear stage */
     static constexpr uint32_t COL_WORDS = (uint32_t)THREADS * DFAST_COL_ROWS;                   /* the column stage: [wave][row][lane] */
+    static_assert((uint32_t)THREADS * DFAST_COL_ROWS_WIDE <= AREA_WORDS, "the wide column stage (no pairs behind it) fits pay + marks");
     static constexpr uint32_t AHEAD_WORDS = COL_WORDS > STAGE_WORDS ? COL_WORDS : STAGE_WORDS;  /* what lies in front of the table of pairs */
     static_assert(offsetof(DecShared<THREADS>, mark) == offsetof(DecShared<THREADS>, pay) + sizeof(DecShared<THREADS>::pay), "one area");
     static_assert(STAGE_WORDS + 4u <= AREA_WORDS, "the linear stage fits the area of the interleaved stage and its marks");
@@ -538,30 +541,32 @@ __device__ __forceinline__ uint32_t dfast_write(const DecShared<THREADS> &sh, co
  * seg0; -1 for a lane 0 whose share starts with the segment).  A lane whose words reach beyond `readable` takes them byte by
  * byte with zeros behind the end (the stream's last segment). */
 template <int THREADS>
-__device__ __forceinline__ void dfast_stage_col(uint32_t *col, const uint8_t *pay, uint64_t seg0, uint64_t readable, int32_t word0, bool wanted)
+__device__ __forceinline__ void dfast_stage_col(uint32_t *col, const uint8_t *pay, uint64_t seg0, uint64_t readable, int32_t word0, bool wanted, const bool wide)
 {
     if (!wanted) return;
     const int64_t first = (int64_t)(seg0 >> 3) + 4 * (int64_t)word0;       /* payload byte of the column's word 0 (-4: the block's tree ends there) */
-    uint32_t w[DFAST_COL_ROWS];
-    if (first + 4 * (int64_t)(DFAST_COL_ROWS + 1u) <= (int64_t)readable) {
+    uint32_t w[DFAST_COL_ROWS_WIDE];
+    if (first + 4 * (int64_t)(DFAST_COL_ROWS_WIDE + 1u) <= (int64_t)readable) {
         struct __attribute__((packed, aligned(4))) Q4 { uint32_t x, y, z, w; };
         const uintptr_t a = (uintptr_t)((intptr_t)(uintptr_t)pay + (intptr_t)first);
         const uint32_t m = (uint32_t)(a & 3u);
         const uint32_t *qw = reinterpret_cast<const uint32_t *>(a - m);
         const Q4 v0 = *reinterpret_cast<const Q4 *>(qw), v1 = *reinterpret_cast<const Q4 *>(qw + 4), v2 = *reinterpret_cast<const Q4 *>(qw + 8);
-        const uint32_t d[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        const uint32_t x = qw[12];
+        const uint32_t d[13] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, x};
         const uint32_t sel = (m << 24) | ((m + 1u) << 16) | ((m + 2u) << 8) | (m + 3u);
 #pragma unroll
-        for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) w[r] = __builtin_amdgcn_perm(d[r + 1], d[r], sel);
+        for (uint32_t r = 0; r < DFAST_COL_ROWS_WIDE; r++) w[r] = __builtin_amdgcn_perm(d[r + 1], d[r], sel);
     } else {
 #pragma unroll
-        for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) {
+        for (uint32_t r = 0; r < DFAST_COL_ROWS_WIDE; r++) {
             const int64_t off = first + 4 * (int64_t)r;
             w[r] = off >= 0 ? load_be32(pay, (uint64_t)off, readable) : 0u;
         }
     }
 #pragma unroll
     for (uint32_t r = 0; r < DFAST_COL_ROWS; r++) col[64u * r] = w[r];
+    if (wide) col[64u * DFAST_COL_ROWS] = w[DFAST_COL_ROWS];
 }
 
 /* The segment that begins at bit seg0 of the payload into the linear stage: need_words words, big-endian. */
@@ -618,10 +623,11 @@ __device__ __forceinline__ bool decode_payload_fast_impl(DecShared<THREADS> &sh,
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     /* linear stage: runs on into the marks' area; column stage: this lane's column, word 0 (its wave's slice: DFAST_COL_ROWS rows of 64 words) */
-    uint32_t *stage = COL ? sh.pay + (uint32_t)wave * (DFAST_COL_ROWS * 64u) + (uint32_t)lane : sh.pay;
+    const bool wide = COL && !pairs;                                  /* (no table of pairs behind the stage: twelve rows, shares of 288 bits) */
+    uint32_t *stage = COL ? sh.pay + (uint32_t)wave * ((wide ? DFAST_COL_ROWS_WIDE : DFAST_COL_ROWS) * 64u) + (uint32_t)lane : sh.pay;
     const uint32_t cb = (uint32_t)(uintptr_t)(dfast_lds_words)stage;
     uint32_t qbase = COL ? 0u : 8u * cb;                               /* (column stage: minus the position of the column's word 0, per lane and segment) */
-    constexpr uint32_t SUB_BITS = COL ? DFAST_COL_SUB_BITS : DFAST_SUB_BITS;
+    const uint32_t SUB_BITS = (COL && !wide) ? DFAST_COL_SUB_BITS : DFAST_SUB_BITS;
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(dfast_lds_halves)sh.lut;
     const uint64_t pay_bits = pay_bytes * 8ull;
     const uint32_t lim = (L::STAGE_WORDS - 2u) * 32u;                  /* bits a walk may look at */
@@ -640,7 +646,8 @@ __device__ __forceinline__ bool decode_payload_fast_impl(DecShared<THREADS> &sh,
         const bool hinted = uni32((end_bits && trust && hint_bytes * 8ull > seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
         if (!end_bits || hinted) {
             const uint64_t rem = (hinted ? hint_bytes * 8ull : pay_bits) - seg0;
-            const uint64_t nseg = (rem + (uint64_t)THREADS * SUB_BITS - 1u) / ((uint64_t)THREADS * SUB_BITS);
+            const uint64_t nseg = SUB_BITS == DFAST_SUB_BITS ? (rem + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS)
+                                                             : (rem + (uint64_t)THREADS * DFAST_COL_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_COL_SUB_BITS);   /* (constant divisors) */
             const uint64_t even = (rem + nseg * THREADS - 1u) / (nseg * THREADS);
             sb = (uint32_t)dmin<uint64_t>(dmax<uint64_t>(even, 64u), SUB_BITS);
         }
@@ -656,7 +663,7 @@ __device__ __forceinline__ bool decode_payload_fast_impl(DecShared<THREADS> &sh,
             const int32_t lo1 = (int32_t)(tid == 0 ? first : hi - sb) - 1;
             const int32_t word0 = lo1 >> 5;                                /* (-1 for a lane 0 whose share starts with the segment) */
             qbase = 0u - (uint32_t)(32 * word0);
-            dfast_stage_col<THREADS>(stage, pay, seg0, readable, word0, hi - sb < pay_rel);
+            dfast_stage_col<THREADS>(stage, pay, seg0, readable, word0, hi - sb < pay_rel, wide);
         } else {
             dfast_stage<THREADS>(stage, pay, seg0, readable, need_words, produced);
         }
@@ -830,7 +837,7 @@ __device__ __forceinline__ bool decode_payload_fast(DecShared<THREADS> &sh, cons
     const uint64_t est_bits = end_bits ? hint_bytes * 8ull : pay_bytes * 8ull;      /* (the probe: the next candidate's offset, 0 = none) */
     const uint64_t seg_col = (est_bits + (uint64_t)THREADS * DFAST_COL_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_COL_SUB_BITS);
     const uint64_t seg_lin = (est_bits + (uint64_t)THREADS * DFAST_SUB_BITS - 1u) / ((uint64_t)THREADS * DFAST_SUB_BITS);
-    if (uni32(seg_col != seg_lin ? 1u : 0u) != 0u)
+    if (pairs && uni32(seg_col != seg_lin ? 1u : 0u) != 0u)          /* (without pairs the columns' shares are 288 bits too) */
         return decode_payload_fast_impl<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, false, pairs);
     return decode_payload_fast_impl<THREADS, true>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, false, pairs);
 #endif

@@ -264,15 +264,17 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
                                                         uint64_t *__restrict__ cand_end,
                                                         int32_t *__restrict__ cand_status,
                                                         const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
-                                                        uint64_t out_cap)
+                                                        uint64_t out_cap, uint32_t *__restrict__ redo, unsigned long long *__restrict__ redo_count)
 {
+    /* Round 5: the lean decoder ONLY; a candidate it cannot vouch for goes on the list of probe_exact_kernel.  (With the exact
+     * decoder in the same kernel the probe spilled 5-13 registers and could not take decode_fast's column stage: the two
+     * stage forms and the exact decoder inlined side by side.) */
     __shared__ DecShared<THREADS> sh;
     const uint64_t c = uni64(cand[blockIdx.x]);
     const uint64_t block_len = uni64(load_u64_unaligned(stream + c));
     const int tl = (int)(int16_t)uni32((uint32_t)stream[c + 8] | ((uint32_t)stream[c + 9] << 8));
     const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
-    uint64_t end_bits = 0, produced = 0;
-    int err;
+    uint64_t end_bits = 0;
     const bool store = uni64(spec_off[gridDim.x]) <= out_cap;
     if (store && block_len != 0 && tl >= 9 && pay0 <= avail) {
         int leaf = -1;
@@ -282,26 +284,45 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
         const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
         const bool shaped = block_len >= 32768u && tl <= HUF_TREE_MAX && dfast_tables_from_tree<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl);
         if ((shaped || (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0)) &&
-            /* (the linear stage only: with both forms inlined the probe spills thirteen registers instead of five, and what the column
-             *  stage wins on zipf255 - 1.88 -> 1.83 ms per GiB - uniform bytes lose, 1.58 -> 1.66) */
-            decode_payload_dfast<THREADS, false>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint)) {
+            decode_payload_dfast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint)) {
             if (threadIdx.x == 0) {
                 cand_status[blockIdx.x] = HUFE_OK;
                 cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
             }
             return;
         }
-        __syncthreads();
     }
-    if (store)
-        err = decode_block<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
-                                          out + spec_off[blockIdx.x], &end_bits, &produced);
-    else
-        err = decode_block<THREADS, false>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
-                                           nullptr, &end_bits, &produced);
-    if (threadIdx.x == 0) {
-        cand_status[blockIdx.x] = err;
-        cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);
+    if (threadIdx.x == 0) redo[atomicAdd(redo_count, 1ull)] = blockIdx.x;
+}
+
+/* The candidates the lean decoder could not vouch for - a damaged block, an unusual tree, a false candidate, and every candidate
+ * when the output does not take them all - through the exact decoder, which has the last word on status and end. */
+template <int THREADS, bool STORE>
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_exact_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
+                                                        const uint64_t *__restrict__ cand, uint64_t ncand,
+                                                        uint64_t *__restrict__ cand_end,
+                                                        int32_t *__restrict__ cand_status,
+                                                        const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
+                                                        uint64_t out_cap, const uint32_t *__restrict__ redo, const unsigned long long *__restrict__ redo_count)
+{
+    __shared__ DecShared<THREADS> sh;
+    const uint64_t n = uni64(*redo_count);
+    if ((uni64(spec_off[ncand]) <= out_cap) != STORE) return;         /* (the other form of this kernel has the list) */
+    for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t k = uni32(redo[i]);
+        const uint64_t c = uni64(cand[k]);
+        const uint64_t block_len = uni64(load_u64_unaligned(stream + c));
+        const int tl = (int)(int16_t)uni32((uint32_t)stream[c + 8] | ((uint32_t)stream[c + 9] << 8));
+        const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
+        uint64_t end_bits = 0, produced = 0;
+        int err;
+        __syncthreads();
+        err = decode_block<THREADS, STORE>(sh, stream + c + HUF_HEADER_FIXED, tl, block_len, avail - pay0,
+                                           STORE ? out + spec_off[k] : nullptr, &end_bits, &produced);
+        if (threadIdx.x == 0) {
+            cand_status[k] = err;
+            cand_end[k] = pay0 + ((end_bits + 7) >> 3);
+        }
     }
 }
 

@@ -134,7 +134,10 @@ int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_l
  * sizes in front of it), every rank's decode result.  The gathered stream is the reference's, byte for byte - the one a
  * single hufgpu_encode() of the whole input writes.  RCCL is looked up with dlopen at the first call (HUF_GPU_RCCL_LIB,
  * else librccl.so.1): without it these entry points return HUF_ERROR_FATAL and hufgpu_shard_last_error(NULL) says why.
- * No call here has a timeout: a rank that never arrives holds the others inside RCCL.
+ * Every call has a deadline (HUF_GPU_SHARD_TIMEOUT_MS when the object is made, default 120 000 ms; hufgpu_shard_set_timeout;
+ * 0 = none): a rank that never arrives, or a communicator that reports an asynchronous error, makes the call return
+ * HUF_ERROR_FATAL on the ranks that did arrive - the object's own communicator is aborted (ncclCommAbort), the object
+ * is broken and every later call on it fails at once; hufgpu_shard_destroy() is still to be called.
  *
  *   hufgpu_shard_create   : nccl_comm = an existing ncclComm_t of the ranks (not destroyed with the object; nranks and rank
  *                           are the communicator's), or NULL: then the object makes its own from `id`
@@ -164,6 +167,7 @@ int hufgpu_shard_create(hufgpu_shard_t **sh, hufgpu_ctx_t *ctx, void *nccl_comm,
 int hufgpu_shard_destroy(hufgpu_shard_t *sh);
 int hufgpu_shard_info(const hufgpu_shard_t *sh, int *nranks, int *rank);
 const char *hufgpu_shard_last_error(const hufgpu_shard_t *sh);
+int hufgpu_shard_set_timeout(hufgpu_shard_t *sh, uint32_t timeout_ms);
 int hufgpu_shard_range(uint64_t n_total, uint64_t blocksize, int rank, int nranks, uint64_t *lo, uint64_t *hi);
 /* first_block[nranks + 1] from a host copy of the block index (nblocks + 1 offsets, the last = the stream's length) */
 int hufgpu_shard_plan_decode(const uint64_t *block_offsets, uint64_t nblocks, int nranks, uint64_t *first_block);

@@ -69,7 +69,7 @@ hufgpu_memcpy_h2d hufgpu_memcpy_d2h hufgpu_memcpy_d2d hufgpu_synchronize hufgpu_
 hufgpu_get_profile hufgpu_sub_index_bytes hufgpu_encode_sub hufgpu_decode_sub
 hufgpu_decode_stream_complete hufgpu_block_index hufgpu_decode_counters hufgpu_calib_bandwidth hufgpu_encode_small hufgpu_decode_small huf_gpu_set_relaxed_tree huf_gpu_memwrap huf_gpu_memwrap_out huf_gpu_decode_blocks huf_gpu_sessions huf_gpu_fanouts huf_gpu_copy_out
 hufgpu_ctx_device hufgpu_shard_unique_id hufgpu_shard_create hufgpu_shard_destroy hufgpu_shard_info hufgpu_shard_last_error
-hufgpu_shard_range hufgpu_shard_plan_decode hufgpu_encode_sharded hufgpu_decode_sharded""".split()
+hufgpu_shard_range hufgpu_shard_plan_decode hufgpu_encode_sharded hufgpu_decode_sharded hufgpu_shard_set_timeout""".split()
 
 
 def so_path() -> str:
@@ -150,6 +150,7 @@ def load() -> C.CDLL:
     L.hufgpu_shard_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.hufgpu_shard_last_error.argtypes = [vp]
     L.hufgpu_shard_last_error.restype = C.c_char_p
+    L.hufgpu_shard_set_timeout.argtypes = [vp, C.c_uint32]
     L.hufgpu_shard_range.argtypes = [u64, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.hufgpu_shard_plan_decode.argtypes = [C.POINTER(u64), u64, i32, C.POINTER(u64)]
     L.hufgpu_encode_sharded.argtypes = [vp, i32, vp, u64, u64, C.c_uint32, vp, u64, vp, C.POINTER(u64), C.POINTER(u64),

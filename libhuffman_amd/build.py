@@ -18,7 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 SO_PATH = os.environ.get("HUF_LIB_PATH") or os.path.join(PKG, "libhuffman.so")   # override: tooling experiments only
 SOURCES = ["hufgpu_api.hip", "huf_host.cpp", "hufgpu_sharded.hip"]
-KERNEL_PARTS = ["util", "histogram", "tree", "offsets", "hist_tree", "hist_lanes", "pack", "hist_chunk", "pack_chunk", "decode", "decode_sub", "decode_fast", "spec_index", "discover", "fill"]
+KERNEL_PARTS = ["util", "histogram", "tree", "offsets", "hist_tree", "hist_lanes", "pack", "hist_chunk", "pack_chunk", "decode", "decode_sub", "decode_fast", "decode_regs", "spec_index", "discover", "fill"]
 DEPENDS = SOURCES + ["hufgpu_kernels.hip", "hufgpu_common.h",
                      os.path.join("..", "..", "include", "huffman.h"),
                      os.path.join("..", "..", "include", "huffman_gpu.h")] + \

@@ -31,6 +31,7 @@
 #include "kernels/decode.hpp"
 #include "kernels/decode_sub.hpp"
 #include "kernels/decode_fast.hpp"
+#include "kernels/decode_regs.hpp"
 #include "kernels/spec_index.hpp"
 #include "kernels/discover.hpp"
 #include "kernels/fill.hpp"

@@ -11,8 +11,15 @@
  * on a machine without it.  Everything here is host code over the public entry points of hufgpu_api.hip plus one
  * eight-line kernel; all of a call's work - RCCL's and the codec's - is enqueued on the shard object's own stream.
  *
- * Nothing in this file has a timeout: a rank that never arrives holds the others inside RCCL.  Callers that must not
- * hang (bench.py) run the call on a thread they can give up on.
+ * Round 6: no call can hang.  Every sharded call has a deadline (HUF_GPU_SHARD_TIMEOUT_MS, default 120 000; 0 = none;
+ * hufgpu_shard_set_timeout): the call's body runs on a helper thread, inside it every wait for the stream is a poll of
+ * hipStreamQuery and ncclCommGetAsyncError against the deadline, and the calling thread waits for the helper against the
+ * same deadline - a rank that never arrives holds the others in the stream (the real RCCL: its kernels spin) or in the
+ * host call (a transport that blocks there: connection set-up, tests/mock_rccl).  On expiry, or on an asynchronous error of
+ * the communicator, the communicator is aborted (ncclCommAbort: pending kernels leave, blocked host calls return) if it is
+ * the object's own, the object is marked broken - every later call returns HUF_ERROR_FATAL at once - and the call returns
+ * HUF_ERROR_FATAL.  Nothing is re-executed and no process is replaced; what the caller does with a broken group is the
+ * caller's business (bench.py: the rank exits non-zero).
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -23,6 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
+#include <vector>
 
 #include "../../include/huffman.h"
 #include "../../include/huffman_gpu.h"
@@ -47,6 +56,8 @@ struct Rccl {
     int (*GroupStart)(void);
     int (*GroupEnd)(void);
     const char *(*GetErrorString)(int);
+    int (*CommAbort)(rccl_comm_t);                       /* optional (every RCCL has them; a stand-in transport may not) */
+    int (*CommGetAsyncError)(rccl_comm_t, int *);
     char why[256];
 };
 Rccl g_rccl;
@@ -77,6 +88,8 @@ void rccl_load(void)
             return;
         }
     }
+    g_rccl.CommAbort = (int (*)(rccl_comm_t))dlsym(g_rccl.lib, "ncclCommAbort");
+    g_rccl.CommGetAsyncError = (int (*)(rccl_comm_t, int *))dlsym(g_rccl.lib, "ncclCommGetAsyncError");
 }
 
 const Rccl *rccl(void)
@@ -106,6 +119,8 @@ struct hufgpu_shard {
     rccl_comm_t comm;
     int owns_comm, nranks, rank, device;
     hipStream_t stream;
+    hipStream_t stream2;                     /* the root's own shard, beside the movements of the others' */
+    hipEvent_t ev;
     char err[512];
     /* this rank's buffers, grown on demand and kept */
     uint8_t *d_raw;   uint64_t raw_cap;      /* my uncompressed shard (not on the root: there it is part of the caller's buffer) */
@@ -118,6 +133,12 @@ struct hufgpu_shard {
     int have_layout, enc_root;
     uint64_t enc_total, enc_bs, enc_len;
     uint64_t *enc_lens;                      /* [nranks] */
+    /* deadlines */
+    uint32_t timeout_ms;                     /* of every call; 0 = none */
+    double deadline;                         /* of the call that is running (now_ms() scale); 0 = none */
+    pthread_mutex_t mu;                      /* guards comm / broken / aborted between a call's helper and its caller */
+    int broken;                              /* a call timed out or the communicator failed: every later call fails at once */
+    int orphans;                             /* helper threads a timed-out call left behind: the object is not freed while one may run */
 };
 
 namespace {
@@ -130,12 +151,61 @@ int fail(hufgpu_shard_t *sh, int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+/* the communicator is done for: abort it (ours) so that whatever waits inside it returns, and mark the object */
+void break_group(hufgpu_shard_t *sh)
+{
+    rccl_comm_t victim = NULL;
+    pthread_mutex_lock(&sh->mu);
+    sh->broken = 1;
+    sh->have_layout = 0;
+    if (sh->owns_comm && sh->comm) { victim = sh->comm; sh->comm = NULL; sh->owns_comm = 0; }
+    pthread_mutex_unlock(&sh->mu);
+    if (victim && rccl() && rccl()->CommAbort) (void)rccl()->CommAbort(victim);
+}
+
+int timed_out(hufgpu_shard_t *sh, const char *where)
+{
+    break_group(sh);
+    return fail(sh, HUF_ERROR_FATAL, "timed out after %u ms %s: a rank of the group did not arrive (HUF_GPU_SHARD_TIMEOUT_MS); the group is broken", sh->timeout_ms, where);
+}
+
+/* Wait for the object's stream: a poll against the call's deadline that also asks the communicator for asynchronous
+ * errors (a peer that died) - never a blind hipStreamSynchronize when there is a deadline. */
+int wait_stream(hufgpu_shard_t *sh, hipStream_t st)
+{
+    if (sh->deadline == 0.0) {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(sh, HUF_ERROR_FATAL, "hipStreamSynchronize failed: %s", hipGetErrorString(e)); }
+        return HUF_ERROR_SUCCESS;
+    }
+    const Rccl *R = rccl();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return HUF_ERROR_SUCCESS;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); break_group(sh); return fail(sh, HUF_ERROR_FATAL, "hipStreamQuery failed: %s", hipGetErrorString(e)); }
+        if ((spins & 31u) == 31u) {
+            pthread_mutex_lock(&sh->mu);
+            rccl_comm_t c = sh->comm;
+            const int broken = sh->broken;
+            pthread_mutex_unlock(&sh->mu);
+            if (broken) return fail(sh, HUF_ERROR_FATAL, "the group was broken while this call waited");
+            int async = 0;
+            if (c && R && R->CommGetAsyncError && R->CommGetAsyncError(c, &async) == 0 && async != 0 && async != 7 /* ncclInProgress */) {
+                break_group(sh);
+                return fail(sh, HUF_ERROR_FATAL, "the communicator reports an asynchronous error: %s", R->GetErrorString(async));
+            }
+            if (now_ms() > sh->deadline) return timed_out(sh, "waiting for the stream");
+        }
+        if (spins > 4000u) usleep(50);                 /* (the first ~0.2 ms: a spin - the control all-gathers take tens of microseconds) */
+    }
+}
+
 #define SH_HIP(sh, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
         return fail(sh, HUF_ERROR_FATAL, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-#define SH_RCCL(sh, call) do { int r_ = (call); if (r_ != 0) \
-        return fail(sh, HUF_ERROR_FATAL, "%s failed: %s", #call, rccl()->GetErrorString(r_)); } while (0)
-#define SH_HUF(sh, call) do { int r_ = (call); if (r_ != HUF_ERROR_SUCCESS) \
-        return fail(sh, r_, "%s failed: %s", #call, hufgpu_last_error(sh->ctx)); } while (0)
+#define SH_RCCL(sh, call) do { int r_ = (call); if (r_ != 0) { break_group(sh); \
+        return fail(sh, HUF_ERROR_FATAL, "%s failed: %s", #call, rccl()->GetErrorString(r_)); } } while (0)
+#define SH_WAIT(sh) do { const int w_ = wait_stream(sh, (sh)->stream); if (w_) return w_; } while (0)
 
 void range_of(uint64_t n_total, uint64_t blocksize, int rank, int nranks, uint64_t *lo, uint64_t *hi)
 {
@@ -173,7 +243,7 @@ int all_words(hufgpu_shard_t *sh, int k)
     SH_HIP(sh, hipMemcpyAsync(sh->d_words, sh->h_words, (size_t)k * 8, hipMemcpyHostToDevice, sh->stream));
     SH_RCCL(sh, R->AllGather(sh->d_words, sh->d_words + k, (size_t)k, RCCL_UINT64, sh->comm, sh->stream));
     SH_HIP(sh, hipMemcpyAsync(sh->h_words + k, sh->d_words + k, n * 8, hipMemcpyDeviceToHost, sh->stream));
-    SH_HIP(sh, hipStreamSynchronize(sh->stream));
+    SH_WAIT(sh);
     return HUF_ERROR_SUCCESS;
 }
 
@@ -191,7 +261,7 @@ int scatter(hufgpu_shard_t *sh, int root, const uint8_t *d_root, const uint64_t 
         r_ = R->Recv(d_mine, (size_t)len[sh->rank], RCCL_UINT8, root, sh->comm, sh->stream);
     }
     const int e_ = R->GroupEnd();
-    if (r_ != 0 || e_ != 0) return fail(sh, HUF_ERROR_FATAL, "ncclSend/ncclRecv (scatter) failed: %s", R->GetErrorString(r_ ? r_ : e_));
+    if (r_ != 0 || e_ != 0) { break_group(sh); return fail(sh, HUF_ERROR_FATAL, "ncclSend/ncclRecv (scatter) failed: %s", R->GetErrorString(r_ ? r_ : e_)); }
     return HUF_ERROR_SUCCESS;
 }
 
@@ -208,7 +278,7 @@ int gather(hufgpu_shard_t *sh, int root, uint8_t *d_root, const uint64_t *off, c
         r_ = R->Send(d_mine, (size_t)len[sh->rank], RCCL_UINT8, root, sh->comm, sh->stream);
     }
     const int e_ = R->GroupEnd();
-    if (r_ != 0 || e_ != 0) return fail(sh, HUF_ERROR_FATAL, "ncclSend/ncclRecv (gather) failed: %s", R->GetErrorString(r_ ? r_ : e_));
+    if (r_ != 0 || e_ != 0) { break_group(sh); return fail(sh, HUF_ERROR_FATAL, "ncclSend/ncclRecv (gather) failed: %s", R->GetErrorString(r_ ? r_ : e_)); }
     return HUF_ERROR_SUCCESS;
 }
 
@@ -224,16 +294,124 @@ struct Legs {
     hufgpu_shard_t *sh;
     double *out, t;
     int i;
-    Legs(hufgpu_shard_t *s, double *o) : sh(s), out(o), t(0), i(0) { if (out) { (void)hipStreamSynchronize(sh->stream); t = now_ms(); } }
+    Legs(hufgpu_shard_t *s, double *o) : sh(s), out(o), t(0), i(0) { if (out) { (void)wait_stream(sh, sh->stream); t = now_ms(); } }
     void next(void)                              /* the leg ends here (timed legs are synchronised: no overlap between them) */
     {
         if (!out) return;
-        (void)hipStreamSynchronize(sh->stream);
+        (void)wait_stream(sh, sh->stream);
         const double n = now_ms();
         out[i++] = n - t;
         t = n;
     }
 };
+
+/* ---- a call's body on a helper thread, its caller waiting against the deadline ---- */
+struct Call {
+    hufgpu_shard_t *sh;
+    int (*body)(Call *);
+    /* arguments (both calls; what a call does not have stays 0) */
+    int root;
+    const void *d_in;
+    uint64_t n_total, blocksize, stream_len, cap;
+    uint32_t flags;
+    void *d_out;
+    uint64_t *d_index;
+    const uint64_t *d_index_in;
+    int want_legs;
+    /* results: the caller's memory is written by the caller, and only by a call that came back in time */
+    uint64_t out_len;
+    std::vector<uint64_t> lens;
+    double legs[4];
+    int rc;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int done, refs;
+};
+
+void call_release(Call *c)
+{
+    pthread_mutex_lock(&c->mu);
+    const int left = --c->refs;
+    pthread_mutex_unlock(&c->mu);
+    if (left == 0) { pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->cv); delete c; }
+}
+
+void *call_main(void *arg)
+{
+    Call *c = (Call *)arg;
+    int rc = hipSetDevice(c->sh->device) == hipSuccess ? c->body(c) : HUF_ERROR_FATAL;
+    pthread_mutex_lock(&c->mu);
+    c->rc = rc;
+    c->done = 1;
+    pthread_cond_broadcast(&c->cv);
+    pthread_mutex_unlock(&c->mu);
+    call_release(c);
+    return NULL;
+}
+
+/* runs c->body; true = the body came back (c->rc), false = the deadline passed first (the group is broken, the helper is
+ * left to itself and frees the call when it returns) */
+bool run_call(Call *c)
+{
+    hufgpu_shard_t *sh = c->sh;
+    pthread_mutex_init(&c->mu, NULL);
+    pthread_cond_init(&c->cv, NULL);
+    c->done = 0;
+    if (sh->timeout_ms == 0) {                       /* no deadline: on the caller's thread */
+        sh->deadline = 0.0;
+        c->refs = 1;
+        c->rc = c->body(c);
+        return true;
+    }
+    sh->deadline = now_ms() + (double)sh->timeout_ms;
+    c->refs = 2;
+    pthread_t th;
+    if (pthread_create(&th, NULL, call_main, c) != 0) {
+        c->refs = 1;
+        c->rc = fail(sh, HUF_ERROR_FATAL, "pthread_create failed");
+        return true;
+    }
+    /* the helper polls the same deadline wherever it waits for the stream; what it cannot poll is a host call that blocks
+     * (connection set-up to a rank that is not there): a grace period for the first, then the abort from here */
+    struct timespec until;
+    clock_gettime(CLOCK_REALTIME, &until);
+    const uint64_t ns = (uint64_t)until.tv_nsec + ((uint64_t)sh->timeout_ms + 500ull) * 1000000ull;
+    until.tv_sec += (time_t)(ns / 1000000000ull);
+    until.tv_nsec = (long)(ns % 1000000000ull);
+    pthread_mutex_lock(&c->mu);
+    int w = 0;
+    while (!c->done && w == 0) w = pthread_cond_timedwait(&c->cv, &c->mu, &until);
+    const int done = c->done;
+    pthread_mutex_unlock(&c->mu);
+    if (done) {
+        pthread_join(th, NULL);
+        return true;
+    }
+    pthread_mutex_lock(&sh->mu);
+    sh->orphans++;
+    pthread_mutex_unlock(&sh->mu);
+    (void)timed_out(sh, "inside the transport");      /* aborts the communicator: the helper's host call returns */
+    /* a moment for the helper to come back (it then still is this call's thread to join) */
+    clock_gettime(CLOCK_REALTIME, &until);
+    until.tv_sec += 2;
+    pthread_mutex_lock(&c->mu);
+    w = 0;
+    while (!c->done && w == 0) w = pthread_cond_timedwait(&c->cv, &c->mu, &until);
+    const int late = c->done;
+    pthread_mutex_unlock(&c->mu);
+    if (late) {
+        pthread_join(th, NULL);
+        pthread_mutex_lock(&sh->mu);
+        sh->orphans--;
+        pthread_mutex_unlock(&sh->mu);
+    } else {
+        pthread_detach(th);
+    }
+    return false;
+}
+
+int encode_body(Call *c);
+int decode_body(Call *c);
 
 }  // namespace
 
@@ -278,11 +456,22 @@ extern "C" const char *hufgpu_shard_last_error(const hufgpu_shard_t *sh)
     return sh->err;
 }
 
+extern "C" int hufgpu_shard_set_timeout(hufgpu_shard_t *sh, uint32_t timeout_ms)
+{
+    if (!sh) return HUF_ERROR_INVALID_ARGUMENT;
+    sh->timeout_ms = timeout_ms;
+    return HUF_ERROR_SUCCESS;
+}
+
 extern "C" int hufgpu_shard_destroy(hufgpu_shard_t *sh)
 {
     if (!sh) return HUF_ERROR_SUCCESS;
     (void)hipSetDevice(sh->device);
-    if (sh->stream) { (void)hipStreamSynchronize(sh->stream); }
+    pthread_mutex_lock(&sh->mu);
+    const int orphans = sh->orphans;
+    pthread_mutex_unlock(&sh->mu);
+    if (orphans) return HUF_ERROR_SUCCESS;           /* a helper of a timed-out call may still run on this object: it is left alone, not freed */
+    if (sh->stream && !sh->broken) { (void)hipStreamSynchronize(sh->stream); }
     if (sh->owns_comm && sh->comm && rccl()) (void)rccl()->CommDestroy(sh->comm);
     if (sh->d_raw) hufgpu_free(sh->ctx, sh->d_raw);
     if (sh->d_comp) hufgpu_free(sh->ctx, sh->d_comp);
@@ -291,7 +480,10 @@ extern "C" int hufgpu_shard_destroy(hufgpu_shard_t *sh)
     if (sh->d_sub) hufgpu_free(sh->ctx, sh->d_sub);
     if (sh->d_words) hufgpu_free(sh->ctx, sh->d_words);
     if (sh->h_words) (void)hipHostFree(sh->h_words);
+    if (sh->ev) (void)hipEventDestroy(sh->ev);
+    if (sh->stream2) (void)hipStreamDestroy(sh->stream2);
     if (sh->stream) (void)hipStreamDestroy(sh->stream);
+    pthread_mutex_destroy(&sh->mu);
     free(sh->enc_lens);
     free(sh);
     return HUF_ERROR_SUCCESS;
@@ -311,16 +503,25 @@ extern "C" int hufgpu_shard_create(hufgpu_shard_t **out, hufgpu_ctx_t *ctx, void
     if (nranks < 1 || rank < 0 || rank >= nranks) return HUF_ERROR_INVALID_ARGUMENT;
     hufgpu_shard_t *sh = (hufgpu_shard_t *)calloc(1, sizeof *sh);
     if (!sh) return HUF_ERROR_MEMORY_ALLOCATION;
+    pthread_mutex_init(&sh->mu, NULL);
     sh->ctx = ctx;
     sh->nranks = nranks;
     sh->rank = rank;
     sh->device = hufgpu_ctx_device(ctx);
     sh->enc_lens = (uint64_t *)calloc((size_t)nranks, sizeof(uint64_t));
+    sh->timeout_ms = 120000u;
+    if (const char *t = getenv("HUF_GPU_SHARD_TIMEOUT_MS")) {
+        char *end = NULL;
+        const unsigned long v = strtoul(t, &end, 10);
+        if (end != t && v <= 0xfffffffful) sh->timeout_ms = (uint32_t)v;
+    }
     int rc = HUF_ERROR_FATAL;
     do {
         if (!sh->enc_lens) { rc = HUF_ERROR_MEMORY_ALLOCATION; break; }
         if (hipSetDevice(sh->device) != hipSuccess) break;
         if (hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&sh->stream2, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipEventCreateWithFlags(&sh->ev, hipEventDisableTiming) != hipSuccess) break;
         const size_t words = 4 * (size_t)nranks + 8;
         void *p = NULL;
         if (hufgpu_malloc(ctx, &p, words * 8) != HUF_ERROR_SUCCESS) { rc = HUF_ERROR_MEMORY_ALLOCATION; break; }
@@ -358,19 +559,67 @@ extern "C" int hufgpu_encode_sharded(hufgpu_shard_t *sh, int root, const void *d
                                      uint64_t *stream_len, uint64_t *shard_lens, double *legs_ms)
 {
     if (!sh) return HUF_ERROR_INVALID_ARGUMENT;
-    const int G = sh->nranks, me = sh->rank;
-    if (root < 0 || root >= G) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "root %d of %d ranks", root, G);
+    if (root < 0 || root >= sh->nranks) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "root %d of %d ranks", root, sh->nranks);
+    if (sh->broken) return fail(sh, HUF_ERROR_FATAL, "the group is broken (an earlier call timed out or its communicator failed)");
     SH_HIP(sh, hipSetDevice(sh->device));
+    Call *c = new Call();
+    c->sh = sh; c->body = encode_body; c->root = root; c->d_in = d_in; c->n_total = n_total; c->blocksize = blocksize;
+    c->flags = flags; c->d_out = d_stream; c->cap = stream_cap; c->d_index = d_block_offsets; c->want_legs = legs_ms != NULL;
+    if (!run_call(c)) return HUF_ERROR_FATAL;                  /* (sh->err says it; the call is the helper's to free) */
+    const int rc = c->rc;
+    if (rc == HUF_ERROR_SUCCESS) {
+        if (stream_len) *stream_len = c->out_len;
+        if (shard_lens) memcpy(shard_lens, c->lens.data(), (size_t)sh->nranks * 8);
+        if (legs_ms) memcpy(legs_ms, c->legs, sizeof c->legs);
+    }
+    call_release(c);
+    return rc;
+}
+
+/*
+ * legs_ms (optional, 4 doubles): the plan (foreign streams: index to the host, broadcast), scatter of the stream, decode
+ * + the result all-gather, gather of the output.
+ */
+extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d_stream, uint64_t stream_len,
+                                     const uint64_t *d_block_offsets, uint64_t n_total, uint64_t blocksize, uint32_t flags,
+                                     void *d_out, uint64_t out_cap, uint64_t *raw_len, double *legs_ms)
+{
+    if (!sh) return HUF_ERROR_INVALID_ARGUMENT;
+    if (raw_len) *raw_len = 0;
+    if (root < 0 || root >= sh->nranks) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "root %d of %d ranks", root, sh->nranks);
+    if (sh->broken) return fail(sh, HUF_ERROR_FATAL, "the group is broken (an earlier call timed out or its communicator failed)");
+    SH_HIP(sh, hipSetDevice(sh->device));
+    Call *c = new Call();
+    c->sh = sh; c->body = decode_body; c->root = root; c->d_in = d_stream; c->stream_len = stream_len; c->d_index_in = d_block_offsets;
+    c->n_total = n_total; c->blocksize = blocksize; c->flags = flags; c->d_out = d_out; c->cap = out_cap; c->want_legs = legs_ms != NULL;
+    if (!run_call(c)) return HUF_ERROR_FATAL;
+    const int rc = c->rc;
+    if (raw_len) *raw_len = c->out_len;                         /* (after an error: what a single decoder would have delivered) */
+    if (rc == HUF_ERROR_SUCCESS && legs_ms) memcpy(legs_ms, c->legs, sizeof c->legs);
+    call_release(c);
+    return rc;
+}
+
+namespace {
+
+int encode_body(Call *c)
+{
+    hufgpu_shard_t *sh = c->sh;
+    const int G = sh->nranks, me = sh->rank, root = c->root;
+    const uint64_t n_total = c->n_total, blocksize = c->blocksize;
+    const uint32_t flags = c->flags;
+    const void *d_in = c->d_in;
+    void *d_stream = c->d_out;
+    uint64_t *d_block_offsets = c->d_index;
     sh->have_layout = 0;
-    uint64_t lo[64], hi[64];
-    if (G > 64) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "more than 64 ranks");
-    for (int r = 0; r < G; r++) range_of(n_total, blocksize, r, G, &lo[r], &hi[r]);
+    std::vector<uint64_t> lo(G), hi(G), len(G), start(G + 1);
+    for (int r = 0; r < G; r++) { range_of(n_total, blocksize, r, G, &lo[r], &hi[r]); len[r] = hi[r] - lo[r]; }
     const uint64_t n = hi[me] - lo[me], nb = hufgpu_block_count(n, blocksize);
     const uint64_t bs_total = hufgpu_block_count(n_total, blocksize);
 
     /* 1. buffers; then everybody says whether it is ready (a rank that fails alone must not leave the others in a collective) */
     int ready = 1, why = HUF_ERROR_SUCCESS;
-    if (me == root && n_total && (!d_in || !d_stream || stream_cap < hufgpu_encode_bound(n_total, blocksize) ||
+    if (me == root && n_total && (!d_in || !d_stream || c->cap < hufgpu_encode_bound(n_total, blocksize) ||
                                   ((flags & HUFGPU_SHARD_INDEX) && !d_block_offsets))) {
         ready = 0; why = HUF_ERROR_INVALID_ARGUMENT;
         fail(sh, why, "the root needs the input, room for hufgpu_encode_bound(n_total) bytes of stream and, with HUFGPU_SHARD_INDEX, for the block index");
@@ -387,76 +636,95 @@ extern "C" int hufgpu_encode_sharded(hufgpu_shard_t *sh, int root, const void *d
     for (int r = 0; r < G; r++)
         if (!sh->h_words[1 + r]) return ready ? fail(sh, HUF_ERROR_FATAL, "rank %d is not ready", r) : why;
 
-    Legs legs(sh, legs_ms);
-    /* 2. the input shards leave the root */
-    uint64_t len[64];
-    for (int r = 0; r < G; r++) len[r] = hi[r] - lo[r];
-    { const int rc = scatter(sh, root, (const uint8_t *)d_in, lo, len, sh->d_raw); if (rc) return rc; }
+    Legs legs(sh, c->want_legs ? c->legs : NULL);
+    /* 2. the input shards leave the root - and the root's own shard, which does not move, is encoded on a stream of its
+     *    own beside the sends (timed legs: one after the other).  From here to the size all-gather a rank that fails
+     *    keeps its error to itself and goes on: the others are on their way into that collective (round 5 returned at
+     *    once and left them there). */
+    int err = HUF_ERROR_SUCCESS;
+    const uint8_t *src = me == root ? (const uint8_t *)d_in + lo[me] : sh->d_raw;
+    const bool beside = me == root && !c->want_legs && n != 0;
+    { const int rc = scatter(sh, root, (const uint8_t *)d_in, lo.data(), len.data(), sh->d_raw); if (rc) return rc; }   /* (a failed group: the communicator is gone, nobody waits) */
     legs.next();
     /* 3. every rank encodes its blocks (stream and side tables stay here: HUFGPU_SHARD_OWN_LAYOUT decodes with them) */
-    const uint8_t *src = me == root ? (const uint8_t *)d_in + lo[me] : sh->d_raw;
-    if (n) SH_HUF(sh, hufgpu_encode_sub(sh->ctx, src, n, blocksize, sh->d_comp, sh->comp_cap, sh->d_offs, sh->d_sub, NULL, sh->stream));
+    if (n) {
+        err = hufgpu_encode_sub(sh->ctx, src, n, blocksize, sh->d_comp, sh->comp_cap, sh->d_offs, sh->d_sub, NULL, beside ? sh->stream2 : sh->stream);
+        if (err) fail(sh, err, "hufgpu_encode_sub failed: %s", hufgpu_last_error(sh->ctx));
+        else if (beside && (hipEventRecord(sh->ev, sh->stream2) != hipSuccess || hipStreamWaitEvent(sh->stream, sh->ev, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            err = fail(sh, HUF_ERROR_FATAL, "ordering the root's encode behind its sends failed");
+        }
+    }
     legs.next();
-    /* 4. how long every shard is: one word a rank (the length stands at the end of the shard's block index) */
-    if (n) SH_HIP(sh, hipMemcpyAsync(sh->d_words, sh->d_offs + nb, 8, hipMemcpyDeviceToDevice, sh->stream));
-    else SH_HIP(sh, hipMemsetAsync(sh->d_words, 0, 8, sh->stream));
-    SH_RCCL(sh, rccl()->AllGather(sh->d_words, sh->d_words + 1, 1, RCCL_UINT64, sh->comm, sh->stream));
-    SH_HIP(sh, hipMemcpyAsync(sh->h_words + 1, sh->d_words + 1, (size_t)G * 8, hipMemcpyDeviceToHost, sh->stream));
-    SH_HIP(sh, hipStreamSynchronize(sh->stream));
-    uint64_t start[65];
+    /* 4. how every rank fared and how long its shard is: two words a rank (the length stands at the end of the shard's block index) */
+    {
+        hipError_t e = hipSuccess;
+        sh->h_words[0] = (uint64_t)err;
+        e = hipMemcpyAsync(sh->d_words, sh->h_words, 8, hipMemcpyHostToDevice, sh->stream);
+        if (e == hipSuccess) e = (n && !err) ? hipMemcpyAsync(sh->d_words + 1, sh->d_offs + nb, 8, hipMemcpyDeviceToDevice, sh->stream)
+                                             : hipMemsetAsync(sh->d_words + 1, 0, 8, sh->stream);
+        if (e != hipSuccess) {                                     /* (nothing to put into the collective: the group cannot go on) */
+            (void)hipGetLastError();
+            break_group(sh);
+            return fail(sh, HUF_ERROR_FATAL, "staging the shard's length failed: %s", hipGetErrorString(e));
+        }
+    }
+    SH_RCCL(sh, rccl()->AllGather(sh->d_words, sh->d_words + 2, 2, RCCL_UINT64, sh->comm, sh->stream));
+    SH_HIP(sh, hipMemcpyAsync(sh->h_words + 2, sh->d_words + 2, (size_t)G * 16, hipMemcpyDeviceToHost, sh->stream));
+    SH_WAIT(sh);
+    for (int r = 0; r < G; r++) {                                  /* the first error in rank order, on every rank */
+        const int e = (int)sh->h_words[2 + 2 * r];
+        if (e) return (e == err && r == me) ? err : fail(sh, e, "rank %d failed to encode its blocks", r);
+    }
     start[0] = 0;
-    for (int r = 0; r < G; r++) { sh->enc_lens[r] = sh->h_words[1 + r]; start[r + 1] = start[r] + sh->enc_lens[r]; }
+    for (int r = 0; r < G; r++) { sh->enc_lens[r] = sh->h_words[2 + 2 * r + 1]; start[r + 1] = start[r] + sh->enc_lens[r]; }
     if (start[G] > hufgpu_encode_bound(n_total, blocksize)) return fail(sh, HUF_ERROR_FATAL, "the shards are longer than the bound of the whole");
     legs.next();
     /* 5. the compressed shards to their places in the root's stream: rank order = stream order */
-    { const int rc = gather(sh, root, (uint8_t *)d_stream, start, sh->enc_lens, sh->d_comp); if (rc) return rc; }
+    { const int rc = gather(sh, root, (uint8_t *)d_stream, start.data(), sh->enc_lens, sh->d_comp); if (rc) return rc; }
     if (me == root && sh->enc_lens[me])
         SH_HIP(sh, hipMemcpyAsync((uint8_t *)d_stream + start[me], sh->d_comp, sh->enc_lens[me], hipMemcpyDeviceToDevice, sh->stream));
     if (flags & HUFGPU_SHARD_INDEX) {
         /* the block index of the whole: every shard's entries counted from the stream's first byte, the last entry = the length */
-        uint64_t boff[64], blen[64];
+        std::vector<uint64_t> boff(G), blen(G);
         for (int r = 0; r < G; r++) {
             boff[r] = 8 * hufgpu_block_count(lo[r], blocksize ? blocksize : n_total);   /* (whole blocks in front of the shard) */
             blen[r] = 8 * hufgpu_block_count(hi[r] - lo[r], blocksize);
         }
         { const int rc = rebase(sh, sh->d_stage, sh->d_offs, nb, 0, start[me]); if (rc) return rc; }
-        { const int rc = gather(sh, root, (uint8_t *)d_block_offsets, boff, blen, (const uint8_t *)sh->d_stage); if (rc) return rc; }
+        { const int rc = gather(sh, root, (uint8_t *)d_block_offsets, boff.data(), blen.data(), (const uint8_t *)sh->d_stage); if (rc) return rc; }
         if (me == root) {
             if (nb) SH_HIP(sh, hipMemcpyAsync((uint8_t *)d_block_offsets + boff[me], sh->d_stage, nb * 8, hipMemcpyDeviceToDevice, sh->stream));
             sh->h_words[0] = start[G];
             SH_HIP(sh, hipMemcpyAsync(d_block_offsets + bs_total, sh->h_words, 8, hipMemcpyHostToDevice, sh->stream));
         }
     }
-    SH_HIP(sh, hipStreamSynchronize(sh->stream));
+    SH_WAIT(sh);
     legs.next();
     sh->have_layout = 1;
     sh->enc_root = root;
     sh->enc_total = n_total;
     sh->enc_bs = blocksize;
     sh->enc_len = start[G];
-    if (stream_len) *stream_len = start[G];
-    if (shard_lens) memcpy(shard_lens, sh->enc_lens, (size_t)G * 8);
+    c->out_len = start[G];
+    c->lens.assign(sh->enc_lens, sh->enc_lens + G);
     return HUF_ERROR_SUCCESS;
 }
 
-/*
- * legs_ms (optional, 4 doubles): the plan (foreign streams: index to the host, broadcast), scatter of the stream, decode
- * + the result all-gather, gather of the output.
- */
-extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d_stream, uint64_t stream_len,
-                                     const uint64_t *d_block_offsets, uint64_t n_total, uint64_t blocksize, uint32_t flags,
-                                     void *d_out, uint64_t out_cap, uint64_t *raw_len, double *legs_ms)
+int decode_body(Call *c)
 {
-    if (!sh) return HUF_ERROR_INVALID_ARGUMENT;
-    const int G = sh->nranks, me = sh->rank;
-    if (root < 0 || root >= G) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "root %d of %d ranks", root, G);
-    if (G > 64) return fail(sh, HUF_ERROR_INVALID_ARGUMENT, "more than 64 ranks");
-    SH_HIP(sh, hipSetDevice(sh->device));
+    hufgpu_shard_t *sh = c->sh;
+    const int G = sh->nranks, me = sh->rank, root = c->root;
+    const uint64_t n_total = c->n_total, blocksize = c->blocksize, stream_len = c->stream_len, out_cap = c->cap;
+    const uint32_t flags = c->flags;
+    const void *d_stream = c->d_in;
+    const uint64_t *d_block_offsets = c->d_index_in;
+    void *d_out = c->d_out;
     const bool own = (flags & HUFGPU_SHARD_OWN_LAYOUT) != 0;
     const uint32_t dflags = flags & (HUFGPU_RELAXED_TREE);
     const uint64_t bs = blocksize ? blocksize : n_total;
     const uint64_t nblocks = hufgpu_block_count(n_total, blocksize);
-    if (raw_len) *raw_len = 0;
+    c->out_len = 0;
 
     int ready = 1, why = HUF_ERROR_SUCCESS;
     if (own && !(sh->have_layout && sh->enc_root == root && sh->enc_total == n_total && sh->enc_bs == blocksize)) {
@@ -468,9 +736,11 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
         ready = 0; why = HUF_ERROR_INVALID_ARGUMENT;
         fail(sh, why, "the root needs the stream, its block index (or the layout of this object's last encode) and room for n_total bytes");
     }
-    Legs legs(sh, legs_ms);
+    /* a foreign stream's index goes into the buffers the last encode's layout lives in: that layout is gone */
+    if (!own) sh->have_layout = 0;
+    Legs legs(sh, c->want_legs ? c->legs : NULL);
     /* 1. which blocks a rank decodes: b[r] .. b[r + 1], and where their bytes lie in the stream */
-    uint64_t b[65], cstart[65];
+    std::vector<uint64_t> b(G + 1), cstart(G + 1);
     if (own) {
         uint64_t lo, hi;
         cstart[0] = 0;
@@ -501,6 +771,12 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
                 else {
                     hufgpu_shard_plan_decode(h_offs, nblocks, G, plan);
                     for (int r = 0; r <= G; r++) plan[G + 1 + r] = h_offs[plan[r]];
+                    /* the cuts of a damaged index must not send the root beyond its stream: they rise and end inside it */
+                    for (int r = 0; r < G && ready; r++)
+                        if (plan[G + 1 + r] > plan[G + 2 + r] || plan[G + 2 + r] > stream_len) {
+                            ready = 0; why = HUF_ERROR_INVALID_ARGUMENT;
+                            fail(sh, why, "the block index does not rise (block %llu): the stream cannot be cut along it", (unsigned long long)plan[r + 1]);
+                        }
                 }
                 free(h_offs);
             }
@@ -509,12 +785,12 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
         if (me == root) SH_HIP(sh, hipMemcpyAsync(sh->d_words, plan, (size_t)W * 8, hipMemcpyHostToDevice, sh->stream));
         SH_RCCL(sh, rccl()->Broadcast(sh->d_words, sh->d_words, (size_t)W, RCCL_UINT64, root, sh->comm, sh->stream));
         SH_HIP(sh, hipMemcpyAsync(plan, sh->d_words, (size_t)W * 8, hipMemcpyDeviceToHost, sh->stream));
-        SH_HIP(sh, hipStreamSynchronize(sh->stream));
+        SH_WAIT(sh);
         if (!plan[2 * G + 2]) return me == root ? why : fail(sh, HUF_ERROR_FATAL, "the root is not ready");
         for (int r = 0; r <= G; r++) { b[r] = plan[r]; cstart[r] = plan[G + 1 + r]; }
     }
     const uint64_t nb = b[me + 1] - b[me];
-    uint64_t rlo[64], rlen[64], clen[64];
+    std::vector<uint64_t> rlo(G), rlen(G), clen(G);
     for (int r = 0; r < G; r++) {
         rlo[r] = b[r] * bs < n_total ? b[r] * bs : n_total;
         const uint64_t rhi = b[r + 1] * bs < n_total ? b[r + 1] * bs : n_total;
@@ -538,10 +814,10 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
     }
     legs.next();
     /* 2. the compressed shards (and, for a foreign stream, each one's block index counted from its first byte) */
-    { const int rc = scatter(sh, root, (const uint8_t *)d_stream, cstart, clen, sh->d_comp); if (rc) return rc; }
+    { const int rc = scatter(sh, root, (const uint8_t *)d_stream, cstart.data(), clen.data(), sh->d_comp); if (rc) return rc; }
     const uint64_t *my_offs = sh->d_offs;
     if (!own) {
-        uint64_t ioff[64], ilen[64];
+        std::vector<uint64_t> ioff(G), ilen(G);
         if (me == root) {
             uint64_t at = 0;
             for (int r = 0; r < G; r++) {                      /* rank r's entries b[r] .. b[r + 1] inclusive, rebased, one after the other */
@@ -554,7 +830,7 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
         } else {
             for (int r = 0; r < G; r++) { ioff[r] = 0; ilen[r] = (b[r + 1] - b[r] + 1) * 8; }
         }
-        { const int rc = scatter(sh, root, (const uint8_t *)sh->d_stage, ioff, ilen, (uint8_t *)sh->d_offs); if (rc) return rc; }
+        { const int rc = scatter(sh, root, (const uint8_t *)sh->d_stage, ioff.data(), ilen.data(), (uint8_t *)sh->d_offs); if (rc) return rc; }
     }
     legs.next();
     /* 3. decode; then everybody learns how it went everywhere */
@@ -577,14 +853,16 @@ extern "C" int hufgpu_decode_sharded(hufgpu_shard_t *sh, int root, const void *d
         const int e = (int)sh->h_words[2 + 2 * r];
         total += sh->h_words[2 + 2 * r + 1];
         if (e) {
-            if (raw_len) *raw_len = total;                     /* (the blocks in front of the failing shard and what it delivered) */
+            c->out_len = total;                                /* (the blocks in front of the failing shard and what it delivered) */
             return e == err && r == me ? err : fail(sh, e, "rank %d failed to decode its blocks", r);
         }
     }
     /* 4. the output shards to the root */
-    { const int rc = gather(sh, root, (uint8_t *)d_out, rlo, rlen, sh->d_raw); if (rc) return rc; }
-    SH_HIP(sh, hipStreamSynchronize(sh->stream));
+    { const int rc = gather(sh, root, (uint8_t *)d_out, rlo.data(), rlen.data(), sh->d_raw); if (rc) return rc; }
+    SH_WAIT(sh);
     legs.next();
-    if (raw_len) *raw_len = total;
+    c->out_len = total;
     return HUF_ERROR_SUCCESS;
 }
+
+}  // namespace

@@ -866,7 +866,7 @@ __device__ __forceinline__ bool decode_payload_dfast(DecShared<THREADS> &sh, con
  * is to be used then, the caller walks the tree - for any other shape of tree and for blocks with codes of more than
  * DEC_LUT_BITS bits (their `long` entries need the child links only the walk builds).
  * ==================================================================================== */
-template <int THREADS, bool SPEC>
+template <int THREADS, bool SPEC, bool REGS = false>
 __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len)
 {
     typedef DsubFastLds<THREADS> F;
@@ -1012,6 +1012,35 @@ __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tr
     }
     if (anylong) ok = false;                                                    /* (uniform: codes beyond the table take the walk's child links) */
     if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    if constexpr (REGS) {
+        /* Round 6, decode_regs.hpp's table: decode_sub's entry format (byte << 8 | length) over the 12 bits at a position.  A
+         * first bit of 0: a leaf - every node below the root's only child has two children and no code is longer than the
+         * table.  A first bit of 1 leaves the tree: length = the run of ones (at most 12), byte 0 - on a speculative track
+         * that is what puts it into step (tracks in a run of ones all land on the 0 behind it), on the block's true track the
+         * first bits are checked (decode_regs.hpp). */
+        static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
+        const uint32_t *code = F::code(sh);
+        const uint32_t x0 = (uint32_t)tid * 8u;
+        uint32_t e[8];
+        if (x0 < (1u << (DEC_LUT_BITS - 1))) {
+            uint32_t k = dsub_leaf_of(code, K, x0 << (32 - DEC_LUT_BITS));
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t v = (x0 + j) << (32 - DEC_LUT_BITS);
+                while (k + 1u < K && code[k + 1u] <= v) k++;
+                e[j] = ((uint32_t)F::sym(sh)[k] << 8) | (uint32_t)F::len(sh)[k];
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t v = (x0 + j) << (32 - DEC_LUT_BITS);
+                e[j] = dmin<uint32_t>((uint32_t)__clz((int)~v), (uint32_t)DEC_LUT_BITS);
+            }
+        }
+        *reinterpret_cast<uint4 *>(sh.lut + x0) = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        __syncthreads();
+        return true;
+    }
     {
         static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
         const uint32_t *code = F::code(sh);
@@ -1052,6 +1081,10 @@ __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tr
     return true;
 }
 
+template <int THREADS, class BuildTables>
+__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                                   uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, BuildTables build_tables);      /* decode_regs.hpp */
+
 /* One indexed block (the body of decode_fast_kernel). */
 template <int THREADS>
 __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64_t blk,
@@ -1087,12 +1120,30 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     /* (from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide next to a long
      *  payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05, log text
      *  1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
+    int regs = 0;                                       /* (uniform) what decode_regs.hpp made of the block: 0 = it declined (another shape of tree, long codes) */
+#ifndef DFAST_NO_REGS
+    if (leaf < 0 && m.block_len >= 32768u)
+        regs = decode_payload_regs<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase, nullptr, 0,
+                                            [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len); });
+#ifdef DFAST_REGS_ONLY       /* (experiment: what the other paths in this kernel cost the new one in registers) */
+    if (regs == 0) rc = HUFE_FATAL;
+#else
+    if (leaf < 0 && regs == 0)
+        rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+#endif
+#else
     if (leaf < 0 && !(m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, tree, m.tree_len)))
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+#endif
     DPROF_ADD(6, kt);
     bool good;
+#ifdef DFAST_REGS_ONLY
+    if (true) { good = regs == 1; } else
+#endif
     if (rc != HUFE_OK) {
         good = false;
+    } else if (regs != 0) {
+        good = regs == 1;                               /* (DREG_OK) */
     } else if (leaf >= 0) {
         uint64_t eb = 0, produced = 0;
         good = decode_single_leaf<THREADS, true>(sh, (uint32_t)leaf, pay, m.block_len, pay_bytes, out + obase, &eb, &produced) == HUFE_OK;

@@ -1,0 +1,593 @@
+/* decode_regs.hpp - decode_payload_regs: the payload of a block decoded with the block index alone (what huf_decode()
+   and streams written by the reference get; src/decoder.c:34-96), round 6 form: every codeword is looked up ONCE per
+   synchronisation round and the decoded bytes wait in registers for their place in the output.
+   Part of hufgpu_kernels.hip (one translation unit, gfx950 only). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../hufgpu_common.h"
+#include "decode.hpp"
+#include "decode_sub.hpp"
+#include "decode_fast.hpp"
+
+namespace hufgpu {
+
+/* ======================================================================================
+ * decode_fast.hpp's lean decoder walks every codeword 3.2 times: a scan that counts, 1.2 scans after the starts have
+ * moved, and a write pass that decodes what the scans only measured - 42.5 vector instructions a symbol where
+ * decode_sub_kernel, which is TOLD where a lane's symbols start, takes 10.5 (profiles/r05/dfast_budget.txt).  The
+ * scans could not keep their symbols because a lane does not know where its bytes go before every lane in front of it
+ * has counted.  Here they are kept all the same - in registers:
+ *
+ *   - a lane's share of a segment is at most 288 payload bits and (the shares are cut to the block's bits per
+ *     symbol) about 40 symbols, at most 64: sixteen registers of four bytes (DREG_ITERS);
+ *   - ONE pass form: from the lane's start, four symbols an iteration with decode_sub's loop (entries byte << 8 | length
+ *     over the 11 bits behind a codeword's first bit, a position register that counts down with a gap, both lengths
+ *     subtracted by one v_dot4c) - 27 vector instructions per four symbols, the iteration's four bytes into register k;
+ *     the last iteration that began in front of the share's end is looked at again, codeword by codeword, for the
+ *     end (the first codeword start at or behind the share's end) and the count;
+ *   - the rounds are decode_fast's: lane 0 starts at the segment's true first codeword, every other lane at its own
+ *     first bit, then at its left neighbour's end, until no start changes.  A wave in which a start changed runs the
+ *     pass again (every lane of it: a lane whose start stood decodes what it decoded before);
+ *   - then the counts are summed and every lane stores its registers: whole 16-byte quads, the rest in dwords - the
+ *     bytes behind a lane's last symbol in its last dword are its right neighbour's first (the iteration decoded
+ *     them on the same track), as in decode_fast's write pass.
+ *
+ * What the in-order decoder would have checked is checked: every codeword's first bit is 0 (the trees this path
+ * takes have a root with a left child only and two children everywhere else - dfast_tables_from_tree - so the 2 048
+ * entries of a first bit 0 are all leaves and a 1 leaves the tree: such an entry advances by the run of ones, which is
+ * what puts a speculative track into step), no codeword of the block needs bits past the payload,
+ * the symbols add up to block_len.  A block that fails any of it goes to the exact decoder (decode_fix_kernel /
+ * probe_exact_kernel), which has the reference's error code and byte count.
+ * A share that holds more than 64 codewords (codes far shorter than the block's average) has the segment done again
+ * with shares of half the bits; 128 bits cannot hold more than 64 codewords (no code of these trees has fewer than 2).
+ * ==================================================================================== */
+#define DREG_ROWS 12u                          /* words of a lane's column: the word with its first bit, 288 bits, the last iteration's windows */
+#define DREG_SUB_BITS 288u
+#ifndef DREG_ITERS
+#define DREG_ITERS 16                          /* iterations of four symbols a pass can take: 12 or 16 */
+#endif
+#ifndef DREG_TARGET_SYMS
+#define DREG_TARGET_SYMS (DREG_ITERS == 16 ? 40u : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
+#endif
+#define DREG_SAFE_BITS (8u * DREG_ITERS)       /* a share of so many bits cannot hold more codewords than the registers take: none has fewer than 2 bits */
+
+typedef const __attribute__((address_space(3))) uint32_t *dreg_lds_words;
+typedef const __attribute__((address_space(3))) uint16_t *dreg_lds_halves;
+
+/* The position register (decode_sub.hpp): R = 32 x (the LDS row of the column's word 0) - bits from that word's first bit, a
+ * row = 256 bytes of LDS counted from address 0, the column's word g at row (word 0's row) - g; kept with a gap,
+ * P = (R >> 5) << 8 | (R & 31): P & 0xff00 is the LDS address of the lower of the two rows that hold the 32 bits at the
+ * position, P as it stands the amount v_alignbit_b32 shifts the pair by, a codeword P = (P - len) & 0xff1f. */
+__device__ __forceinline__ uint32_t dreg_gap(uint32_t R) { return ((R << 3) & 0xff00u) | (R & 31u); }
+__device__ __forceinline__ uint32_t dreg_ungap(uint32_t P) { return ((P >> 3) & 0x1fe0u) | (P & 31u); }
+
+__device__ __forceinline__ uint32_t dreg_bits_at(uint32_t P, uint32_t lane4)
+{
+    dreg_lds_words wp = (dreg_lds_words)(uintptr_t)((P & 0xff00u) | lane4);
+    return __builtin_amdgcn_alignbit(wp[64], wp[0], P);
+}
+__device__ __forceinline__ uint32_t dreg_entry(uint32_t lut_addr, uint32_t d)
+{
+    return *(dreg_lds_halves)(uintptr_t)(lut_addr + ((d >> 19) & 0x1ffeu));
+}
+
+/* what a pass leaves in a lane besides the sixteen registers */
+struct DregTrack {
+    uint32_t Pend;       /* the first codeword start at or behind the share's end (the start, for a lane that holds nothing) */
+    uint32_t cnt;        /* codewords that start in front of the share's end */
+    uint32_t ng;         /* iterations that began in front of the share's end: registers 0 .. ng - 1 hold the lane's bytes */
+    uint32_t Pg;         /* where the last of them began */
+    uint32_t fg;         /* the first bits (bit 31) of the codewords in front of it, OR-ed */
+    bool bad;            /* one of the cnt codewords began with a 1 */
+    bool over;           /* sixteen iterations were not enough */
+};
+
+/* One pass of a lane: from Pstart while the position lies in front of Phi (both as position registers). */
+/* (the sixteen registers are sixteen variables, DregSyms' members: an array of them the compiler turns into ONE value of sixteen
+ *  registers in a row, moved, spilled and reloaded whole) */
+struct DregSyms { uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15; };
+__device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uint32_t Pstart, uint32_t Phi, DregSyms &sym, DregTrack &t)
+{
+    uint32_t P = Pstart, Pg = Pstart, ng = 0, firsts = 0, fg = 0;
+#define DREG_WINDOW(PAIR)                                                                                      \
+    {                                                                                                         \
+        const uint32_t d1_ = dreg_bits_at(P, lane4);                                                          \
+        const uint32_t e1_ = dreg_entry(lut_addr, d1_);                                                       \
+        const uint32_t d2_ = d1_ << (e1_ & 31u);                                                              \
+        const uint32_t e2_ = dreg_entry(lut_addr, d2_);                                                       \
+        firsts |= d1_ | d2_;                                                                                  \
+        asm volatile("" : "+v"(firsts));                                                                      \
+        PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x04000501u);           /* byte 1, byte 2, length 1, length 2 */ \
+        P = (uint32_t)__builtin_amdgcn_sdot4((int)PAIR, (int)0xffff0000, (int)P, false) & 0xff1fu;            \
+    }
+    /* one iteration: four symbols into register S (the chain of iterations ends when no lane of the wave has a position
+     * in front of its share's end any more) */
+#define DREG_ITER(S)                                                                                           \
+    {                                                                                                         \
+        const bool act = P > Phi;                                                                             \
+        if (!__any(act)) goto done;                                                                           \
+        /* a lane that is done walks on while its wave does: what it reads there is ignored */                 \
+        Pg = act ? P : Pg;                                                                                    \
+        fg = act ? firsts : fg;                                                                               \
+        ng += act ? 1u : 0u;                                                                                  \
+        uint32_t p01, p23;                                                                                    \
+        DREG_WINDOW(p01)                                                                                      \
+        DREG_WINDOW(p23)                                                                                      \
+        S = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                                     \
+    }
+    DREG_ITER(sym.s0) DREG_ITER(sym.s1) DREG_ITER(sym.s2) DREG_ITER(sym.s3)
+    DREG_ITER(sym.s4) DREG_ITER(sym.s5) DREG_ITER(sym.s6) DREG_ITER(sym.s7)
+    DREG_ITER(sym.s8) DREG_ITER(sym.s9) DREG_ITER(sym.s10) DREG_ITER(sym.s11)
+#if DREG_ITERS == 16
+    DREG_ITER(sym.s12) DREG_ITER(sym.s13) DREG_ITER(sym.s14) DREG_ITER(sym.s15)
+#endif
+done:
+#undef DREG_ITER
+#undef DREG_WINDOW
+    t.over = P > Phi;
+    t.ng = ng;
+    t.Pg = Pg;
+    t.fg = fg;
+    t.Pend = Pstart;
+    t.cnt = 0;
+    t.bad = false;
+    if (__any(ng != 0u)) {
+        /* the last iteration that counts again: its codewords begin at Pg, b1, b2, b3 and it ends at b4 */
+        const uint32_t d1 = dreg_bits_at(Pg, lane4);
+        const uint32_t e1 = dreg_entry(lut_addr, d1);
+        const uint32_t d2 = d1 << (e1 & 31u);
+        const uint32_t e2 = dreg_entry(lut_addr, d2);
+        const uint32_t b1 = (Pg - (e1 & 31u)) & 0xff1fu, b2 = (b1 - (e2 & 31u)) & 0xff1fu;
+        const uint32_t d3 = dreg_bits_at(b2, lane4);
+        const uint32_t e3 = dreg_entry(lut_addr, d3);
+        const uint32_t d4 = d3 << (e3 & 31u);
+        const uint32_t e4 = dreg_entry(lut_addr, d4);
+        const uint32_t b3 = (b2 - (e3 & 31u)) & 0xff1fu, b4 = (b3 - (e4 & 31u)) & 0xff1fu;
+        const bool in1 = b1 > Phi, in2 = b2 > Phi, in3 = b3 > Phi;
+        const uint32_t fb = fg | d1 | (in1 ? d2 : 0u) | (in2 ? d3 : 0u) | (in3 ? d4 : 0u);
+        if (ng != 0u) {
+            t.cnt = 4u * ng - 3u + (in1 ? 1u : 0u) + (in2 ? 1u : 0u) + (in3 ? 1u : 0u);
+            t.Pend = !in1 ? b1 : !in2 ? b2 : !in3 ? b3 : b4;
+            t.bad = (fb >> 31) != 0u;
+        }
+    }
+}
+
+/* the position behind the first n codewords from Pfrom; *first_bits |= their first bits (bit 31).  (One lane a block: the
+ * one that holds the block's last symbol and codewords behind it.) */
+__device__ __forceinline__ uint32_t dreg_walk(uint32_t lut_addr, uint32_t lane4, uint32_t Pfrom, uint32_t n, uint32_t *first_bits)
+{
+    uint32_t P = Pfrom, f = 0;
+#pragma unroll 1
+    while (__any(n != 0u)) {
+        const uint32_t d = dreg_bits_at(P, lane4);
+        const uint32_t e = dreg_entry(lut_addr, d);
+        if (n != 0u) {
+            f |= d;
+            P = (P - (e & 31u)) & 0xff1fu;
+            n--;
+        }
+    }
+    *first_bits |= f;
+    return P;
+}
+
+/* The lane's column: payload words word0 .. word0 + 11 of the segment that begins at bit seg0 (big-endian), word r at row
+ * DREG_ROWS - 1 - r.  In two steps, so that the words are on their way while something else happens (the table build; the
+ * sums and the checks of the segment before): dreg_request asks for thirteen dwords from the 4-byte aligned word that
+ * holds the column's first byte - through a buffer resource over the readable bytes: a lane that wants nothing, or whose
+ * words reach beyond the end, asks beyond it and gets zeros, no branch around the loads -, dreg_commit puts the bytes right
+ * (one v_perm_b32 a word, whatever the payload's alignment) and writes the column; a lane whose words reach beyond
+ * `readable` takes them byte by byte there, with zeros behind the end (the stream's last segment).  A column is read by
+ * its own lane only: no barrier around any of this. */
+struct DregWords {
+    uint32_t d[DREG_ROWS + 1u];
+    bool fast;
+};
+typedef uint32_t dreg_dwords4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ DregWords dreg_request(__amdgpu_buffer_rsrc_t rsrc, uint64_t seg0, uint64_t readable, uint32_t word0, bool wanted)
+{
+    DregWords q;
+    const uint64_t first = (seg0 >> 3) + 4ull * word0;                 /* payload byte of the column's word 0 */
+    q.fast = wanted && first + 4ull * (DREG_ROWS + 1u) <= readable && first < 0xffffff00ull;
+    const uint32_t off = q.fast ? (uint32_t)first : 0xffffff00u;       /* (the resource begins at the aligned word that holds payload byte 0) */
+    const dreg_dwords4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    const dreg_dwords4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
+    const dreg_dwords4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+    q.d[12] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 48u, 0, 0);
+    q.d[0] = v0.x; q.d[1] = v0.y; q.d[2] = v0.z; q.d[3] = v0.w;
+    q.d[4] = v1.x; q.d[5] = v1.y; q.d[6] = v1.z; q.d[7] = v1.w;
+    q.d[8] = v2.x; q.d[9] = v2.y; q.d[10] = v2.z; q.d[11] = v2.w;
+    return q;
+}
+
+__device__ __forceinline__ void dreg_commit(uint32_t *col, const DregWords &q, uint32_t sel, const uint8_t *pay, uint64_t seg0, uint64_t readable, uint32_t word0, bool wanted)
+{
+    /* (word by word: twelve results held for one block of stores are twelve registers more at the kernel's fullest point) */
+    if (q.fast) {
+#pragma unroll
+        for (uint32_t r = 0; r < DREG_ROWS; r++) col[64u * (DREG_ROWS - 1u - r)] = __builtin_amdgcn_perm(q.d[r + 1], q.d[r], sel);
+    }
+    if (__builtin_expect(__ballot(wanted && !q.fast) != 0ull, 0)) {
+        if (wanted && !q.fast) {
+            const uint64_t first = (seg0 >> 3) + 4ull * word0;
+#pragma unroll 1
+            for (uint32_t r = 0; r < DREG_ROWS; r++) col[64u * (DREG_ROWS - 1u - r)] = load_be32(pay, first + 4ull * r, readable);
+        }
+    }
+}
+
+/* Runs of one byte value (decode_fast.hpp, dfast_run_at / dfast_run_jump, on this stage): does ONE codeword, repeated,
+ * fill the column from position `pos` (register P0) to `hi` and a codeword further?  Its length, or 0. */
+__device__ __forceinline__ uint32_t dreg_run_at(uint32_t lut_addr, uint32_t lane4, uint32_t P0, uint32_t pos, uint32_t hi)
+{
+    /* (one window after the other, three registers: this runs next to the sixteen that hold the lane's symbols) */
+    uint32_t w = dreg_bits_at(P0, lane4);
+    const uint32_t L = dreg_entry(lut_addr, w) & 31u;
+    if ((w >> 31) != 0u || L == 0u) return 0u;
+    bool same = true;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 10; k++) {
+        const uint32_t wn = dreg_bits_at(P0 - ((k + 1u) << 8), lane4);       /* (32 bits on: one row down) */
+        const bool counts = pos + 32u * k < hi;
+        if (counts && __builtin_amdgcn_alignbit(w, wn, 32u - L) != w) same = false;
+        w = wn;
+    }
+    return same ? L : 0u;
+}
+
+/* A lane that has just been put right and holds one codeword over and over is the beginning of a run as far as this wave
+ * is concerned: the lanes to its right take the codeword starts that follow from it if THEIR shares hold the same
+ * repetition from there on.  Returns (start, end, moved): a lane that moved runs its pass in the next round. */
+__device__ __forceinline__ uint4 dreg_run_jump(uint32_t lut_addr, uint32_t lane4, uint32_t rbase, bool changed, bool dead, uint32_t hi, uint32_t lo, uint32_t pay_rel,
+                                            uint32_t start, uint32_t end)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t myL = (changed && start < hi) ? dreg_run_at(lut_addr, lane4, dreg_gap(rbase - start), start, hi) : 0u;
+    int src = (myL != 0u) ? (int)lane : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(src, o);
+        if ((int)lane >= o && t > src) src = t;
+    }
+    const uint32_t P = (uint32_t)__shfl((int)start, src < 0 ? 0 : src);
+    const uint32_t L = (uint32_t)__shfl((int)myL, src < 0 ? 0 : src);
+    bool pass = false;
+    uint32_t cand = 0;
+    if (src >= 0 && src < (int)lane && !dead && !changed && lo >= P) {
+        const uint32_t back = (lo - P) % L;
+        cand = lo + (back ? L - back : 0u);
+        pass = cand >= hi || (cand < pay_rel && dreg_run_at(lut_addr, lane4, dreg_gap(rbase - cand), cand, hi) == L);
+    }
+    int bad = (src >= 0 && src < (int)lane && !pass) ? (int)lane : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(bad, o);
+        if ((int)lane >= o && t > bad) bad = t;
+    }
+    if (pass && bad <= src && cand != start) {
+        const uint32_t cnt = (cand < hi) ? (hi - cand + L - 1u) / L : 0u;
+        return make_uint4(cand, cand + cnt * L, 1u, 0u);
+    }
+    return make_uint4(start, end, 0u, 0u);
+}
+
+#define DREG_MAX_ROUNDS 64
+
+/* a segment: where it begins (bit seg0 of the payload, a multiple of 32; its first codeword at seg0 + first) and the bits of a share */
+struct DregSeg { uint64_t seg0; uint32_t sb, first; bool hinted; };
+template <int THREADS>
+__device__ __forceinline__ DregSeg dreg_plan(uint64_t ts, bool trust, uint32_t shrink, uint32_t cap, bool probing, uint64_t hint_bytes, uint64_t pay_bytes)
+{
+    DregSeg g;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+    g.seg0 = ts & ~31ull;
+    g.first = (uint32_t)(ts - g.seg0);
+    const uint32_t SUB = dmax<uint32_t>(cap >> shrink, 64u);
+    uint32_t sb = SUB;
+    g.hinted = uni32((probing && trust && hint_bytes * 8ull > g.seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
+    if ((!probing || g.hinted) && pay_bits > g.seg0) {
+        /* equal shares of what is left (decode_fast.hpp: the block's last segment as full as the others) */
+        const uint64_t rem = (g.hinted ? hint_bytes * 8ull : pay_bits) - g.seg0;
+        if (rem < (1ull << 31)) {
+            const uint32_t r32 = (uint32_t)rem, per = (uint32_t)THREADS * SUB;
+            const uint32_t nseg = (r32 + per - 1u) / per;
+            const uint32_t even = (r32 + nseg * (uint32_t)THREADS - 1u) / (nseg * (uint32_t)THREADS);
+            sb = dmin<uint32_t>(dmax<uint32_t>(even, 64u), SUB);
+        }
+    }
+    g.sb = uni32(sb);
+    return g;
+}
+
+/* A block's payload.  build_tables() (workgroup-uniform result) fills sh.lut with dfast_tables_from_tree<THREADS, SPEC, true>'s
+ * table - it runs HERE, behind the request of the first segment's words, which then arrive while the tables are built.
+ * Returns DREG_NO_TABLES when it declined (nothing was decoded: the caller takes another path), DREG_OK when block_len
+ * symbols were written and everything the in-order decoder would have checked held, DREG_FAILED otherwise.  Arguments as
+ * decode_payload_fast_impl (decode_fast.hpp): end_bits = the caller does not know where the payload ends (the raw-stream
+ * probe: pay_bytes = the rest of the stream) and wants to be told, hint_bytes = where it probably ends. */
+enum { DREG_NO_TABLES = 0, DREG_OK = 1, DREG_FAILED = 2 };
+template <int THREADS, class BuildTables>
+__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                                   uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, BuildTables build_tables)
+{
+    constexpr int WAVES = THREADS / 64;
+    static_assert(offsetof(DecShared<THREADS>, pay) % 256 == 0, "a row of a column is 256 bytes at a multiple of 256: its number is a bit field of an LDS address");
+    static_assert((uint32_t)THREADS * DREG_ROWS <= DfastLds<THREADS>::AREA_WORDS, "the columns fit pay + marks");
+    static_assert(sizeof(DecShared<THREADS>) <= 65536 - 256, "rows are numbered in eight bits");
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = (int)uni32((uint32_t)tid >> 6);
+    uint32_t *slice = sh.pay + (uint32_t)wave * (DREG_ROWS * 64u);
+    const uint32_t slice_a = uni32((uint32_t)(uintptr_t)(dreg_lds_words)slice);
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    const uint32_t r_top = 32u * ((slice_a >> 8) + DREG_ROWS - 1u);         /* R of the first bit of a column's word 0 */
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(dreg_lds_halves)sh.lut;
+    const uint64_t pay_bits = pay_bytes * 8ull;
+    /* the payload through a buffer resource from the aligned word that holds its first byte to the end of what may be read */
+    const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
+    const uint32_t mis = (uint32_t)(pay_a & 3u);
+    const uint32_t sel = (mis << 24) | ((mis + 1u) << 16) | ((mis + 2u) << 8) | (mis + 3u);
+    const uint64_t span = readable + mis;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(pay_a - mis), (short)0, (int)(uint32_t)dmin<uint64_t>(span, 0xffffff00ull), 0x00020000);
+    /* shares cut for DREG_TARGET_SYMS symbols at the block's bits per symbol (the probe: at the hint's; without one, whole) */
+    uint32_t cap = DREG_SUB_BITS;
+    {
+        const uint64_t known = end_bits ? ((hint_bytes && hint_bytes <= pay_bytes) ? hint_bytes * 8ull : 0ull) : pay_bits;
+        if (known != 0ull && known < (1ull << 32)) {
+            const float est = (float)DREG_TARGET_SYMS * ((float)(uint32_t)known / (float)block_len);
+            cap = est >= (float)DREG_SUB_BITS ? DREG_SUB_BITS : dmax<uint32_t>((uint32_t)est, 64u);
+        }
+    }
+    cap = uni32(cap);
+    /* (plain functions of plain values, no closures: a closure over a dozen locals is an object the compiler keeps whole -
+     *  sixteen registers in a row, spilled and reloaded as one) */
+#define DREG_PLAN(TS, TRUST, SHRINK) dreg_plan<THREADS>((TS), (TRUST), (SHRINK), cap, end_bits != nullptr, hint_bytes, pay_bytes)
+#define DREG_REL(G) (pay_bits > (G).seg0 ? (uint32_t)dmin<uint64_t>(pay_bits - (G).seg0, 0xfffffff0ull) : 0u)       /* payload bits from seg0 on */
+#define DREG_WORD0(G) ((tid == 0 ? (G).first : (uint32_t)tid * (G).sb) >> 5)
+#define DREG_WANTED(G) ((uint32_t)tid * (G).sb < DREG_REL(G))
+    uint32_t shrink = 0;                                               /* (uniform) halvings of the shares after a lane ran out of registers */
+    uint64_t true_start = 0, produced = 0;
+    bool ok = true;
+    bool trust = true;
+    DregSeg g = DREG_PLAN(0, true, 0);
+#ifndef DREG_NO_PRE0
+    const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+    if (!build_tables()) return DREG_NO_TABLES;
+#else
+    if (!build_tables()) return DREG_NO_TABLES;
+    const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+#endif
+    dreg_commit(slice + lane, q, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+    bool have = true;                                                  /* (uniform) the columns hold segment g */
+    while (produced < block_len) {
+        if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }
+        unsigned long long pt = DPROF_T();
+        DregSyms sym;                                                  /* (the segment's: nothing of them lives from one segment to the next) */
+        if (!have) {                                                   /* a segment done again with other shares: staged on the spot */
+            g = DREG_PLAN(true_start, trust, shrink);
+            const DregWords q2 = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+            dreg_commit(slice + lane, q2, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+        }
+        have = false;
+        const uint64_t seg0 = g.seg0;
+        const uint32_t sb = g.sb, first = g.first;
+        const bool hinted = g.hinted;
+        const uint32_t pay_rel = DREG_REL(g);
+        const uint32_t hi = ((uint32_t)tid + 1u) * sb;
+        const uint32_t lo = tid == 0 ? first : hi - sb;
+        const uint32_t rbase = r_top + 32u * (lo >> 5);               /* R = rbase - position */
+        uint32_t start = lo;
+        bool dead = hi - sb >= pay_rel;
+        const uint64_t remaining = block_len - produced;
+        bool guessed = false;
+        if (hinted) {
+            const uint32_t bound = (uint32_t)dmin<uint64_t>(hint_bytes * 8ull - seg0, 0xfffffff0ull);
+            if (!dead && hi - sb >= bound) dead = true;
+            guessed = (uint32_t)(THREADS - 1) * sb >= bound;
+        } else if (end_bits && trust && produced != 0) {
+            const float est = (float)remaining * ((float)true_start / (float)produced);
+            const float lim_f = (float)first + est * 1.0625f + 1024.0f;
+            const uint32_t bound = lim_f < 4.0e9f ? (uint32_t)lim_f : 0xffffffffu;
+            if (!dead && hi - sb >= bound) dead = true;
+            guessed = (uint32_t)(THREADS - 1) * sb >= bound;
+        }
+        /* codewords that start at or behind the payload's end are nobody's */
+        const uint32_t hi_eff = dmin<uint32_t>(hi, pay_rel);
+        uint32_t Phi = dreg_gap(rbase - (dead ? lo : hi_eff));
+        DregTrack t;
+        t.Pend = 0; t.cnt = 0; t.ng = 0; t.Pg = 0; t.fg = 0; t.bad = false; t.over = false;
+        uint32_t end = hi, cnt = 0;
+        bool need = !dead;
+        int rounds = 0;
+        DPROF_ADD(1, pt); pt = DPROF_T();
+        for (;;) {
+            if (__ballot(need)) {
+                DFAST_DBGW(8, 1);
+                DFAST_DBGW(rounds == 0 ? 6 : rounds == 1 ? 7 : 14, 1);
+                dreg_pass(lut_addr, lane4, dreg_gap(rbase - (dead ? lo : start)), Phi, sym, t);
+                /* (a track of more than 64 look-ups - a speculative one through entries that leave the tree, bit by bit; or,
+                 *  when the rounds are over, the lane's true one - ends where the share does for now: its neighbour is not
+                 *  sent in front of its own column) */
+                end = (dead || t.over) ? hi : rbase - dreg_ungap(t.Pend);
+                cnt = dead ? 0u : t.cnt;
+            }
+            if (rounds == 0 && end_bits && trust && !hinted) {
+                /* (the probe without a hint) the speculative counts are right to a few symbols either way: a lane in front of
+                 * which they already hold the rest of the block and a margin is taken for dead */
+                uint32_t spec_total;
+                const uint32_t exs = block_excl_scan_u32<THREADS>(cnt, sh.part, spec_total);
+                if (!dead && (uint64_t)exs >= remaining + 128u + ((uint32_t)tid >> 2)) {
+                    dead = true;
+                    end = hi;
+                    cnt = 0;
+                    Phi = dreg_gap(rbase - lo);
+                }
+                guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
+            }
+            if (lane == 63) sh.wend[wave] = end;
+            __syncthreads();
+            if (rounds == 0) { DPROF_ADD(2, pt); pt = DPROF_T(); }
+            uint32_t ns = wave_up1_u32(end);
+            if (lane == 0) ns = (tid == 0) ? first : sh.wend[wave - 1];
+            const bool changed = (ns != start) && !dead;
+            if (changed) start = ns;
+            bool jumped = false;
+#ifndef DREG_EXP_NOJUMP
+            if (rounds >= DFAST_JUMP_FROM_ROUND && __ballot(changed)) {
+                DFAST_DBGW(15, 1);
+                const uint4 r = dreg_run_jump(lut_addr, lane4, rbase, changed, dead, hi_eff, hi - sb, pay_rel, start, end);
+                start = r.x; end = r.y; jumped = r.z != 0u;
+            }
+#endif
+            need = changed || jumped;
+            /* does any lane of the workgroup go on?  (One barrier: a wave's word is written behind the barrier above and read
+             * behind this one, and the next round's barrier above lies in front of its next writer; everyone has read sh.wend.) */
+            const uint32_t wave_needs = __ballot(need) != 0ull ? 1u : 0u;   /* (the vote of the whole wave: outside the lane's branch) */
+            if (lane == 0) sh.wtile[wave] = wave_needs;
+            __syncthreads();
+            {
+                uint32_t any = 0;
+#pragma unroll
+                for (int i = 0; i < WAVES; i++) any |= sh.wtile[i];
+                if (uni32(any) == 0u) break;
+            }
+            DFAST_DBG(10, 1);
+            if (++rounds > DREG_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }
+        }
+        if (!ok) break;
+        DPROF_ADD(3, pt); pt = DPROF_T();
+        /* where the next segment begins is known: its words are asked for NOW, in front of this segment's stores - loads
+         * and stores come back in the order they went out, and behind the stores the words would wait for every one of
+         * them - and arrive under the sums */
+        const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
+        const uint64_t next_start = seg0 + last_end;
+        const DregSeg gn = DREG_PLAN(next_start, true, shrink);
+#ifndef DREG_EXP_NOPRE
+        const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
+#endif
+        /* the counts' sum; above it the lanes whose true track ran out of registers (counts: at most 64 a lane, 2^15 a segment) */
+        uint32_t seg_total;
+        const uint32_t ex = block_excl_scan_u32<THREADS>(cnt | ((uint32_t)(t.over && !dead) << 16), sh.part, seg_total) & 0xffffu;
+        seg_total = uni32(seg_total);
+        if ((seg_total >> 16) != 0u) {                                 /* a share of more than 64 codewords: the segment again, shares of half the bits */
+            DFAST_DBG(9, 1);
+            shrink++;
+            continue;
+        }
+        if (guessed) DFAST_DBG(12, 1);
+        if (guessed && (uint64_t)seg_total < remaining) {             /* a guess that did not hold: the segment again, without */
+            DFAST_DBG(13, 1);
+            trust = false;
+            continue;
+        }
+        trust = true;
+        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
+        uint32_t quota = 0;
+        if (ex < take) {
+            quota = take - ex;
+            if (quota > cnt) quota = cnt;
+        }
+        DPROF_ADD(4, pt); pt = DPROF_T();
+        bool lane_ok = true;
+        uint32_t qe = end;                                             /* the position behind the lane's last symbol of the block */
+        const bool partial = quota != 0u && quota < cnt;               /* the block ends inside this lane's codewords */
+#ifndef DREG_EXP_NOWALK
+        if (__ballot(partial)) {
+            /* from the last iteration's start when the block's last symbol lies in it, else from the lane's start */
+            const bool tail = partial && quota > 4u * (t.ng - 1u);
+            uint32_t fb = tail ? t.fg : 0u;
+            const uint32_t Pq = dreg_walk(lut_addr, lane4, tail ? t.Pg : dreg_gap(rbase - start), partial ? (tail ? quota - 4u * (t.ng - 1u) : quota) : 0u, &fb);
+            if (partial) {
+                qe = rbase - dreg_ungap(Pq);
+                lane_ok = (fb >> 31) == 0u;
+            }
+        }
+#endif
+        /* this segment's columns have been read for the last time: the next segment's words into them (the wait for them
+         * counts only what went out before them) */
+        if (produced + take < block_len) {
+#ifdef DREG_EXP_NOPRE
+            const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
+#endif
+            dreg_commit(slice + lane, qn, sel, pay, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
+            have = true;
+        }
+        if (quota != 0u) {
+            if (!partial && t.bad) lane_ok = false;
+            if (qe > pay_rel) lane_ok = false;                         /* a codeword of the block needs bits past the payload */
+            if (end_bits && ex + quota == take && (uint64_t)take == remaining) sh.qend = qe;
+            /* the registers: all of the lane's symbols and the whole last dword still inside this block's output, or
+             * whole dwords and the rest byte by byte */
+            uint8_t *gp = gout + produced + ex;
+            const bool whole = !partial && produced + ex + ((quota + 3u) & ~3u) <= block_len;
+            const uint32_t nd = whole ? (quota + 3u) >> 2 : quota >> 2;
+            typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
+            typedef uint32_t unaligned_q4 __attribute__((ext_vector_type(4), aligned(1)));
+#ifdef DREG_DWORD_STORES
+#define DREG_QUAD(Q4, A, B, C, D)                                                                              \
+            if (nd > 4u * (Q4)) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4)) = sym.A;                  \
+            if (nd > 4u * (Q4) + 1u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 4u) = sym.B;        \
+            if (nd > 4u * (Q4) + 2u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 8u) = sym.C;        \
+            if (nd > 4u * (Q4) + 3u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 12u) = sym.D;
+#else
+#define DREG_QUAD(Q4, A, B, C, D)                                                                              \
+            if (nd >= 4u * (Q4) + 4u) {                                                                       \
+                unaligned_q4 v4;                                                                              \
+                v4.x = sym.A; v4.y = sym.B; v4.z = sym.C; v4.w = sym.D;                                       \
+                *reinterpret_cast<unaligned_q4 *>(gp + 16u * (Q4)) = v4;                                      \
+            } else {                                                                                          \
+                if (nd > 4u * (Q4)) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4)) = sym.A;              \
+                if (nd > 4u * (Q4) + 1u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 4u) = sym.B;    \
+                if (nd > 4u * (Q4) + 2u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 8u) = sym.C;    \
+            }
+#endif
+            DREG_QUAD(0, s0, s1, s2, s3)
+            DREG_QUAD(1, s4, s5, s6, s7)
+            DREG_QUAD(2, s8, s9, s10, s11)
+#if DREG_ITERS == 16
+            DREG_QUAD(3, s12, s13, s14, s15)
+#endif
+#undef DREG_QUAD
+            if (!whole && (quota & 3u) != 0u) {
+                const uint32_t kq = quota >> 2;
+                uint32_t tw = sym.s0;
+#define DREG_PICK(K, S) tw = kq == (K) ? sym.S : tw;
+                DREG_PICK(1, s1) DREG_PICK(2, s2) DREG_PICK(3, s3) DREG_PICK(4, s4) DREG_PICK(5, s5) DREG_PICK(6, s6) DREG_PICK(7, s7)
+                DREG_PICK(8, s8) DREG_PICK(9, s9) DREG_PICK(10, s10) DREG_PICK(11, s11)
+#if DREG_ITERS == 16
+                DREG_PICK(12, s12) DREG_PICK(13, s13) DREG_PICK(14, s14) DREG_PICK(15, s15)
+#endif
+#undef DREG_PICK
+                for (uint32_t c = 0; c < (quota & 3u); c++) gp[(quota & ~3u) + c] = (uint8_t)(tw >> (8u * c));
+            }
+        }
+        {
+            /* is every lane content?  (The waves' words lie behind the rounds': this barrier also ends the segment.) */
+            const uint32_t wave_bad = __ballot(!lane_ok) != 0ull ? 1u : 0u;
+            if (lane == 0) sh.wtile[WAVES + wave] = wave_bad;
+            __syncthreads();
+            uint32_t bad_any = 0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) bad_any |= sh.wtile[WAVES + i];
+            if (uni32(bad_any) != 0u) { ok = false; DFAST_DBG(2, 1); break; }
+        }
+        DPROF_ADD(5, pt);
+        DFAST_DBG(11, 1);
+        produced += take;
+        if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }
+        if (end_bits && produced == block_len) *end_bits = seg0 + (uint64_t)uni32(sh.qend);
+        true_start = next_start;
+        g = gn;
+    }
+    return ok ? DREG_OK : DREG_FAILED;
+#undef DREG_PLAN
+#undef DREG_REL
+#undef DREG_WORD0
+#undef DREG_WANTED
+}
+
+}  // namespace hufgpu

@@ -7,6 +7,7 @@
 #include "../hufgpu_common.h"
 #include "decode.hpp"
 #include "decode_fast.hpp"
+#include "decode_regs.hpp"
 
 namespace hufgpu {
 
@@ -282,9 +283,18 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
          * offset as a first guess at where this one's payload ends: probe 1.62 -> 1.53 ms per GiB of zipf255, the indexed decoder's time (profiles/r04/raw_stream_kernels.txt) */
         const uint64_t nextc = (blockIdx.x + 1u < gridDim.x) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
         const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
+#ifndef DFAST_NO_REGS
+        const int shaped = !(block_len >= 32768u && tl <= HUF_TREE_MAX) ? 0 :
+            decode_payload_regs<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint,
+                                         [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, stream + c + HUF_HEADER_FIXED, tl); });
+        if (shaped != 0 ? shaped == 1 /* DREG_OK */
+                        : (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0 &&
+                           decode_payload_dfast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint))) {
+#else
         const bool shaped = block_len >= 32768u && tl <= HUF_TREE_MAX && dfast_tables_from_tree<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl);
         if ((shaped || (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0)) &&
             decode_payload_dfast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint)) {
+#endif
             if (threadIdx.x == 0) {
                 cand_status[blockIdx.x] = HUFE_OK;
                 cand_end[blockIdx.x] = pay0 + ((end_bits + 7) >> 3);

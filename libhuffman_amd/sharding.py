@@ -61,7 +61,8 @@ class ShardGroup:
                 buf = C.create_string_buffer(128)
                 err = self.lib.hufgpu_shard_unique_id(buf)
                 box[0] = (err, buf.raw, self.lib.hufgpu_shard_last_error(None).decode())
-            dist.broadcast_object_list(box, src=0, group=group)
+            # (src is a GLOBAL rank: the group's first member, which need not be rank 0 of the world)
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             err, id_bytes, why = box[0]
             if err:
                 raise RuntimeError("RCCL is not available to the C library: %s" % why)
@@ -69,6 +70,10 @@ class ShardGroup:
         err = self.lib.hufgpu_shard_create(C.byref(self._sh), codec._ctx, None, id_bytes, self.nranks, self.rank)
         if err:
             raise RuntimeError("hufgpu_shard_create failed (%d): %s" % (err, self.lib.hufgpu_shard_last_error(None).decode()))
+
+    def set_timeout(self, ms: int):
+        """deadline of every sharded call in milliseconds (0 = none; default HUF_GPU_SHARD_TIMEOUT_MS or 120 000)"""
+        self._check(self.lib.hufgpu_shard_set_timeout(self._sh, int(ms)), "hufgpu_shard_set_timeout")
 
     def close(self):
         if self._sh:

@@ -1,17 +1,20 @@
 /*
- * mock_rccl.cpp - TEST ONLY.  The twelve RCCL entry points libhuffman_amd/csrc/hufgpu_sharded.hip looks up, over named
+ * mock_rccl.cpp - TEST ONLY.  The fourteen RCCL entry points libhuffman_amd/csrc/hufgpu_sharded.hip looks up, over named
  * pipes between processes that SHARE ONE GPU, so that the multi-rank control flow of hufgpu_encode_sharded /
  * hufgpu_decode_sharded (who sends what to whom, in which group, at which offset) runs on a one-GPU box - RCCL itself
  * refuses two ranks on one device.  HUF_GPU_RCCL_LIB points the library at this file's .so; MOCK_RCCL_DIR names the
  * directory the pipes live in.  Semantics kept: operations inside ncclGroupStart/End are deferred to the group's end and
  * run concurrently there (a thread a peer and direction); an operation waits for the work enqueued on its stream before
  * it touches the buffer, and the caller's thread returns when the data has arrived.  Not kept: asynchrony (every
- * operation is complete when the call returns), performance, error reporting beyond "it failed".
+ * operation is complete when the call returns - a peer that never arrives holds the CALL, where the real RCCL would hold
+ * the stream), performance, error reporting beyond "it failed".  ncclCommAbort makes every blocked operation of the
+ * communicator return a failure within a few milliseconds (the pipes are opened and read without blocking, in a poll loop).
  * build: hipcc -O1 -fPIC -shared tests/mock_rccl/mock_rccl.cpp -o <somewhere>/libmock_rccl.so -lpthread
  */
 #include <hip/hip_runtime.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <poll.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,7 +25,7 @@
 #include <vector>
 
 namespace {
-struct Comm { int nranks, rank, device; char tag[33]; int fd_send[64], fd_recv[64]; };   /* pipes stay open for the communicator's life: data written is not lost between two groups */
+struct Comm { int nranks, rank, device; char tag[33]; int fd_send[64], fd_recv[64]; volatile int aborted; };   /* pipes stay open for the communicator's life: data written is not lost between two groups */
 struct Op { int send; void *dev; size_t bytes; int peer; Comm *c; hipStream_t stream; };
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
@@ -34,13 +37,19 @@ void pipe_path(const Comm *c, int from, int to, char *out, size_t n)
     snprintf(out, n, "%s/%s_%d_%d", dir ? dir : "/tmp", c->tag, from, to);
 }
 
-bool io_all(int fd, char *p, size_t n, bool wr)
+/* (the descriptors are non-blocking: a peer that is not there yet - a read end without a writer reads 0 bytes, a full pipe
+ *  refuses - is waited for in steps of a few milliseconds, so that an abort of the communicator is seen) */
+bool io_all(const Comm *c, int fd, char *p, size_t n, bool wr)
 {
     while (n) {
+        if (c->aborted) return false;
         const ssize_t k = wr ? write(fd, p, n) : read(fd, p, n);
+        if (k > 0) { p += k; n -= (size_t)k; continue; }
         if (k < 0 && errno == EINTR) continue;
-        if (k <= 0) return false;
-        p += k; n -= (size_t)k;
+        if (k < 0 && errno != EAGAIN && errno != EWOULDBLOCK) return false;
+        struct pollfd pf = {fd, (short)(wr ? POLLOUT : POLLIN), 0};
+        (void)poll(&pf, 1, 5);
+        if (k == 0 && !wr) usleep(2000);                /* (no writer yet: poll returns at once with POLLHUP) */
     }
     return true;
 }
@@ -58,7 +67,8 @@ void *lane_main(void *arg)
     int *slot = first.send ? &first.c->fd_send[first.peer] : &first.c->fd_recv[first.peer];
     if (*slot < 0) {
         if (mkfifo(path, 0600) != 0 && errno != EEXIST) return NULL;
-        *slot = open(path, first.send ? O_WRONLY : O_RDONLY);             /* (waits for the peer's end) */
+        /* (a write end opens only when the read end is there: ENXIO until then) */
+        while (!first.c->aborted && (*slot = open(path, (first.send ? O_WRONLY : O_RDONLY) | O_NONBLOCK)) < 0 && errno == ENXIO) usleep(2000);
     }
     const int fd = *slot;
     if (fd < 0) return NULL;
@@ -67,9 +77,9 @@ void *lane_main(void *arg)
         char *host = (char *)malloc(op.bytes ? op.bytes : 1);
         if (!host) { ok = false; break; }
         if (op.send) {
-            ok = hipMemcpy(host, op.dev, op.bytes, hipMemcpyDeviceToHost) == hipSuccess && io_all(fd, host, op.bytes, true);
+            ok = hipMemcpy(host, op.dev, op.bytes, hipMemcpyDeviceToHost) == hipSuccess && io_all(op.c, fd, host, op.bytes, true);
         } else {
-            ok = io_all(fd, host, op.bytes, false) && hipMemcpy(op.dev, host, op.bytes, hipMemcpyHostToDevice) == hipSuccess;
+            ok = io_all(op.c, fd, host, op.bytes, false) && hipMemcpy(op.dev, host, op.bytes, hipMemcpyHostToDevice) == hipSuccess;
         }
         free(host);
         if (!ok) break;
@@ -138,6 +148,10 @@ int ncclCommDestroy(void *comm)
     free(c);
     return 0;
 }
+/* every blocked operation of the communicator returns a failure; the object itself is left to the process's end (its
+ * operations may still be on their way out) */
+int ncclCommAbort(void *comm) { ((Comm *)comm)->aborted = 1; return 0; }
+int ncclCommGetAsyncError(void *comm, int *err) { *err = ((Comm *)comm)->aborted ? 1 : 0; return 0; }
 int ncclCommCount(void *comm, int *n) { *n = ((Comm *)comm)->nranks; return 0; }
 int ncclCommUserRank(void *comm, int *r) { *r = ((Comm *)comm)->rank; return 0; }
 const char *ncclGetErrorString(int r) { return r ? "mock RCCL: the operation failed" : "no error"; }

@@ -27,6 +27,46 @@ while not os.path.exists(id_path):
     time.sleep(0.01)
 group = ShardGroup(codec, id_bytes=open(id_path, "rb").read(), nranks=nranks, rank=rank)
 
+if len(sys.argv) > 4 and sys.argv[4] == "absent":
+    # The last rank never makes the call.  Every other rank must come back with HUF_ERROR_FATAL within the deadline (and
+    # a little: the helper's host call is inside the transport, the abort comes from the calling thread), the group is
+    # broken afterwards - the next call fails at once - and can still be destroyed.
+    if rank == nranks - 1:
+        time.sleep(8.0)
+        print("DONE (never arrived)")
+        sys.exit(0)
+    group.set_timeout(1500)
+    n_total, bs = 3 * (1 << 20), 65536
+    data = stream = None
+    if rank == 0:
+        data = torch.from_numpy(datagen.zipf255(n_total)).cuda()
+        stream = torch.zeros(codec.encode_bound(n_total, bs) + 8, dtype=torch.uint8, device="cuda")
+    t0 = time.time()
+    try:
+        group.encode(data, n_total, bs, stream)
+        raise SystemExit("the call came back although a rank never arrived")
+    except HuffmanGpuError as e:
+        took = time.time() - t0
+        assert e.code == 6, e                             # HUF_ERROR_FATAL
+        assert 1.4 <= took <= 6.0, took
+        assert "timed out" in str(e) or "broken" in str(e), e
+    t0 = time.time()
+    for call in (lambda: group.encode(data, n_total, bs, stream), lambda: group.decode(stream, 10, n_total, bs, None, own_layout=True)):
+        try:
+            call()
+            raise SystemExit("a broken group took a call")
+        except HuffmanGpuError as e:
+            assert e.code == 6 and "broken" in str(e), e
+    assert time.time() - t0 < 0.5
+    group.close()
+    # the codec itself is untouched by all this
+    if rank == 0:
+        out, offs, length = codec.encode(data, bs)
+        back = torch.empty(n_total, dtype=torch.uint8, device="cuda")
+        assert codec.decode(out, length, offs, codec.block_count(n_total, bs), back) == n_total and torch.equal(back, data)
+    print("DONE (returned HUF_ERROR_FATAL after %.2f s)" % took)
+    sys.exit(0)
+
 CASES = [  # n_total, blocksize, root, workload
     (5 * (1 << 20) + 17, 65536, 0, "zipf255"),
     (5 * (1 << 20) + 17, 65536, 1, "uniform256"),

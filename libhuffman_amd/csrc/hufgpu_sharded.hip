@@ -404,6 +404,8 @@ bool run_call(Call *c)
         pthread_mutex_lock(&sh->mu);
         sh->orphans--;
         pthread_mutex_unlock(&sh->mu);
+        /* (the helper's own words - "the all-gather failed" - are the abort's echo: what happened is the deadline) */
+        fail(sh, HUF_ERROR_FATAL, "timed out after %u ms inside the transport: a rank of the group did not arrive (HUF_GPU_SHARD_TIMEOUT_MS); the group is broken", sh->timeout_ms);
     } else {
         pthread_detach(th);
     }

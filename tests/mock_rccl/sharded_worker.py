@@ -47,7 +47,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "absent":
         raise SystemExit("the call came back although a rank never arrived")
     except HuffmanGpuError as e:
         took = time.time() - t0
-        assert e.code == 6, e                             # HUF_ERROR_FATAL
+        assert e.err == 4, e                              # HUF_ERROR_FATAL
         assert 1.4 <= took <= 6.0, took
         assert "timed out" in str(e) or "broken" in str(e), e
     t0 = time.time()
@@ -56,7 +56,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "absent":
             call()
             raise SystemExit("a broken group took a call")
         except HuffmanGpuError as e:
-            assert e.code == 6 and "broken" in str(e), e
+            assert e.err == 4 and "broken" in str(e), e
     assert time.time() - t0 < 0.5
     group.close()
     # the codec itself is untouched by all this
@@ -113,6 +113,20 @@ for n_total, bs, root, wl in CASES:
     assert got == n_total and len(legs) == 4
     if me_root:
         assert torch.equal(out[:n_total], data), "foreign stream: the output differs"
+    # the foreign decode took the buffers the encode's layout lived in: an own-layout decode now says so on every rank (round 5
+    # decoded with a stale block index), and after the next encode it works again
+    try:
+        group.decode(stream, total, n_total, bs, out, root=root, own_layout=True, relaxed=relaxed)
+        raise AssertionError("an own-layout decode after a foreign one went through")
+    except HuffmanGpuError as e:
+        assert e.err == 2, e                                 # HUF_ERROR_INVALID_ARGUMENT
+    total2, lens2 = group.encode(data, n_total, bs, stream, root=root)
+    assert (total2, lens2) == (total, lens)
+    if me_root:
+        out.zero_()
+    assert group.decode(stream, total, n_total, bs, out, root=root, own_layout=True, relaxed=relaxed) == n_total
+    if me_root:
+        assert torch.equal(out[:n_total], data), "own layout after a foreign decode and a new encode: the output differs"
     # a damaged payload: every rank returns the same error
     if n_total >= (1 << 20) and not relaxed:
         if me_root:

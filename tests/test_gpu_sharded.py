@@ -91,6 +91,43 @@ def test_one_rank_through_the_real_rccl(torch_mod):
     group.close()
 
 
+def _run_mock_ranks(nranks, extra_args=(), timeout=300):
+    hipcc = "/opt/rocm/bin/hipcc"
+    with tempfile.TemporaryDirectory(prefix="mockrccl") as d:
+        so = os.path.join(d, "libmock_rccl.so")
+        subprocess.check_call([hipcc, "-O1", "-fPIC", "-shared", os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"),
+                               "-o", so, "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        env = dict(os.environ, HUF_GPU_RCCL_LIB=so, MOCK_RCCL_DIR=d)
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "sharded_worker.py"), str(r), str(nranks), d, *extra_args],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nranks)]
+        outs, codes = [], []
+        try:
+            for p in procs:
+                try:
+                    o, _ = p.communicate(timeout=timeout)
+                except subprocess.TimeoutExpired:
+                    o = "(timed out)"
+                outs.append(o)
+                codes.append(p.returncode)
+        finally:
+            for p in procs:                      # (a rank that waits for a dead peer)
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+        return outs, codes
+
+
+@pytest.mark.gpu
+def test_a_rank_that_never_arrives_costs_the_others_a_deadline_not_a_hang(torch_mod):
+    """RCCL failures map to HUF_ERROR_FATAL.  Three ranks, the last never makes the call: the other two
+    return HUF_ERROR_FATAL within the deadline they were given (1.5 s + the grace of the abort), their group is broken
+    (every later call fails at once), hufgpu_shard_destroy still works and the codec behind it is untouched."""
+    outs, codes = _run_mock_ranks(3, ("absent",), timeout=120)
+    for r in range(3):
+        assert codes[r] == 0 and "DONE" in outs[r], "rank %d:\n%s" % (r, outs[r][-3000:])
+    assert "returned HUF_ERROR_FATAL" in outs[0] and "returned HUF_ERROR_FATAL" in outs[1] and "never arrived" in outs[2]
+
+
 @pytest.mark.gpu
 def test_three_ranks_on_one_gpu_over_the_mock_transport(torch_mod):
     hipcc = "/opt/rocm/bin/hipcc"

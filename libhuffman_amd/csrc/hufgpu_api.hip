@@ -187,7 +187,7 @@ extern "C" int hufgpu_ctx_create(hufgpu_ctx_t **out, int device)
     HIP_OK(NULL, hipSetDevice(device));
     ctx->stream = NULL;   /* the device's default stream: ordered with every blocking stream (torch's default included) */
     HIP_OK(ctx, hipMalloc((void **)&ctx->d_result, 8 * sizeof(uint64_t)));
-    HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, 8 * sizeof(uint64_t)));
+    HIP_OK(ctx, hipMalloc((void **)&ctx->d_walk, DISC_WORDS * sizeof(uint64_t)));
     HIP_OK(ctx, hipHostMalloc((void **)&ctx->h_result, 16 * sizeof(uint64_t), hipHostMallocDefault));
 
     /* zipf255 cumulative weights: w_r = floor(2^32 / r), r = 1..255 */
@@ -811,12 +811,6 @@ extern "C" int hufgpu_decode_sub(hufgpu_ctx_t *ctx, const void *d_stream, uint64
     return decode_impl(ctx, d_stream, stream_len, d_block_offsets, nblocks, &sub, blocksize, d_out, out_cap, flags, raw_len, stream);
 }
 
-#ifdef DISC_DEBUG
-#define DISC_TRACE(msg) do { (void)hipStreamSynchronize(s); fprintf(stderr, "disc: %s\n", msg); fflush(stderr); } while (0)
-#else
-#define DISC_TRACE(msg) do { } while (0)
-#endif
-
 /* The exact sequential decoder (one workgroup, blocks in order). */
 static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint64_t length, uint8_t *out,
                         uint64_t out_cap, int max_tree, hipStream_t s, uint64_t *raw, uint64_t *used,
@@ -1098,78 +1092,72 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
                           bool *complete_out, uint64_t *in_place_out)
 {
     *m_out = 0; *resume_out = 0; *complete_out = false; *in_place_out = ~0ull;
-        const uint64_t nwg = (scan_len + DISC_CHUNK - 1) / DISC_CHUNK;
+    const uint64_t nwg = (scan_len + DISC_CHUNK - 1) / DISC_CHUNK;
+    const uint64_t ngroups = (nwg + DISC_SCAN_GROUP - 1) / DISC_SCAN_GROUP;
     if (nwg > ctx->disc_wgs) {
         HIP_OK(ctx, hipStreamSynchronize(s));
         free_disc_ws(ctx, 1);
         const uint64_t cap = nwg + nwg / 8 + 16;
+        const uint64_t gcap = (cap + DISC_SCAN_GROUP - 1) / DISC_SCAN_GROUP + 1;
         HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
-        HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1) * sizeof(uint64_t)));
+        HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1 + 2 * gcap) * sizeof(uint64_t)));     /* local sums, then the groups' bases and totals */
         HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_masks, cap * DISC_THREADS * sizeof(uint64_t)));
         ctx->disc_wgs = cap;
     }
-    discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
-    DISC_TRACE("discover count done");
-    scan_counts_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base);
-    DISC_TRACE("scan done");
-    HIP_OK(ctx, hipGetLastError());
-    HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_wg_base + nwg, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_OK(ctx, hipStreamSynchronize(s));
-    const uint64_t ncand = ctx->h_result[0];
-#ifdef DISC_DEBUG
-    fprintf(stderr, "disc: ncand=%llu nwg=%llu\n", (unsigned long long)ncand, (unsigned long long)nwg);
-#endif
-    if (ncand > 0 && ncand < 0x7fffffffull) {
-        if (ncand > ctx->disc_cands) {
-            free_disc_ws(ctx, 2);
-            const uint64_t cap = ncand + ncand / 8 + 16;
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand, cap * sizeof(uint64_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_end, cap * sizeof(uint64_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
-            HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
-            ctx->disc_cands = cap;
+    uint64_t *const group_base = ctx->d_wg_base + ctx->disc_wgs + 1;
+    uint64_t *const group_total = group_base + (ctx->disc_wgs + DISC_SCAN_GROUP - 1) / DISC_SCAN_GROUP + 1;
+    /* Round 6: ONE wait per call.  Everything that needs the number of candidates - the probes' launch, the sums, the links,
+     * the walk - reads it on the device (ctx->d_walk, DISC_NCAND) and is launched as wide as the candidate arrays are:
+     * surplus workgroups leave at once.  Only when there are no arrays yet (the context's first raw stream), or when the
+     * stream turns out to hold more candidates than they take (the walk's result says so), does the host wait for the
+     * count, make room and go again - what every call did until round 5. */
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIP_OK(ctx, hipMemsetAsync(ctx->d_walk, 0, DISC_WORDS * sizeof(uint64_t), s));
+        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
+        scan_counts_kernel<SCAN_THREADS><<<dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base, group_base, group_total, ctx->d_walk, ctx->disc_cands);
+        HIP_OK(ctx, hipGetLastError());
+        if (ctx->disc_cands == 0 || attempt == 1) {
+            HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk + DISC_FOUND, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_OK(ctx, hipStreamSynchronize(s));
+            const uint64_t found = ctx->h_result[0];
+            if (found == 0 || found >= 0x7fffffffull) return HUFE_OK;
+            if (found > ctx->disc_cands) {
+                free_disc_ws(ctx, 2);
+                const uint64_t cap = found + found / 8 + 16;
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_end, cap * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_chain, (cap + 1) * sizeof(uint64_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_cand_status, cap * sizeof(int32_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_nxt, cap * sizeof(uint32_t)));
+                HIP_OK(ctx, hipMalloc((void **)&ctx->d_spec_off, (cap + 1) * sizeof(uint64_t)));
+                ctx->disc_cands = cap;
+            }
+            /* (the count kernel clamped DISC_NCAND to the capacity it was given: all of them now; h_result[0] is pinned and not
+             *  written again before this copy has run - the next one into it is behind it on the stream) */
+            HIP_OK(ctx, hipMemcpyAsync(ctx->d_walk + DISC_NCAND, ctx->h_result, sizeof(uint64_t), hipMemcpyHostToDevice, s));
         }
+        const uint64_t width = ctx->disc_cands;                          /* launches are as wide as the arrays */
         /* (the candidates' block_len fields pass through d_cand_end, which the probes then overwrite with the ends) */
-        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks, ctx->d_cand_end);
-        DISC_TRACE("discover write done");
-        cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_cand_end, ncand, ctx->d_spec_off);
-        /* (the list of candidates for the exact decoder lives in d_nxt, which link_kernel writes behind the probes; its count in a spare word of d_walk) */
-        unsigned long long *redo_count = (unsigned long long *)(ctx->d_walk + 6);
-        HIP_OK(ctx, hipMemsetAsync(redo_count, 0, sizeof(unsigned long long), s));
-        probe_kernel<DEC_THREADS><<<dim3((unsigned)ncand), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
+        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks, ctx->d_cand_end, group_base, width);
+        cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_cand_end, ctx->d_walk, ctx->d_spec_off);
+        /* (the list of candidates for the exact decoder lives in d_nxt, which link_kernel writes behind the probes; its count in DISC_REDO) */
+        probe_kernel<DEC_THREADS><<<dim3((unsigned)width), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, ctx->d_walk);
         /* (two forms, each at the lean probe's register budget; the one whose mode it is not leaves at once.  Count-only - every
          *  candidate on the list: hufgpu_block_index - takes a workgroup per candidate) */
-        const unsigned exact_grid = (unsigned)(ncand < 1024 || !out ? ncand : 1024);
-        probe_exact_kernel<DEC_THREADS, true><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ncand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
-        probe_exact_kernel<DEC_THREADS, false><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ncand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, redo_count);
-        DISC_TRACE("probe done");
-        link_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ncand, length, ctx->d_nxt);
-        DISC_TRACE("link done");
-#ifdef DISC_DEBUG
-        if (ncand <= 32) {
-            uint64_t hc[32], he[32], ho[33]; int32_t hs[32]; uint32_t hn[32];
-            (void)hipMemcpy(hc, ctx->d_cand, ncand * 8, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(he, ctx->d_cand_end, ncand * 8, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(ho, ctx->d_spec_off, (ncand + 1) * 8, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hs, ctx->d_cand_status, ncand * 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hn, ctx->d_nxt, ncand * 4, hipMemcpyDeviceToHost);
-            for (uint64_t i = 0; i < ncand; i++)
-                fprintf(stderr, "disc: cand %llu at %llu end %llu status %d nxt %u spec_off %llu\n", (unsigned long long)i, (unsigned long long)hc[i],
-                        (unsigned long long)he[i], hs[i], hn[i], (unsigned long long)ho[i]);
-            fprintf(stderr, "disc: spec_off total %llu out_cap %llu length %llu\n", (unsigned long long)ho[ncand], (unsigned long long)out_cap, (unsigned long long)length);
-        }
-#endif
-        walk_kernel<<<dim3(1), dim3(WALK_THREADS), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ncand, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
-        DISC_TRACE("walk done");
+        const unsigned exact_grid = (unsigned)(width < 1024 || !out ? width : 1024);
+        probe_exact_kernel<DEC_THREADS, true><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, ctx->d_walk);
+        probe_exact_kernel<DEC_THREADS, false><<<dim3(exact_grid), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, ctx->d_walk);
+        link_kernel<<<dim3((unsigned)((width + 255) / 256)), dim3(256), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_walk, length, ctx->d_nxt);
+        walk_kernel<<<dim3(1), dim3(WALK_THREADS), 0, s>>>(ctx->d_cand, ctx->d_cand_end, ctx->d_nxt, ctx->d_chain, ctx->d_walk, ctx->d_spec_off, out_cap);
         HIP_OK(ctx, hipGetLastError());
-        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_walk, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_OK(ctx, hipStreamSynchronize(s));
+        if (ctx->h_result[DISC_FOUND] > width) continue;                 /* more candidates than the arrays took: once more, with room */
         *m_out = ctx->h_result[0];
         *in_place_out = ctx->h_result[4];   /* bytes the probe already decoded into `out` for these m blocks */
         *complete_out = ctx->h_result[2] != 0;
         *resume_out = *complete_out ? ctx->h_result[3] : ctx->h_result[1];
+        return HUFE_OK;
     }
     return HUFE_OK;
 }

@@ -1125,21 +1125,14 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
     if (leaf < 0 && m.block_len >= 32768u)
         regs = decode_payload_regs<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase, nullptr, 0,
                                             [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len); });
-#ifdef DFAST_REGS_ONLY       /* (experiment: what the other paths in this kernel cost the new one in registers) */
-    if (regs == 0) rc = HUFE_FATAL;
-#else
     if (leaf < 0 && regs == 0)
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
-#endif
 #else
     if (leaf < 0 && !(m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, tree, m.tree_len)))
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
 #endif
     DPROF_ADD(6, kt);
     bool good;
-#ifdef DFAST_REGS_ONLY
-    if (true) { good = regs == 1; } else
-#endif
     if (rc != HUFE_OK) {
         good = false;
     } else if (regs != 0) {

@@ -105,24 +105,24 @@ __device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uin
     }
     /* one iteration: four symbols into register S (the chain of iterations ends when no lane of the wave has a position
      * in front of its share's end any more) */
-#define DREG_ITER(S)                                                                                           \
+#define DREG_ITER(S, K)                                                                                        \
     {                                                                                                         \
         const bool act = P > Phi;                                                                             \
         if (!__any(act)) goto done;                                                                           \
         /* a lane that is done walks on while its wave does: what it reads there is ignored */                 \
         Pg = act ? P : Pg;                                                                                    \
         fg = act ? firsts : fg;                                                                               \
-        ng += act ? 1u : 0u;                                                                                  \
+        ng = act ? (K) : ng;                     /* (positions only grow: the active iterations are the first ng) */ \
         uint32_t p01, p23;                                                                                    \
         DREG_WINDOW(p01)                                                                                      \
         DREG_WINDOW(p23)                                                                                      \
         S = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                                     \
     }
-    DREG_ITER(sym.s0) DREG_ITER(sym.s1) DREG_ITER(sym.s2) DREG_ITER(sym.s3)
-    DREG_ITER(sym.s4) DREG_ITER(sym.s5) DREG_ITER(sym.s6) DREG_ITER(sym.s7)
-    DREG_ITER(sym.s8) DREG_ITER(sym.s9) DREG_ITER(sym.s10) DREG_ITER(sym.s11)
+    DREG_ITER(sym.s0, 1u) DREG_ITER(sym.s1, 2u) DREG_ITER(sym.s2, 3u) DREG_ITER(sym.s3, 4u)
+    DREG_ITER(sym.s4, 5u) DREG_ITER(sym.s5, 6u) DREG_ITER(sym.s6, 7u) DREG_ITER(sym.s7, 8u)
+    DREG_ITER(sym.s8, 9u) DREG_ITER(sym.s9, 10u) DREG_ITER(sym.s10, 11u) DREG_ITER(sym.s11, 12u)
 #if DREG_ITERS == 16
-    DREG_ITER(sym.s12) DREG_ITER(sym.s13) DREG_ITER(sym.s14) DREG_ITER(sym.s15)
+    DREG_ITER(sym.s12, 13u) DREG_ITER(sym.s13, 14u) DREG_ITER(sym.s14, 15u) DREG_ITER(sym.s15, 16u)
 #endif
 done:
 #undef DREG_ITER
@@ -294,10 +294,13 @@ __device__ __forceinline__ DregSeg dreg_plan(uint64_t ts, bool trust, uint32_t s
         /* equal shares of what is left (decode_fast.hpp: the block's last segment as full as the others) */
         const uint64_t rem = (g.hinted ? hint_bytes * 8ull : pay_bits) - g.seg0;
         if (rem < (1ull << 31)) {
-            const uint32_t r32 = (uint32_t)rem, per = (uint32_t)THREADS * SUB;
-            const uint32_t nseg = (r32 + per - 1u) / per;
-            const uint32_t even = (r32 + nseg * (uint32_t)THREADS - 1u) / (nseg * (uint32_t)THREADS);
-            sb = dmin<uint32_t>(dmax<uint32_t>(even, 64u), SUB);
+            /* (in floats: two integer divisions are some eighty vector instructions a segment, and nothing depends on the
+             *  quotients being exact - shares a bit off the even ones are shares all the same; the uniform-bytes case,
+             *  589 824 bits = 4 x 512 x 288, is exact in 24 bits) */
+            const float r = (float)(uint32_t)rem;
+            const float nseg = ceilf(r / (float)((uint32_t)THREADS * SUB));
+            const float even = ceilf(r / (nseg * (float)THREADS));
+            sb = dmin<uint32_t>(dmax<uint32_t>((uint32_t)even, 64u), SUB);
         }
     }
     g.sb = uni32(sb);
@@ -354,13 +357,8 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     bool ok = true;
     bool trust = true;
     DregSeg g = DREG_PLAN(0, true, 0);
-#ifndef DREG_NO_PRE0
     const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
     if (!build_tables()) return DREG_NO_TABLES;
-#else
-    if (!build_tables()) return DREG_NO_TABLES;
-    const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
-#endif
     dreg_commit(slice + lane, q, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
     bool have = true;                                                  /* (uniform) the columns hold segment g */
     while (produced < block_len) {
@@ -436,13 +434,11 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             const bool changed = (ns != start) && !dead;
             if (changed) start = ns;
             bool jumped = false;
-#ifndef DREG_EXP_NOJUMP
             if (rounds >= DFAST_JUMP_FROM_ROUND && __ballot(changed)) {
                 DFAST_DBGW(15, 1);
                 const uint4 r = dreg_run_jump(lut_addr, lane4, rbase, changed, dead, hi_eff, hi - sb, pay_rel, start, end);
                 start = r.x; end = r.y; jumped = r.z != 0u;
             }
-#endif
             need = changed || jumped;
             /* does any lane of the workgroup go on?  (One barrier: a wave's word is written behind the barrier above and read
              * behind this one, and the next round's barrier above lies in front of its next writer; everyone has read sh.wend.) */
@@ -466,9 +462,10 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
         const uint64_t next_start = seg0 + last_end;
         const DregSeg gn = DREG_PLAN(next_start, true, shrink);
-#ifndef DREG_EXP_NOPRE
-        const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
-#endif
+        /* (behind the payload's last byte there is no next segment: its lanes ask beyond the resource and nothing is fetched -
+         *  one request in five was for the first kilobytes of the NEXT block, which that block's workgroup reads again) */
+        const bool more = uni32(next_start + 7ull < (gn.hinted ? hint_bytes * 8ull : pay_bits) ? 1u : 0u) != 0u;
+        const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), more && DREG_WANTED(gn));
         /* the counts' sum; above it the lanes whose true track ran out of registers (counts: at most 64 a lane, 2^15 a segment) */
         uint32_t seg_total;
         const uint32_t ex = block_excl_scan_u32<THREADS>(cnt | ((uint32_t)(t.over && !dead) << 16), sh.part, seg_total) & 0xffffu;
@@ -495,7 +492,6 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         bool lane_ok = true;
         uint32_t qe = end;                                             /* the position behind the lane's last symbol of the block */
         const bool partial = quota != 0u && quota < cnt;               /* the block ends inside this lane's codewords */
-#ifndef DREG_EXP_NOWALK
         if (__ballot(partial)) {
             /* from the last iteration's start when the block's last symbol lies in it, else from the lane's start */
             const bool tail = partial && quota > 4u * (t.ng - 1u);
@@ -506,13 +502,9 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
                 lane_ok = (fb >> 31) == 0u;
             }
         }
-#endif
         /* this segment's columns have been read for the last time: the next segment's words into them (the wait for them
          * counts only what went out before them) */
-        if (produced + take < block_len) {
-#ifdef DREG_EXP_NOPRE
-            const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
-#endif
+        if (more && produced + take < block_len) {
             dreg_commit(slice + lane, qn, sel, pay, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
             have = true;
         }
@@ -527,13 +519,6 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             const uint32_t nd = whole ? (quota + 3u) >> 2 : quota >> 2;
             typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
             typedef uint32_t unaligned_q4 __attribute__((ext_vector_type(4), aligned(1)));
-#ifdef DREG_DWORD_STORES
-#define DREG_QUAD(Q4, A, B, C, D)                                                                              \
-            if (nd > 4u * (Q4)) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4)) = sym.A;                  \
-            if (nd > 4u * (Q4) + 1u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 4u) = sym.B;        \
-            if (nd > 4u * (Q4) + 2u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 8u) = sym.C;        \
-            if (nd > 4u * (Q4) + 3u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 12u) = sym.D;
-#else
 #define DREG_QUAD(Q4, A, B, C, D)                                                                              \
             if (nd >= 4u * (Q4) + 4u) {                                                                       \
                 unaligned_q4 v4;                                                                              \
@@ -544,7 +529,6 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
                 if (nd > 4u * (Q4) + 1u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 4u) = sym.B;    \
                 if (nd > 4u * (Q4) + 2u) *reinterpret_cast<unaligned_u32 *>(gp + 16u * (Q4) + 8u) = sym.C;    \
             }
-#endif
             DREG_QUAD(0, s0, s1, s2, s3)
             DREG_QUAD(1, s4, s5, s6, s7)
             DREG_QUAD(2, s8, s9, s10, s11)

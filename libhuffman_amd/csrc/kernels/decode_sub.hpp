@@ -899,10 +899,6 @@ void decode_sub_kernel(
     unsigned long long *__restrict__ result, HufSubIndex sub, uint64_t blocksize, uint32_t cpb, DecFixList fix)
 {
     __shared__ DsubShared<THREADS> sh;
-#ifdef DSUB_LDS_PAD             /* (occupancy experiments: fewer workgroups per CU) */
-    __shared__ uint32_t lds_pad[DSUB_LDS_PAD / 4];
-    if (stream_len == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
-#endif
     static_assert(DSUB_CHUNK_SYMS % (THREADS * DSUB_SPL) == 0 && DSUB_CHUNK_SYMS % HUF_SUB_TILE == 0, "chunks are whole tiles");
     const int tid = (int)threadIdx.x;
     const uint64_t blk = blockIdx.x / cpb;

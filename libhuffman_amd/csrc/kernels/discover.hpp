@@ -33,6 +33,11 @@ namespace hufgpu {
 #define DISC_PER 16
 #define DISC_ITERS 4
 #define DISC_CHUNK (DISC_THREADS * DISC_PER * DISC_ITERS)
+#define DISC_SCAN_GROUP 1024u              /* workgroup counts one workgroup of scan_counts_kernel sums */
+/* the words the discovery's kernels share (ctx->d_walk): 0..4 walk_kernel's result, 5 the candidates found (may be more
+ * than the arrays hold), 6 the exact probes' list length, 7 scan_counts_kernel's ticket, 8 links that are not "the next
+ * candidate", 9 the candidates the arrays hold = min(found, capacity) */
+enum { DISC_FOUND = 5, DISC_REDO = 6, DISC_TICKET = 7, DISC_ODD_LINKS = 8, DISC_NCAND = 9, DISC_WORDS = 16 };
 #define LINK_BAD      0xfffffffdu
 #define LINK_TERMINAL 0xfffffffeu
 #define LINK_NOTFOUND 0xffffffffu
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                                                                 const uint64_t *__restrict__ wg_base,
                                                                 uint64_t *__restrict__ cand,
                                                                 uint64_t *__restrict__ masks,
-                                                                uint64_t *__restrict__ cand_len = nullptr)
+                                                                uint64_t *__restrict__ cand_len = nullptr,
+                                                                const uint64_t *__restrict__ group_base = nullptr, uint64_t cand_cap = 0)
 {
     /* A workgroup scans 16 KiB (with 4 KiB workgroups the kernel was bound by their dispatch) in DISC_ITERS rows of
      * DISC_THREADS 16-byte pieces; a thread owns piece `tid` of every row.  (Round 4.  Until then a thread owned four
@@ -213,7 +219,9 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
         if (threadIdx.x == 0) wg_counts[blockIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
     } else {
         const uint32_t first[4] = {ex_lo & 0xffffu, tot[0] + (ex_lo >> 16), tot[0] + tot[1] + (ex_hi & 0xffffu), tot[0] + tot[1] + tot[2] + (ex_hi >> 16)};
-        const uint64_t wgb = wg_base[blockIdx.x];
+        /* (round 6: scan_counts_kernel sums in groups of DISC_SCAN_GROUP workgroups; a candidate beyond the arrays' capacity -
+         *  the launch was sized before the count was known - is not written, and the walk's result says there were more) */
+        const uint64_t wgb = group_base[blockIdx.x / DISC_SCAN_GROUP] + wg_base[blockIdx.x];
 #pragma unroll
         for (int it = 0; it < DISC_ITERS; it++) {
             uint32_t m = (uint32_t)(mask >> (16 * it)) & 0xffffu;
@@ -222,30 +230,67 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
                 const int k = __builtin_ctz(m);
                 m &= m - 1;
                 const uint64_t p = t0 + (uint64_t)it * ROW + (uint64_t)k;
-                cand[at] = p;
-                /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
-                 * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> 7 us) */
-                cand_len[at] = load_u64_unaligned(stream + p);
+                if (at < cand_cap) {
+                    cand[at] = p;
+                    /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
+                     * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> 7 us) */
+                    cand_len[at] = load_u64_unaligned(stream + p);
+                }
                 at++;
             }
         }
     }
 }
 
+/* The candidates in front of every discovery workgroup, in two levels (round 6; until then ONE workgroup summed the 65 536
+ * counts of a GiB: 30 us): workgroup g sums the counts of discovery workgroups [g 1024, (g + 1) 1024) - local[i] = the
+ * candidates of its group in front of i -, and the workgroup that finishes last (a ticket) sums the groups' totals:
+ * group_base[g], and the candidates found / held in ctrl[]. */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint64_t n,
-                                                              uint64_t *__restrict__ base)
+                                                              uint64_t *__restrict__ local, uint64_t *__restrict__ group_base,
+                                                              uint64_t *__restrict__ group_total, uint64_t *__restrict__ ctrl, uint64_t cand_cap)
 {
-    const uint64_t total = chunked_excl_scan<THREADS>(n, base, [counts](uint64_t i) { return (uint64_t)counts[i]; });
-    if (threadIdx.x == 0) base[n] = total;
+    static_assert(THREADS == (int)DISC_SCAN_GROUP, "one count a thread");
+    __shared__ uint32_t s_part[THREADS / 64];
+    __shared__ uint64_t s_part64[THREADS / 64];
+    __shared__ uint32_t s_last;
+    const uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t c = i < n ? counts[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_u32<THREADS>(c, s_part, total);       /* (a workgroup's candidates: < 2^22) */
+    if (i < n) local[i] = ex;
+    if (threadIdx.x == 0) {
+        group_total[blockIdx.x] = total;
+        __threadfence();
+        s_last = atomicAdd((unsigned long long *)&ctrl[DISC_TICKET], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    /* the groups' totals: a chunk of THREADS at a time (16 GiB of stream are one chunk) */
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < gridDim.x; base += THREADS) {
+        const uint64_t g = base + threadIdx.x;
+        const uint64_t v = g < gridDim.x ? __builtin_nontemporal_load(&group_total[g]) : 0ull;
+        uint64_t tot;
+        const uint64_t e = block_excl_scan<THREADS, uint64_t>(v, s_part64, tot);
+        if (g < gridDim.x) group_base[g] = carry + e;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        ctrl[DISC_FOUND] = carry;
+        ctrl[DISC_NCAND] = carry < cand_cap ? carry : cand_cap;
+    }
 }
 
 /* Where the output of candidate i would start if every candidate were a block of the stream, in
  * order: the exclusive prefix sum of the block_len fields (ONE workgroup; spec_off[ncand] = sum). */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint64_t *__restrict__ cand_len, uint64_t ncand,
+__global__ __launch_bounds__(THREADS) void cand_lens_kernel(const uint64_t *__restrict__ cand_len, const uint64_t *__restrict__ ctrl,
                                                             uint64_t *__restrict__ spec_off)
 {
+    const uint64_t ncand = uni64(ctrl[DISC_NCAND]);
     const uint64_t total = chunked_excl_scan<THREADS>(ncand, spec_off, [=](uint64_t i) {
         return cand_len[i];
     });
@@ -265,8 +310,12 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
                                                         uint64_t *__restrict__ cand_end,
                                                         int32_t *__restrict__ cand_status,
                                                         const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
-                                                        uint64_t out_cap, uint32_t *__restrict__ redo, unsigned long long *__restrict__ redo_count)
+                                                        uint64_t out_cap, uint32_t *__restrict__ redo, uint64_t *__restrict__ ctrl)
 {
+    /* (round 6: the launch is as wide as the arrays - it went out before anybody knew how many candidates there are) */
+    const uint64_t ncand = uni64(ctrl[DISC_NCAND]);
+    if (blockIdx.x >= ncand) return;
+    unsigned long long *const redo_count = (unsigned long long *)&ctrl[DISC_REDO];
     /* Round 5: the lean decoder ONLY; a candidate it cannot vouch for goes on the list of probe_exact_kernel.  (With the exact
      * decoder in the same kernel the probe spilled 5-13 registers and could not take decode_fast's column stage: the two
      * stage forms and the exact decoder inlined side by side.) */
@@ -276,12 +325,12 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
     const int tl = (int)(int16_t)uni32((uint32_t)stream[c + 8] | ((uint32_t)stream[c + 9] << 8));
     const uint64_t pay0 = c + HUF_HEADER_FIXED + 2ull * (uint64_t)tl;
     uint64_t end_bits = 0;
-    const bool store = uni64(spec_off[gridDim.x]) <= out_cap;
+    const bool store = uni64(spec_off[ncand]) <= out_cap;
     if (store && block_len != 0 && tl >= 9 && pay0 <= avail) {
         int leaf = -1;
         /* (round 4) the tables from the tree's shape where decode_fast_kernel takes them from it, and the next candidate's
          * offset as a first guess at where this one's payload ends: probe 1.62 -> 1.53 ms per GiB of zipf255, the indexed decoder's time (profiles/r04/raw_stream_kernels.txt) */
-        const uint64_t nextc = (blockIdx.x + 1u < gridDim.x) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
+        const uint64_t nextc = (blockIdx.x + 1u < ncand) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
         const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
 #ifndef DFAST_NO_REGS
         const int shaped = !(block_len >= 32768u && tl <= HUF_TREE_MAX) ? 0 :
@@ -309,14 +358,15 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
  * when the output does not take them all - through the exact decoder, which has the last word on status and end. */
 template <int THREADS, bool STORE>
 __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_exact_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
-                                                        const uint64_t *__restrict__ cand, uint64_t ncand,
+                                                        const uint64_t *__restrict__ cand,
                                                         uint64_t *__restrict__ cand_end,
                                                         int32_t *__restrict__ cand_status,
                                                         const uint64_t *__restrict__ spec_off, uint8_t *__restrict__ out,
-                                                        uint64_t out_cap, const uint32_t *__restrict__ redo, const unsigned long long *__restrict__ redo_count)
+                                                        uint64_t out_cap, const uint32_t *__restrict__ redo, const uint64_t *__restrict__ ctrl)
 {
     __shared__ DecShared<THREADS> sh;
-    const uint64_t n = uni64(*redo_count);
+    const uint64_t ncand = uni64(ctrl[DISC_NCAND]);
+    const uint64_t n = uni64(ctrl[DISC_REDO]);
     if ((uni64(spec_off[ncand]) <= out_cap) != STORE) return;         /* (the other form of this kernel has the list) */
     for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t k = uni32(redo[i]);
@@ -337,9 +387,10 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_exact_kerne
 }
 
 __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *__restrict__ cand_end,
-                            const int32_t *__restrict__ cand_status, uint64_t ncand, uint64_t length,
+                            const int32_t *__restrict__ cand_status, uint64_t *__restrict__ ctrl, uint64_t length,
                             uint32_t *__restrict__ nxt)
 {
+    const uint64_t ncand = ctrl[DISC_NCAND];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncand) return;
     uint32_t r;
@@ -357,6 +408,10 @@ __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *_
         }
     }
     nxt[i] = r;
+    /* (round 6) is the chain the plain one - every candidate a block, each ending where the next begins, the last at the
+     * stream's end?  Then walk_kernel has nothing to follow.  Any other link is counted. */
+    const bool plain = (i + 1 < ncand) ? r == (uint32_t)(i + 1) : r == LINK_TERMINAL;
+    if (!plain || (i == 0 && cand[0] != 0)) atomicAdd((unsigned long long *)&ctrl[DISC_ODD_LINKS], 1ull);
 }
 
 /* result: [0] validated blocks m, [1] offset where the sequential decoder must take over
@@ -375,11 +430,28 @@ __global__ void link_kernel(const uint64_t *__restrict__ cand, const uint64_t *_
  * walks read cand[] from memory inside its loop, one round trip per step of 64: 115 us per GiB of 64 KiB blocks.) */
 __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const uint64_t *__restrict__ cand,
                                                   const uint64_t *__restrict__ cand_end,
-                                                  const uint32_t *__restrict__ nxt, uint64_t ncand,
+                                                  const uint32_t *__restrict__ nxt,
                                                   uint64_t *__restrict__ block_offsets,
                                                   uint64_t *__restrict__ result,
                                                   const uint64_t *__restrict__ spec_off, uint64_t out_cap)
 {
+    const uint64_t ncand = uni64(result[DISC_NCAND]);
+    if (ncand != 0 && uni64(result[DISC_ODD_LINKS]) == 0ull && uni64(result[DISC_FOUND]) == ncand) {
+        /* (round 6) the plain chain - what a stream is unless a payload holds the bytes of a header or a block is damaged:
+         * validated block j IS candidate j, and the sixteen waves copy the offsets (the wave that walks took 256 steps of
+         * 64 links for a GiB of 64 KiB blocks: 59 us) */
+        for (uint64_t i = threadIdx.x; i < ncand; i += WALK_THREADS) block_offsets[i] = cand[i];
+        if (threadIdx.x == 0) {
+            const uint64_t consumed = cand_end[ncand - 1];
+            result[0] = ncand;
+            result[1] = 0;
+            result[2] = 1;
+            result[3] = consumed;
+            result[4] = spec_off[ncand] <= out_cap ? spec_off[ncand] : ~0ull;
+            block_offsets[ncand] = consumed;
+        }
+        return;
+    }
     __shared__ uint32_t s_nxt[WALK_CHUNK];
     __shared__ uint64_t s_cand[WALK_CHUNK];
     __shared__ uint64_t s_cur;

@@ -649,10 +649,6 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     __shared__ uint32_t s_tail[THREADS / 64 + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[PACK_STAGE_WORDS];
 
-#ifdef PACK_LDS_PAD             /* (occupancy experiments: fewer workgroups per CU) */
-    __shared__ uint32_t lds_pad[PACK_LDS_PAD / 4];
-    if (n == 0x123456789abcull) lds_pad[threadIdx.x] = 1;
-#endif
 #ifdef PACK_VGPR_SLACK      /* test builds only: "v72" gives the 72-VGPR (7 waves per SIMD) build its register of slack */
     asm volatile("; one VGPR more than the kernel uses" ::: PACK_VGPR_SLACK);
 #endif
@@ -675,8 +671,7 @@ __global__ __launch_bounds__(THREADS, SHORT ? PACK_WAVES_PER_SIMD : 4) void pack
     uint16_t *sub_groups = sub.tile_bits ? sub.group_bits + blk * sub.gpb : nullptr;
     if (sub.tile_bits && m.tree_len != 5)
         for (int i = (int)threadIdx.x; i < HUF_NSYM; i += THREADS) sub.lens[blk * HUF_NSYM + i] = (uint8_t)(codes[i] & 0xffu);
-#if !defined(PACK_ROUND4_PUSH) && !defined(PACK_ACC64)   /* (-DPACK_ROUND4_PUSH: round 4's placement loop for these blocks too, for A/B timing;
-                                                             -DPACK_ACC64 = round 2's kernel, tests/test_isa_check.py) */
+#if !defined(PACK_ACC64)   /* (-DPACK_ACC64 = round 2's kernel, tests/test_isa_check.py) */
     if (m.max_len <= 10)                 /* three codes per push */
         pack_block_multi<THREADS, 3>(in + base, len, codes, tb, m.tree_len, out, o0, o1,
                                      reinterpret_cast<uint2 *>(s_code), s_part, s_tail, s_stage, sub_tiles, sub_groups);

@@ -253,7 +253,7 @@ def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0,
     got = {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("SQ_INSTS_VALU",) if valu else ()):
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE") if valu else ()):
                 cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(d, ctr), "-o", "p", "--",
                        sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--workload", workload,
                        "--secondary", "none", "--no-cpu-baseline", "--no-other-decode", "--no-index-free",
@@ -265,6 +265,7 @@ def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0,
                 if not files:
                     return None
                 total, launches = {k: 0.0 for k in kernels}, {k: set() for k in kernels}
+                spans = {k: {} for k in kernels}                       # dispatch -> its nanoseconds under this pass
                 with open(files[0]) as f:
                     for row in csv.DictReader(f):
                         if row["Counter_Name"] != ctr:
@@ -273,11 +274,21 @@ def live_traffic(workload: str, kernels, passthrough=(), timeout: float = 120.0,
                             if k in row["Kernel_Name"]:
                                 total[k] += float(row["Counter_Value"])
                                 launches[k].add(row["Dispatch_Id"])
+                                try:
+                                    spans[k][row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                                except (KeyError, ValueError):
+                                    pass
                 got[ctr] = {k: total[k] / len(launches[k]) for k in kernels if launches[k]}
+                if ctr == "GRBM_GUI_ACTIVE":
+                    # the clock a kernel ran at: busy cycles (rocprofv3 reports the sum over the 8 XCDs) / 8 / the dispatch's time IN THIS
+                    # pass (MI355X_MICROARCH.md, DVFS give-back; reads high for dispatches of less than about 0.3 ms)
+                    got["__clock__"] = {k: round(total[k] / 8.0 / sum(spans[k].values()), 3)
+                                        for k in kernels if launches[k] and len(spans[k]) == len(launches[k]) and sum(spans[k].values()) > 0}
         out = {k: round(got["FETCH_SIZE"][k] * 1024 * 2 + got["WRITE_SIZE"][k] * 1024)
                for k in kernels if k in got["FETCH_SIZE"] and k in got["WRITE_SIZE"]}
         if valu and out:
             out["__valu__"] = {k: round(v) for k, v in got.get("SQ_INSTS_VALU", {}).items()}      # wave instructions per launch
+            out["__clock__"] = got.get("__clock__", {})
         return out or None
     except Exception:
         return None
@@ -1072,6 +1083,7 @@ def main() -> None:
             want = sorted({result["roofline"]["kernel"], "pack_kernel", "hist_lanes_kernel", "tree_wave_kernel"})
             lt = live_traffic(args.workload, want, same, valu=True)
             valu = lt.pop("__valu__", None) if lt else None
+            clocks = lt.pop("__clock__", None) if lt else None
             if lt and result["roofline"]["kernel"] in lt:
                 result["roofline"]["traffic"] = lt[result["roofline"]["kernel"]]
                 result["roofline"]["traffic_source"] = live_src
@@ -1089,6 +1101,17 @@ def main() -> None:
                                                    "issue_frac = instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x the kernel's time)"}
                 if result["roofline"]["kernel"] in fr:
                     result["roofline"]["valu_issue_frac"] = fr[result["roofline"]["kernel"]]
+                if clocks:
+                    # the same share at the clock the kernel was seen to run at (GRBM_GUI_ACTIVE / 8 / the dispatch's time in a
+                    # counter pass of its own; the guide: reads high below ~0.3 ms a dispatch, profiled passes clock a few % lower)
+                    fr_m = {k: round(v * 4.0 / (1024 * clocks[k] * 1e9 * main_rec["kernels"][kms[k]]["avg_ms"] * 1e-3), 4)
+                            for k, v in valu.items() if k in fr and clocks.get(k)}
+                    result["kernel_valu"]["clock_GHz"] = clocks
+                    result["kernel_valu"]["issue_frac_at_measured_clock"] = fr_m
+                    result["kernel_valu"]["clock_source"] = ("rocprofv3 --pmc GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / the dispatch's own time, "
+                                                             "a child pass of this command")
+                    if result["roofline"]["kernel"] in clocks:
+                        result["roofline"]["clock_GHz"] = clocks[result["roofline"]["kernel"]]
             # the index-alone decoder's kernel: one more pair of passes of the same command with --decode selfsync
             if (args.workload + "_index_free") in sec_recs and args.decode == "sub":
                 same_idx = [x if x != args.decode else "selfsync" for x in same]

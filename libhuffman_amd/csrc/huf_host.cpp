@@ -2439,7 +2439,10 @@ static int decode_duplex(huf_decoder_t *dec, membuf_t *rmem, membuf_t *wmem, uin
             if (rounds >= 2) DX_T(t_out, rc = dx_wait_done(P, 1, out0 + rounds - 2));
             if (rc != HUF_ERROR_SUCCESS) { ok = 0; break; }
             DX_T(t_k, rc = hufgpu_decode_stream(g_ctx, g_stage.d_c, avail, round_len, d_out[rounds & 1], out_cap, flags, &raw, &used, NULL));
-            if (rc == HUF_ERROR_READ_WRITE && loaded < total) {                                /* the last block wants more of the stream: it is on its way */
+            /* (a round that already looks at all it may - R + margin bytes - and still wants more holds a block longer than
+             *  that: more segments cannot help it, the ordinary path takes the call at once; round 5 loaded every remaining
+             *  segment, decoding in vain each time, before it gave up) */
+            if (rc == HUF_ERROR_READ_WRITE && loaded < total && avail < R + margin) {          /* the last block wants more of the stream: it is on its way */
                 need = loaded + R < total ? loaded + R : total;
                 continue;
             }

@@ -64,6 +64,7 @@ struct hufgpu_ctx {
     /* raw-stream discovery workspace */
     uint64_t disc_wgs, disc_cands;
     uint32_t *d_wg_counts;
+    void *d_disc_slots;           /* DISC_SLOTS candidates a discovery workgroup (kernels/discover.hpp, DiscSlot) */
     uint64_t *d_disc_masks;       /* 64 header-test verdicts per discovery thread */
     uint64_t *d_wg_base;
     uint64_t *d_cand, *d_cand_end, *d_chain;
@@ -220,7 +221,7 @@ static void free_encode_ws(hufgpu_ctx *c)
 
 static void free_disc_ws(hufgpu_ctx *c, int which)
 {
-    if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); (void)hipFree(c->d_disc_masks); c->d_wg_counts = NULL; c->d_wg_base = NULL; c->d_disc_masks = NULL; c->disc_wgs = 0; }
+    if (which & 1) { (void)hipFree(c->d_wg_counts); (void)hipFree(c->d_wg_base); (void)hipFree(c->d_disc_masks); (void)hipFree(c->d_disc_slots); c->d_disc_slots = NULL; c->d_wg_counts = NULL; c->d_wg_base = NULL; c->d_disc_masks = NULL; c->disc_wgs = 0; }
     if (which & 2) {
         (void)hipFree(c->d_cand); (void)hipFree(c->d_cand_end); (void)hipFree(c->d_chain); (void)hipFree(c->d_cand_status); (void)hipFree(c->d_nxt); (void)hipFree(c->d_spec_off);
         c->d_cand = c->d_cand_end = c->d_chain = NULL; c->d_cand_status = NULL; c->d_nxt = NULL; c->d_spec_off = NULL; c->disc_cands = 0;
@@ -1102,6 +1103,7 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
         HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_counts, cap * sizeof(uint32_t)));
         HIP_OK(ctx, hipMalloc((void **)&ctx->d_wg_base, (cap + 1 + 2 * gcap) * sizeof(uint64_t)));     /* local sums, then the groups' bases and totals */
         HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_masks, cap * DISC_THREADS * sizeof(uint64_t)));
+        HIP_OK(ctx, hipMalloc((void **)&ctx->d_disc_slots, cap * DISC_SLOTS * sizeof(DiscSlot)));
         ctx->disc_wgs = cap;
     }
     uint64_t *const group_base = ctx->d_wg_base + ctx->disc_wgs + 1;
@@ -1113,7 +1115,7 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
      * count, make room and go again - what every call did until round 5. */
     for (int attempt = 0; attempt < 2; attempt++) {
         HIP_OK(ctx, hipMemsetAsync(ctx->d_walk, 0, DISC_WORDS * sizeof(uint64_t), s));
-        discover_kernel<false><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, NULL, NULL, ctx->d_disc_masks);
+        discover_kernel<<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, ctx->d_wg_counts, (DiscSlot *)ctx->d_disc_slots, ctx->d_disc_masks);
         scan_counts_kernel<SCAN_THREADS><<<dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s>>>(ctx->d_wg_counts, nwg, ctx->d_wg_base, group_base, group_total, ctx->d_walk, ctx->disc_cands);
         HIP_OK(ctx, hipGetLastError());
         if (ctx->disc_cands == 0 || attempt == 1) {
@@ -1138,7 +1140,7 @@ static int discover_chain(hufgpu_ctx_t *ctx, const uint8_t *st, uint64_t avail, 
         }
         const uint64_t width = ctx->disc_cands;                          /* launches are as wide as the arrays */
         /* (the candidates' block_len fields pass through d_cand_end, which the probes then overwrite with the ends) */
-        discover_kernel<true><<<dim3((unsigned)nwg), dim3(DISC_THREADS), 0, s>>>(st, avail, scan_len, max_tree, NULL, ctx->d_wg_base, ctx->d_cand, ctx->d_disc_masks, ctx->d_cand_end, group_base, width);
+        place_cands_kernel<<<dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, s>>>(st, ctx->d_wg_counts, nwg, ctx->d_wg_base, group_base, (const DiscSlot *)ctx->d_disc_slots, ctx->d_disc_masks, ctx->d_cand, ctx->d_cand_end, width);
         cand_lens_kernel<SCAN_THREADS><<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(ctx->d_cand_end, ctx->d_walk, ctx->d_spec_off);
         /* (the list of candidates for the exact decoder lives in d_nxt, which link_kernel writes behind the probes; its count in DISC_REDO) */
         probe_kernel<DEC_THREADS><<<dim3((unsigned)width), dim3(DEC_THREADS), 0, s>>>(st, avail, ctx->d_cand, ctx->d_cand_end, ctx->d_cand_status, ctx->d_spec_off, out, out_cap, ctx->d_nxt, ctx->d_walk);

@@ -33,6 +33,7 @@ namespace hufgpu {
 #define DISC_PER 16
 #define DISC_ITERS 4
 #define DISC_CHUNK (DISC_THREADS * DISC_PER * DISC_ITERS)
+#define DISC_SLOTS 4u                       /* candidates a discovery workgroup hands over directly (its 16 KiB hold one in four, at 64 KiB blocks) */
 #define DISC_SCAN_GROUP 1024u              /* workgroup counts one workgroup of scan_counts_kernel sums */
 /* the words the discovery's kernels share (ctx->d_walk): 0..4 walk_kernel's result, 5 the candidates found (may be more
  * than the arrays hold), 6 the exact probes' list length, 7 scan_counts_kernel's ticket, 8 links that are not "the next
@@ -108,15 +109,18 @@ __device__ __noinline__ bool tree_grammar_complete_wave(const uint8_t *t, int tl
     return __ballot(bad) == 0ull && open == 0;
 }
 
-template <bool WRITE>
+/* Round 6: ONE pass over the stream.  A workgroup that finds at most DISC_SLOTS candidates - all of them, in a stream of
+ * blocks of a few KiB and more - leaves them (offset and block_len) in its own slots, in stream order; place_cands_kernel,
+ * one thread a workgroup, moves them to their places once the counts are summed.  Until then the 64 verdicts of every
+ * thread went to memory (an eighth of the stream's size written, and read again by a second launch of this kernel that
+ * placed the candidates: 45 us per GiB beside the writes); only a workgroup with more candidates still does that, and
+ * place_cands_kernel reads its verdicts. */
+struct DiscSlot { uint64_t offset, block_len; };
 __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *__restrict__ stream, uint64_t avail,
                                                                 uint64_t scan_len, int max_tree_len,
                                                                 uint32_t *__restrict__ wg_counts,
-                                                                const uint64_t *__restrict__ wg_base,
-                                                                uint64_t *__restrict__ cand,
-                                                                uint64_t *__restrict__ masks,
-                                                                uint64_t *__restrict__ cand_len = nullptr,
-                                                                const uint64_t *__restrict__ group_base = nullptr, uint64_t cand_cap = 0)
+                                                                DiscSlot *__restrict__ slots,
+                                                                uint64_t *__restrict__ masks)
 {
     /* A workgroup scans 16 KiB (with 4 KiB workgroups the kernel was bound by their dispatch) in DISC_ITERS rows of
      * DISC_THREADS 16-byte pieces; a thread owns piece `tid` of every row.  (Round 4.  Until then a thread owned four
@@ -130,8 +134,7 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
     uint64_t mask = 0;                                                          /* bit 16 it + k: offset t0 + it * ROW + k */
     /* the counting pass leaves its 64 verdicts per thread for the writing pass, which then reads
      * 1/8 of the stream's size instead of testing the whole stream again */
-    if (WRITE) mask = masks[slot];
-    else if (t0 < scan_len) {
+    if (t0 < scan_len) {
         /* all eight loads of the thread are issued before the first use (one memory round trip) */
         uint4 va[DISC_ITERS], vb[DISC_ITERS];
 #pragma unroll
@@ -214,32 +217,65 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
     const uint32_t ex_lo = block_excl_scan_u32<DISC_THREADS>(c_lo, s_part, tot_lo);
     const uint32_t ex_hi = block_excl_scan_u32<DISC_THREADS>(c_hi, s_part2, tot_hi);
     const uint32_t tot[4] = {tot_lo & 0xffffu, tot_lo >> 16, tot_hi & 0xffffu, tot_hi >> 16};
-    if (!WRITE) {
-        masks[slot] = mask;
-        if (threadIdx.x == 0) wg_counts[blockIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
-    } else {
+    const uint32_t total = tot[0] + tot[1] + tot[2] + tot[3];
+    if (total <= DISC_SLOTS) {                                     /* (uniform) */
         const uint32_t first[4] = {ex_lo & 0xffffu, tot[0] + (ex_lo >> 16), tot[0] + tot[1] + (ex_hi & 0xffffu), tot[0] + tot[1] + tot[2] + (ex_hi >> 16)};
-        /* (round 6: scan_counts_kernel sums in groups of DISC_SCAN_GROUP workgroups; a candidate beyond the arrays' capacity -
-         *  the launch was sized before the count was known - is not written, and the walk's result says there were more) */
-        const uint64_t wgb = group_base[blockIdx.x / DISC_SCAN_GROUP] + wg_base[blockIdx.x];
 #pragma unroll
         for (int it = 0; it < DISC_ITERS; it++) {
             uint32_t m = (uint32_t)(mask >> (16 * it)) & 0xffffu;
-            uint64_t at = wgb + first[it];
+            uint32_t at = first[it];
             while (m) {
                 const int k = __builtin_ctz(m);
                 m &= m - 1;
                 const uint64_t p = t0 + (uint64_t)it * ROW + (uint64_t)k;
-                if (at < cand_cap) {
-                    cand[at] = p;
-                    /* (round 4) the candidate's block_len beside it: cand_lens_kernel - ONE workgroup - then sums an array instead of
-                     * fetching 8 bytes from 16 384 places of the stream, sixteen dependent loads a thread (50 -> 7 us) */
-                    cand_len[at] = load_u64_unaligned(stream + p);
-                }
+                DiscSlot sl;
+                sl.offset = p;
+                sl.block_len = load_u64_unaligned(stream + p);      /* (cand_lens_kernel sums these: not 8 bytes from 16 384 places of the stream again) */
+                slots[(uint64_t)blockIdx.x * DISC_SLOTS + at] = sl;
                 at++;
             }
         }
+    } else {
+        masks[slot] = mask;
     }
+    if (threadIdx.x == 0) wg_counts[blockIdx.x] = total | (total > DISC_SLOTS ? 0x80000000u : 0u);
+}
+
+/* a thread a discovery workgroup: its candidates to their places in stream order (a candidate beyond the arrays' capacity - the
+ * launch was sized before the count was known - is not written, and the walk's result says there were more) */
+__global__ __launch_bounds__(256) void place_cands_kernel(const uint8_t *__restrict__ stream, const uint32_t *__restrict__ wg_counts, uint64_t nwg,
+                                                          const uint64_t *__restrict__ local, const uint64_t *__restrict__ group_base,
+                                                          const DiscSlot *__restrict__ slots, const uint64_t *__restrict__ masks,
+                                                          uint64_t *__restrict__ cand, uint64_t *__restrict__ cand_len, uint64_t cand_cap)
+{
+    const uint64_t wg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wg >= nwg) return;
+    const uint32_t c = wg_counts[wg];
+    uint64_t at = group_base[wg / DISC_SCAN_GROUP] + local[wg];
+    if ((c >> 31) == 0u) {
+        for (uint32_t j = 0; j < c; j++, at++) {
+            if (at >= cand_cap) return;
+            const DiscSlot sl = slots[wg * DISC_SLOTS + j];
+            cand[at] = sl.offset;
+            cand_len[at] = sl.block_len;
+        }
+        return;
+    }
+    /* (rare) the workgroup's verdicts, row by row, thread by thread inside a row */
+    constexpr uint64_t ROW = (uint64_t)DISC_THREADS * DISC_PER;
+    for (int it = 0; it < DISC_ITERS; it++)
+        for (uint32_t t = 0; t < DISC_THREADS; t++) {
+            uint32_t m = (uint32_t)(masks[wg * DISC_THREADS + t] >> (16 * it)) & 0xffffu;
+            while (m) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1;
+                if (at >= cand_cap) return;
+                const uint64_t p = wg * DISC_CHUNK + (uint64_t)t * DISC_PER + (uint64_t)it * ROW + (uint64_t)k;
+                cand[at] = p;
+                cand_len[at] = load_u64_unaligned(stream + p);
+                at++;
+            }
+        }
 }
 
 /* The candidates in front of every discovery workgroup, in two levels (round 6; until then ONE workgroup summed the 65 536
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void scan_counts_kernel(const uint32_t *__
     __shared__ uint64_t s_part64[THREADS / 64];
     __shared__ uint32_t s_last;
     const uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    const uint32_t c = i < n ? counts[i] : 0u;
+    const uint32_t c = i < n ? (counts[i] & 0x7fffffffu) : 0u;      /* (bit 31: the workgroup's candidates are in its verdicts, not in its slots) */
     uint32_t total;
     const uint32_t ex = block_excl_scan_u32<THREADS>(c, s_part, total);       /* (a workgroup's candidates: < 2^22) */
     if (i < n) local[i] = ex;

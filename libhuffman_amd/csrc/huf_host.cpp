@@ -1624,6 +1624,7 @@ static int own_fd_of(const huf_read_writer_t *rw, int writer)
 }
 
 /* ------------------------------------------------------------------ huf_encode (src/encoder.c:261-388) */
+#define SMALL_DECODE_BYTES ((uint64_t)128 << 10)  /* (round 6: streams of up to 128 KiB decode in one workgroup's chain with one wait - 64 KiB: 141 -> ~70 us) */
 #define SMALL_CALL_BYTES ((uint64_t)32 << 10)     /* (1 B: 56 -> 31 us, 4 KiB: 78 -> 54; from 64 KiB on the bound-sized copy back costs more than the waits) */
 static huf_error_t encode_rounds(huf_encoder_t *enc, uint64_t batch, membuf_t *rmem, membuf_t *wmem,
                                  fd_worker_t *rd, fd_worker_t *wr)
@@ -2493,7 +2494,7 @@ static huf_error_t decode_locked(huf_decoder_t *dec, uint64_t *pieces)
     }
     /* a small call between two memory streams: one synchronisation instead of three (hufgpu_decode_small).  Anything but
      * a clean decode - an error, a last block that wants bytes behind `length` - goes on below as if nothing had happened */
-    if (!pieces && rmem && wmem && length <= SMALL_CALL_BYTES && rmem->len - rmem->off >= length) {
+    if (!pieces && rmem && wmem && length <= SMALL_DECODE_BYTES && rmem->len - rmem->off >= length) {
         const uint64_t out_cap = (uint64_t)length * 8 + 64;
         const uint64_t h_need = ((out_cap + 7u) & ~7ull) + 64u;
         if (grow_host(&g_stage.h_a, &g_stage.h_a_cap, (size_t)length) == HUF_ERROR_SUCCESS &&

@@ -829,8 +829,8 @@ static int decode_chain(hufgpu_ctx *ctx, const uint8_t *st, uint64_t avail, uint
 }
 
 /* One small decode with ONE synchronisation (include/huffman_gpu.h), hufgpu_encode_small's twin: the raw stream from pinned
- * host memory, the in-order chain (decode_chain_kernel: the block loop of src/decoder.c:218-276 as it stands, one
- * workgroup - what hufgpu_decode_stream runs for streams of less than 64 KiB anyway), the output and the kernel's six
+ * host memory, the in-order chain (decode_chain_lean_kernel: the block loop of src/decoder.c:218-276, one workgroup, the lean decoders in
+ * front of the exact one), the output and the kernel's six
  * result words back into pinned host memory behind one another.  A call through the general entry points waits three
  * times (stream up, the result words, the output back): 62-140 microseconds where the kernel takes twenty. */
 extern "C" int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, uint64_t avail, uint64_t length, uint32_t flags,
@@ -838,8 +838,13 @@ extern "C" int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, u
                                    uint64_t *raw_len, uint64_t *consumed)
 {
     if (!ctx || !h_in_pinned || !d_in || !d_out || !h_out_pinned || !raw_len || !consumed || avail == 0) return HUFE_ARGUMENT;
-    const uint64_t copy = out_cap < avail * 8u + 64u ? out_cap : avail * 8u + 64u;          /* (a symbol takes a bit at least) */
-    const uint64_t res_at = (copy + 7u) & ~7ull;
+    const uint64_t bound = out_cap < avail * 8u + 64u ? out_cap : avail * 8u + 64u;         /* (a symbol takes a bit at least) */
+    /* what comes back with the result words: twice the stream and a bit - all of the output unless the stream is less than half
+     * of it (round 6; until then the whole bound, eight times the stream, came back every time: 0.5 MiB for a call of 64 KiB).
+     * The rest, if there is one, follows in a second copy. */
+    const uint64_t first = 2u * avail + 4096u;
+    const uint64_t copy = bound < first ? bound : first;
+    const uint64_t res_at = (bound + 7u) & ~7ull;
     if (h_out_cap < res_at + 6u * sizeof(uint64_t)) return HUFE_ARGUMENT;
     *raw_len = *consumed = 0;
     if (length == 0) return HUFE_OK;
@@ -847,7 +852,7 @@ extern "C" int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, u
     hipStream_t s = ctx->stream;
     const int max_tree = (flags & HUFGPU_RELAXED_TREE) ? HUF_TREE_MAX : HUF_TREE_STRICT;
     HIP_OK(ctx, hipMemcpyAsync(d_in, h_in_pinned, avail, hipMemcpyHostToDevice, s));
-    decode_chain_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_in, avail, length, max_tree, (uint8_t *)d_out, out_cap, ctx->d_result, NULL, 0);
+    decode_chain_lean_kernel<DEC_THREADS><<<dim3(1), dim3(DEC_THREADS), 0, s>>>((const uint8_t *)d_in, avail, length, max_tree, (uint8_t *)d_out, out_cap, ctx->d_result);
     HIP_OK(ctx, hipGetLastError());
     HIP_OK(ctx, hipMemcpyAsync(h_out_pinned, d_out, copy, hipMemcpyDeviceToHost, s));
     HIP_OK(ctx, hipMemcpyAsync((char *)h_out_pinned + res_at, ctx->d_result, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -857,7 +862,11 @@ extern "C" int hufgpu_decode_small(hufgpu_ctx_t *ctx, const void *h_in_pinned, u
     *consumed = r[2];
     ctx->complete_used = r[4];
     ctx->complete_raw = r[5];
-    if (r[1] > copy) return HUFE_FATAL;                                                       /* (cannot be: more symbols than bits) */
+    if (r[1] > bound) return HUFE_FATAL;                                                      /* (cannot be: more symbols than bits) */
+    if (r[1] > copy) {
+        HIP_OK(ctx, hipMemcpyAsync((char *)h_out_pinned + copy, (const char *)d_out + copy, r[1] - copy, hipMemcpyDeviceToHost, s));
+        HIP_OK(ctx, hipStreamSynchronize(s));
+    }
     return (int)r[0];
 }
 

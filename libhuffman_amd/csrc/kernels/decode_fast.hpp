@@ -60,6 +60,9 @@ namespace hufgpu {
 #ifndef DFAST_PAIRS_FROM
 #define DFAST_PAIRS_FROM 32768u                      /* symbols of a block from which its scans read the table of pairs (dfast_pair_table) */
 #endif
+#ifndef DREG_MIN_BLOCK
+#define DREG_MIN_BLOCK 32768u                        /* symbols of a block from which decode_regs.hpp's path takes it (below: the tables' chain of leaves is most of a block's time) */
+#endif
 #ifndef DFAST_JUMP_FROM_ROUND
 #define DFAST_JUMP_FROM_ROUND 1                      /* the round loop's pass from which runs of one byte value are looked for (dfast_run_jump) */
 #endif
@@ -1122,7 +1125,7 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
      *  1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
     int regs = 0;                                       /* (uniform) what decode_regs.hpp made of the block: 0 = it declined (another shape of tree, long codes) */
 #ifndef DFAST_NO_REGS
-    if (leaf < 0 && m.block_len >= 32768u)
+    if (leaf < 0 && m.block_len >= DREG_MIN_BLOCK)
         regs = decode_payload_regs<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase, nullptr, 0,
                                             [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len); });
     if (leaf < 0 && regs == 0)

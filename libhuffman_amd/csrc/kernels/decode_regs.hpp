@@ -300,7 +300,9 @@ __device__ __forceinline__ DregSeg dreg_plan(uint64_t ts, bool trust, uint32_t s
             const float r = (float)(uint32_t)rem;
             const float nseg = ceilf(r / (float)((uint32_t)THREADS * SUB));
             const float even = ceilf(r / (nseg * (float)THREADS));
-            sb = dmin<uint32_t>(dmax<uint32_t>((uint32_t)even, 64u), SUB);
+            /* (not below 192 bits while the registers allow: a speculative track needs a hundred bits or so to fall into step,
+             *  and a short payload spread thin over all the lanes - 4 KiB: 60 bits a lane - is put right one lane a round) */
+            sb = dmin<uint32_t>(dmax<uint32_t>((uint32_t)even, 192u), SUB);
         }
     }
     g.sb = uni32(sb);
@@ -572,6 +574,84 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
 #undef DREG_REL
 #undef DREG_WORD0
 #undef DREG_WANTED
+}
+
+/* The in-order chain of decode.hpp (decode_chain_kernel: the block loop of src/decoder.c:218-276, one workgroup) with the
+ * lean decoder in front of the exact one: a block with an encoder-shaped tree goes through decode_payload_regs first - told
+ * where the stream ends as a hint at where its payload does, which is right for the stream of one block that a small call
+ * usually is - and only what that cannot vouch for (a damaged block, another shape of tree, a one-symbol block) through
+ * decode_block, which has the reference's error codes and byte counts.  What hufgpu_decode_small runs (streams of up to
+ * 32 KiB: the call is a latency, and the exact decoder's 54 instructions a symbol on one workgroup were most of it -
+ * 4 KiB 76 us, 64 KiB 141 us a call in round 5).  result[] as decode_chain_kernel's. */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_t *__restrict__ stream, uint64_t avail, uint64_t length,
+                                                                    int max_tree_len, uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                    uint64_t *__restrict__ result)
+{
+    __shared__ DecShared<THREADS> sh;
+    uint64_t rd = 0, wr = 0, nblk = 0;
+    uint64_t good_rd = 0, good_wr = 0;
+    int err = HUFE_OK;
+    while (length > rd) {                                             /* decoder.c:218 */
+        good_rd = rd;
+        good_wr = wr;
+        if (avail - rd < 8) { err = HUFE_RW; break; }                 /* decoder.c:220-224 */
+        const uint64_t block_len = uni64(load_u64_unaligned(stream + rd));
+        rd += 8;
+        if (avail - rd < 2) { err = HUFE_RW; break; }                 /* decoder.c:231-234 */
+        const int16_t tl = (int16_t)uni32((uint32_t)stream[rd] | ((uint32_t)stream[rd + 1] << 8));
+        rd += 2;
+        if (tl < 0 || tl > max_tree_len) { err = HUFE_OVERFLOW; break; }   /* decoder.c:237-239 */
+        if (avail - rd < 2ull * (uint64_t)tl) { err = HUFE_RW; break; }    /* decoder.c:248-252 */
+        const uint8_t *tree = stream + rd;
+        rd += 2ull * (uint64_t)tl;
+        if (block_len == 0) { nblk++; continue; }
+        uint64_t want = block_len;
+        if (want > (avail - rd) * 8ull) want = (avail - rd) * 8ull + 1;
+        const bool capped = want > out_cap - wr;
+        if (capped) want = out_cap - wr;
+        if (want > HUF_MAX_BLOCK_LEN) { err = HUFE_ARGUMENT; break; }
+        uint64_t end_bits = 0, produced = 0;
+        if (want == block_len && tl >= 9 && tl <= HUF_TREE_MAX && block_len >= 256u) {
+            const uint64_t hint = length > rd ? length - rd : 0;
+            __syncthreads();
+            /* (blocks of a few KiB have codes beyond the table's 12 bits - a byte seen once in 4 096 - and the path of this file
+             *  declines them: decode_fast.hpp's lean decoder walks such codes, with the tables of the tree's walk) */
+            const int lean = block_len < DREG_MIN_BLOCK ? DREG_NO_TABLES :
+                decode_payload_regs<THREADS>(sh, stream + rd, avail - rd, avail - rd, block_len, out + wr, &end_bits, hint,
+                                             [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, tl); });
+            bool done = lean == DREG_OK;
+            if (lean == DREG_NO_TABLES) {
+                int leaf = -1;
+                end_bits = 0;
+                __syncthreads();
+                done = dec_build_tables<THREADS, true>(sh, tree, tl, &leaf) == HUFE_OK && leaf < 0 &&
+                       decode_payload_dfast<THREADS>(sh, stream + rd, avail - rd, avail - rd, block_len, out + wr, &end_bits, hint);
+            }
+            if (done) {
+                rd += (end_bits + 7) >> 3;
+                wr += block_len;
+                nblk++;
+                continue;
+            }
+            end_bits = 0;
+            __syncthreads();
+        }
+        if (want) err = decode_block<THREADS>(sh, tree, tl, want, avail - rd, out + wr, &end_bits, &produced);
+        if (err != HUFE_OK) { wr += produced; break; }   /* symbols before the failure stay delivered */
+        if (capped) { wr += want; err = HUFE_MEMORY; break; }
+        rd += (end_bits + 7) >> 3;
+        wr += block_len;
+        nblk++;
+    }
+    if (threadIdx.x == 0) {
+        result[0] = (uint64_t)err;
+        result[1] = wr;
+        result[2] = rd;
+        result[3] = nblk;
+        result[4] = (err == HUFE_OK) ? rd : good_rd;
+        result[5] = (err == HUFE_OK) ? wr : good_wr;
+    }
 }
 
 }  // namespace hufgpu

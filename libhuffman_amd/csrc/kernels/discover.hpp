@@ -369,7 +369,7 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
         const uint64_t nextc = (blockIdx.x + 1u < ncand) ? uni64(cand[blockIdx.x + 1u]) : 0ull;
         const uint64_t hint = nextc > pay0 ? nextc - pay0 : 0ull;
 #ifndef DFAST_NO_REGS
-        const int shaped = !(block_len >= 32768u && tl <= HUF_TREE_MAX) ? 0 :
+        const int shaped = !(block_len >= DREG_MIN_BLOCK && tl <= HUF_TREE_MAX) ? 0 :
             decode_payload_regs<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint,
                                          [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, stream + c + HUF_HEADER_FIXED, tl); });
         if (shaped != 0 ? shaped == 1 /* DREG_OK */

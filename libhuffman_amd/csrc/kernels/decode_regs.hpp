@@ -358,10 +358,14 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     uint64_t true_start = 0, produced = 0;
     bool ok = true;
     bool trust = true;
+    unsigned long long pt0 = DPROF_T();
     DregSeg g = DREG_PLAN(0, true, 0);
     const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+    DPROF_ADD(10, pt0); pt0 = DPROF_T();
     if (!build_tables()) return DREG_NO_TABLES;
+    DPROF_ADD(11, pt0); pt0 = DPROF_T();
     dreg_commit(slice + lane, q, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
+    DPROF_ADD(12, pt0);
     bool have = true;                                                  /* (uniform) the columns hold segment g */
     while (produced < block_len) {
         if (true_start >= pay_bits) { ok = false; DFAST_DBG(0, 1); break; }
@@ -506,10 +510,12 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         }
         /* this segment's columns have been read for the last time: the next segment's words into them (the wait for them
          * counts only what went out before them) */
+        DPROF_ADD(7, pt); pt = DPROF_T();
         if (more && produced + take < block_len) {
             dreg_commit(slice + lane, qn, sel, pay, gn.seg0, readable, DREG_WORD0(gn), DREG_WANTED(gn));
             have = true;
         }
+        DPROF_ADD(8, pt); pt = DPROF_T();
         if (quota != 0u) {
             if (!partial && t.bad) lane_ok = false;
             if (qe > pay_rel) lane_ok = false;                         /* a codeword of the block needs bits past the payload */
@@ -551,6 +557,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
                 for (uint32_t c = 0; c < (quota & 3u); c++) gp[(quota & ~3u) + c] = (uint8_t)(tw >> (8u * c));
             }
         }
+        DPROF_ADD(9, pt); pt = DPROF_T();
         {
             /* is every lane content?  (The waves' words lie behind the rounds': this barrier also ends the segment.) */
             const uint32_t wave_bad = __ballot(!lane_ok) != 0ull ? 1u : 0u;

@@ -263,6 +263,38 @@ __device__ __forceinline__ void wave_sort_r(uint32_t (&k)[4])
 }
 __device__ __forceinline__ void wave_sort256(uint32_t (&k)[4]) { wave_sort_r<4>(k); }
 
+/* Round 6: the last phase of that sort alone - a bitonic MERGE: keys that go down and then up along the sorted positions (followed by
+ * KMAX) come out ascending in log2(64 R) stages instead of the sort's 21 / 28 / 36.  What a tree round leaves behind is such a sequence
+ * when it is laid out for it (tree_fast_wave): the keys it did not pair are still sorted, and the nodes it made come out in key order. */
+template <int R>
+__device__ __forceinline__ void wave_merge_r(uint32_t (&k)[4])
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    constexpr int STAGES = R == 4 ? 8 : (R == 2 ? 7 : 6);              /* log2(64 R) */
+#pragma unroll
+    for (int st = STAGES - 1; st >= 0; st--) {
+        const uint32_t jj = 1u << st;
+        if (jj >= (uint32_t)R) {
+            const bool lower = (lane & (jj / R)) == 0u;               /* I hold the pair's lower position */
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t d = jj / R;
+                const uint32_t o = d == 1 ? wave_xor_u32<1>(k[r]) : d == 2 ? wave_xor_u32<2>(k[r]) : d == 4 ? wave_xor_u32<4>(k[r])
+                                 : d == 8 ? wave_xor_u32<8>(k[r]) : d == 16 ? wave_xor_u32<16>(k[r]) : wave_xor_u32<32>(k[r]);
+                k[r] = lower ? dmin(k[r], o) : dmax(k[r], o);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < (uint32_t)R; r++) {
+                if (r & jj) continue;
+                const uint32_t lo = dmin(k[r], k[r | jj]), hi = dmax(k[r], k[r | jj]);
+                k[r] = lo;
+                k[r | jj] = hi;
+            }
+        }
+    }
+}
+
 struct TreeLds {                  /* 5 KiB: what bounds the tree waves a CU holds (they are latency bound): 32 per CU */
     uint64_t state[HUF_NSLOT];    /* per node: its path to an ancestor, see TREE_STATE below.  The entries of nodes that do
                                      not exist yet also serve as scratch for keys on their way into fewer registers: with
@@ -375,13 +407,29 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
 
     int node = HUF_NSYM;
     int root = -1;
+    bool sorted = false;                                           /* (uniform) the keys stand in key order along the sorted positions lane * R + r */
     for (;;) {
-        const uint32_t a = wave_min_u32(dmin(dmin(k[0], k[1]), dmin(k[2], k[3])));
-        if (a == KMAX) { root = node - 1; break; }                 /* tree.c:355-358 */
+        uint32_t a, b;
         uint32_t t[4];
+        if (sorted) {
+            /* (round 6) the two smallest are the first two: no reduction over the wave */
+            a = wave_lane_u32(k[0], 0);
+            b = R == 1u ? wave_lane_u32(k[0], 1) : wave_lane_u32(k[1], 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) t[j] = (k[j] == a) ? KMAX : k[j];
-        const uint32_t b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
+            for (int j = 0; j < 4; j++) t[j] = (k[j] == a) ? KMAX : k[j];
+        } else {
+            a = wave_min_u32(dmin(dmin(k[0], k[1]), dmin(k[2], k[3])));
+            if (a != KMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[j] = (k[j] == a) ? KMAX : k[j];
+                b = wave_min_u32(dmin(dmin(t[0], t[1]), dmin(t[2], t[3])));
+            } else {
+                b = KMAX;
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[j] = k[j];
+            }
+        }
+        if (a == KMAX) { root = node - 1; break; }                 /* tree.c:355-358 */
         const int i1 = 511 - (int)(a & 511u);
         if (b == KMAX) {                                           /* tree.c:410-413: left-only wrap root */
             if (lane == 0) {
@@ -408,7 +456,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
             if (sel >= round_min) {
                 const uint32_t pairs = sel >> 1;
                 if (R == 4u) {
-                    wave_sort_r<4>(k);
+                    if (!sorted) wave_sort_r<4>(k);
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const uint32_t p = 2u * (uint32_t)lane + (uint32_t)h;
@@ -425,7 +473,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                         }
                     }
                 } else if (R == 2u) {
-                    wave_sort_r<2>(k);
+                    if (!sorted) wave_sort_r<2>(k);
                     const uint32_t p = (uint32_t)lane;
                     if (p < pairs) {
                         const uint32_t x = k[0], y = k[1];
@@ -439,7 +487,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                         k[1] = KMAX;
                     }
                 } else {
-                    wave_sort_r<1>(k);
+                    if (!sorted) wave_sort_r<1>(k);
                     const uint32_t p = (uint32_t)lane >> 1;
                     const uint32_t o = wave_xor_u32<1>(k[0]);              /* the pair's other key */
                     if (p < pairs) {
@@ -461,23 +509,56 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                 const uint32_t was = live;                           /* keys at positions < was are live or just paired */
                 live -= pairs;
                 const uint32_t nr = live <= 64u ? 1u : (live <= 128u ? 2u : 4u);
-                if (nr < R) {
-                    /* fewer registers from here on: new node p (at position 2p) becomes key p, a key that was
-                     * not paired (position q >= 2 pairs) key q - pairs */
-                    s_scratch = reinterpret_cast<uint32_t *>(s_state + node);
+                s_scratch = reinterpret_cast<uint32_t *>(s_state + node);
+                if (nr == 4u && pairs <= 64u) {
+                    /* Round 6.  More than 128 keys are left: the next round's sort would be the dear one (36 stages on four registers,
+                     * ~650 instructions), and a Zipf-like block spends its first rounds here - the two smallest rates bound what may
+                     * pair, a few dozen items a round.  But the keys that were NOT paired still stand in key order, and the few new
+                     * nodes only have to be put among them: the nodes sorted on their own (64 keys, one register, 21 stages - their
+                     * sums rise with p, but equal sums come in FALLING key order, the later node having the larger index), then
+                     * unpaired keys (downwards from position 0) and nodes (upwards behind them) as ONE bitonic sequence through LDS,
+                     * merged in 8 stages.  The order is checked, not trusted (one compare with the next position). */
+                    const uint32_t unp = live - pairs;               /* keys that were not paired */
 #pragma unroll
                     for (uint32_t r = 0; r < 4; r++) {
                         const uint32_t q = (uint32_t)lane * R + r;
-                        if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? (q >> 1) : (q - pairs)] = k[r];
+                        if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? unp + (q >> 1) : was - 1u - q] = k[r];
                     }
                     TREE_WAVE_SYNC();
-                    R = nr;
+                    uint32_t nd[4] = {(uint32_t)lane < pairs ? s_scratch[unp + (uint32_t)lane] : KMAX, KMAX, KMAX, KMAX};
+                    wave_sort_r<1>(nd);
+                    TREE_WAVE_SYNC();
+                    if ((uint32_t)lane < pairs) s_scratch[unp + (uint32_t)lane] = nd[0];
+                    TREE_WAVE_SYNC();
+                    R = 4u;
 #pragma unroll
                     for (uint32_t r = 0; r < 4; r++) {
-                        const uint32_t c = (uint32_t)lane * R + r;
-                        k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
+                        const uint32_t c = (uint32_t)lane * 4u + r;
+                        k[r] = c < live ? s_scratch[c] : KMAX;
                     }
                     TREE_WAVE_SYNC();
+                    wave_merge_r<4>(k);
+                    const uint32_t nxt_first = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)k[0], 0x130, 0xf, 0xf, false);   /* wave_shl:1, lane 63 <- KMAX */
+                    sorted = __ballot(!(k[0] <= k[1] && k[1] <= k[2] && k[2] <= k[3] && k[3] <= nxt_first)) == 0ull;
+                } else {
+                    sorted = false;
+                    if (nr < R) {
+                        /* fewer registers from here on: new node p (at position 2p) becomes key p, a key that was
+                         * not paired (position q >= 2 pairs) key q - pairs */
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; r++) {
+                            const uint32_t q = (uint32_t)lane * R + r;
+                            if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? (q >> 1) : (q - pairs)] = k[r];
+                        }
+                        TREE_WAVE_SYNC();
+                        R = nr;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; r++) {
+                            const uint32_t c = (uint32_t)lane * R + r;
+                            k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
+                        }
+                        TREE_WAVE_SYNC();
+                    }
                 }
                 continue;
             }
@@ -486,6 +567,7 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
         const uint32_t nk = (((a >> 9) + (b >> 9)) << 9) | (uint32_t)(511 - node);   /* tree.c:407 */
 #pragma unroll
         for (int j = 0; j < 4; j++) k[j] = (k[j] == a) ? nk : ((t[j] == b) ? KMAX : t[j]);
+        sorted = false;                                            /* (the new key stands where the smaller of the two stood) */
         if (lane == 0) {
             const uint32_t lx = s_lcnt[i1];                        /* tree.c:390-404 */
             s_state[i1] = tree_state((uint32_t)node, 1u, 1u, 0u);

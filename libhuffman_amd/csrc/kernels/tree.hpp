@@ -510,14 +510,16 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                 live -= pairs;
                 const uint32_t nr = live <= 64u ? 1u : (live <= 128u ? 2u : 4u);
                 s_scratch = reinterpret_cast<uint32_t *>(s_state + node);
-                if (nr == 4u && pairs <= 64u) {
-                    /* Round 6.  More than 128 keys are left: the next round's sort would be the dear one (36 stages on four registers,
-                     * ~650 instructions), and a Zipf-like block spends its first rounds here - the two smallest rates bound what may
-                     * pair, a few dozen items a round.  But the keys that were NOT paired still stand in key order, and the few new
-                     * nodes only have to be put among them: the nodes sorted on their own (64 keys, one register, 21 stages - their
-                     * sums rise with p, but equal sums come in FALLING key order, the later node having the larger index), then
-                     * unpaired keys (downwards from position 0) and nodes (upwards behind them) as ONE bitonic sequence through LDS,
-                     * merged in 8 stages.  The order is checked, not trusted (one compare with the next position). */
+                {
+                    /* Round 6: the next round does not sort again.  The keys that were NOT paired still stand in key order and the new
+                     * nodes only have to be put among them: unpaired keys downwards from position 0, nodes upwards behind them - ONE
+                     * bitonic sequence through LDS, in as many registers as the keys need - merged in log2(64 nr) stages (8 / 7 / 6
+                     * where the sort takes 36 / 28 / 21).  The nodes' sums rise with p, but EQUAL sums come in falling key order (the
+                     * later node has the larger index): while more than 64 keys are left - the rounds of the dear sorts, 250 and 650
+                     * instructions, in which a Zipf-like block pairs a few dozen items of nearly equal rates - nodes that are not in
+                     * order are sorted on their own first (64 keys in one register: 21 stages); the rounds on one register have no
+                     * ties to speak of and take their chance.  The order is CHECKED after the merge (one compare with the next position): keys that are not in order
+                     * are sorted by the next round as every round did before. */
                     const uint32_t unp = live - pairs;               /* keys that were not paired */
 #pragma unroll
                     for (uint32_t r = 0; r < 4; r++) {
@@ -525,40 +527,52 @@ __device__ __forceinline__ uint64_t tree_fast_wave(const uint32_t (&rate)[4], Tr
                         if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? unp + (q >> 1) : was - 1u - q] = k[r];
                     }
                     TREE_WAVE_SYNC();
-                    uint32_t nd[4] = {(uint32_t)lane < pairs ? s_scratch[unp + (uint32_t)lane] : KMAX, KMAX, KMAX, KMAX};
-                    wave_sort_r<1>(nd);
-                    TREE_WAVE_SYNC();
-                    if ((uint32_t)lane < pairs) s_scratch[unp + (uint32_t)lane] = nd[0];
-                    TREE_WAVE_SYNC();
-                    R = 4u;
+                    if (nr >= 2u) {
+                        /* the nodes on their own: in order already (no two equal sums - one compare with the next node says), or
+                         * sorted in one register (up to 64 of them) or two */
+                        const uint32_t p0 = 2u * (uint32_t)lane, p1 = p0 + 1u;
+                        uint32_t nd[4] = {KMAX, KMAX, KMAX, KMAX};
+                        if (pairs <= 64u) {
+                            nd[0] = (uint32_t)lane < pairs ? s_scratch[unp + (uint32_t)lane] : KMAX;
+                            const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)nd[0], 0x130, 0xf, 0xf, false);   /* wave_shl:1, lane 63 <- KMAX */
+                            if (__ballot(nd[0] > nf) != 0ull) {
+                                wave_sort_r<1>(nd);
+                                TREE_WAVE_SYNC();
+                                if ((uint32_t)lane < pairs) s_scratch[unp + (uint32_t)lane] = nd[0];
+                                TREE_WAVE_SYNC();
+                            }
+                        } else {
+                            nd[0] = p0 < pairs ? s_scratch[unp + p0] : KMAX;
+                            nd[1] = p1 < pairs ? s_scratch[unp + p1] : KMAX;
+                            wave_sort_r<2>(nd);
+                            TREE_WAVE_SYNC();
+                            if (p0 < pairs) s_scratch[unp + p0] = nd[0];
+                            if (p1 < pairs) s_scratch[unp + p1] = nd[1];
+                            TREE_WAVE_SYNC();
+                        }
+                    }
+                    R = nr;
 #pragma unroll
                     for (uint32_t r = 0; r < 4; r++) {
-                        const uint32_t c = (uint32_t)lane * 4u + r;
-                        k[r] = c < live ? s_scratch[c] : KMAX;
+                        const uint32_t c = (uint32_t)lane * R + r;
+                        k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
                     }
                     TREE_WAVE_SYNC();
-                    wave_merge_r<4>(k);
-                    const uint32_t nxt_first = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)k[0], 0x130, 0xf, 0xf, false);   /* wave_shl:1, lane 63 <- KMAX */
-                    sorted = __ballot(!(k[0] <= k[1] && k[1] <= k[2] && k[2] <= k[3] && k[3] <= nxt_first)) == 0ull;
-                } else {
-                    sorted = false;
-                    if (nr < R) {
-                        /* fewer registers from here on: new node p (at position 2p) becomes key p, a key that was
-                         * not paired (position q >= 2 pairs) key q - pairs */
-#pragma unroll
-                        for (uint32_t r = 0; r < 4; r++) {
-                            const uint32_t q = (uint32_t)lane * R + r;
-                            if (r < R && q < was && k[r] != KMAX) s_scratch[q < 2u * pairs ? (q >> 1) : (q - pairs)] = k[r];
-                        }
-                        TREE_WAVE_SYNC();
-                        R = nr;
-#pragma unroll
-                        for (uint32_t r = 0; r < 4; r++) {
-                            const uint32_t c = (uint32_t)lane * R + r;
-                            k[r] = (r < R && c < live) ? s_scratch[c] : KMAX;
-                        }
-                        TREE_WAVE_SYNC();
+                    bool in_order;
+                    if (R == 4u) {
+                        wave_merge_r<4>(k);
+                        const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)k[0], 0x130, 0xf, 0xf, false);   /* wave_shl:1, lane 63 <- KMAX */
+                        in_order = k[0] <= k[1] && k[1] <= k[2] && k[2] <= k[3] && k[3] <= nf;
+                    } else if (R == 2u) {
+                        wave_merge_r<2>(k);
+                        const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)k[0], 0x130, 0xf, 0xf, false);
+                        in_order = k[0] <= k[1] && k[1] <= nf;
+                    } else {
+                        wave_merge_r<1>(k);
+                        const uint32_t nf = (uint32_t)__builtin_amdgcn_update_dpp((int)KMAX, (int)k[0], 0x130, 0xf, 0xf, false);
+                        in_order = k[0] <= nf;
                     }
+                    sorted = __ballot(!in_order) == 0ull;
                 }
                 continue;
             }

@@ -757,9 +757,12 @@ __device__ int decode_single_leaf(SH &sh, uint32_t symv, const uint8_t *pay, uin
  * Returns HUFE_OK with the tables in sh (*single_leaf = -1), HUFE_OK with *single_leaf = the byte of
  * a tree whose root has one leaf child on the left (no table is built: the payload is all zero
  * bits), or HUFE_CORRUPTED for a NULL root.  SPEC = the table also folds "failing run + the codeword
- * behind it" into one entry, which only the speculative (self-synchronising) lanes profit from. */
+ * behind it" into one entry, which only the speculative (self-synchronising) lanes profit from.
+ * (Inlined by force: out of line it is compiled without its callers' register bound - 70 registers - and a kernel's count is
+ *  the largest of its own and its callees': decode_fast_kernel and probe_kernel fell to three workgroups a CU when the
+ *  compiler stopped inlining it; tests/test_isa_check.py watches the count.) */
 template <int THREADS, bool SPEC = true>
-__device__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, int *single_leaf)
+__device__ __forceinline__ int dec_build_tables(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len, int *single_leaf)
 {
     constexpr int ENT = DecShared<THREADS>::ENT;
     const int tid = (int)threadIdx.x;

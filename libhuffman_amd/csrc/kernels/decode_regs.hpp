@@ -24,10 +24,10 @@ namespace hufgpu {
  *   - a lane's share of a segment is at most 288 payload bits and (the shares are cut to the block's bits per
  *     symbol) about 40 symbols, at most 64: sixteen registers of four bytes (DREG_ITERS);
  *   - ONE pass form: from the lane's start, four symbols an iteration with decode_sub's loop (entries byte << 8 | length
- *     over the 11 bits behind a codeword's first bit, a position register that counts down with a gap, both lengths
- *     subtracted by one v_dot4c) - 27 vector instructions per four symbols, the iteration's four bytes into register k;
- *     the last iteration that began in front of the share's end is looked at again, codeword by codeword, for the
- *     end (the first codeword start at or behind the share's end) and the count;
+ *     over the 12 bits at a position, a position register that counts down with a gap, both lengths of a window
+ *     subtracted by one v_dot4c) - 28 vector instructions per four symbols, the iteration's four bytes into register k;
+ *     a lane whose position has passed its share's end is switched off; the four lengths of its last iteration give
+ *     the end (the first codeword start at or behind the share's end) and the count;
  *   - the rounds are decode_fast's: lane 0 starts at the segment's true first codeword, every other lane at its own
  *     first bit, then at its left neighbour's end, until no start changes.  A wave in which a start changed runs the
  *     pass again (every lane of it: a lane whose start stood decodes what it decoded before);
@@ -76,12 +76,10 @@ __device__ __forceinline__ uint32_t dreg_entry(uint32_t lut_addr, uint32_t d)
 
 /* what a pass leaves in a lane besides the sixteen registers */
 struct DregTrack {
-    uint32_t Pend;       /* the first codeword start at or behind the share's end (the start, for a lane that holds nothing) */
+    uint32_t Rend;       /* (as R, not gapped) the first codeword start at or behind the share's end (the start, for a lane that holds nothing) */
     uint32_t cnt;        /* codewords that start in front of the share's end */
-    uint32_t ng;         /* iterations that began in front of the share's end: registers 0 .. ng - 1 hold the lane's bytes */
-    uint32_t Pg;         /* where the last of them began */
-    uint32_t fg;         /* the first bits (bit 31) of the codewords in front of it, OR-ed */
-    bool bad;            /* one of the cnt codewords began with a 1 */
+    bool bad;            /* a codeword of the lane's iterations began with a 1 (the last iteration's may lie behind the share's end: whoever
+                            needs to know exactly walks the lane's codewords again, decode_payload_regs) */
     bool over;           /* sixteen iterations were not enough */
 };
 
@@ -91,7 +89,7 @@ struct DregTrack {
 struct DregSyms { uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15; };
 __device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uint32_t Pstart, uint32_t Phi, DregSyms &sym, DregTrack &t)
 {
-    uint32_t P = Pstart, Pg = Pstart, ng = 0, firsts = 0, fg = 0;
+    uint32_t P = Pstart, ng = 0, firsts = 0, L4 = 0;
 #define DREG_WINDOW(PAIR)                                                                                      \
     {                                                                                                         \
         const uint32_t d1_ = dreg_bits_at(P, lane4);                                                          \
@@ -103,20 +101,22 @@ __device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uin
         PAIR = __builtin_amdgcn_perm(e2_, e1_, 0x04000501u);           /* byte 1, byte 2, length 1, length 2 */ \
         P = (uint32_t)__builtin_amdgcn_sdot4((int)PAIR, (int)0xffff0000, (int)P, false) & 0xff1fu;            \
     }
-    /* one iteration: four symbols into register S (the chain of iterations ends when no lane of the wave has a position
-     * in front of its share's end any more) */
+    /* one iteration: four symbols into register S.  The chain of iterations ends when no lane of the wave has a position in
+     * front of its share's end any more; a lane that is done is switched OFF while its wave goes on (a branch, not selects):
+     * its position, the four lengths of its last iteration and that iteration's number stand where it left them - round 6b:
+     * until then a done lane walked on and three selects an iteration kept what the end needed (31 -> 28 instructions). */
 #define DREG_ITER(S, K)                                                                                        \
     {                                                                                                         \
         const bool act = P > Phi;                                                                             \
         if (!__any(act)) goto done;                                                                           \
-        /* a lane that is done walks on while its wave does: what it reads there is ignored */                 \
-        Pg = act ? P : Pg;                                                                                    \
-        fg = act ? firsts : fg;                                                                               \
-        ng = act ? (K) : ng;                     /* (positions only grow: the active iterations are the first ng) */ \
-        uint32_t p01, p23;                                                                                    \
-        DREG_WINDOW(p01)                                                                                      \
-        DREG_WINDOW(p23)                                                                                      \
-        S = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                                     \
+        if (act) {                                                                                            \
+            uint32_t p01, p23;                                                                                \
+            DREG_WINDOW(p01)                                                                                  \
+            DREG_WINDOW(p23)                                                                                  \
+            S = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                                 \
+            L4 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);     /* lengths 1 .. 4 */                       \
+            ng = (K);                            /* (positions only grow: the active iterations are the first ng) */ \
+        }                                                                                                     \
     }
     DREG_ITER(sym.s0, 1u) DREG_ITER(sym.s1, 2u) DREG_ITER(sym.s2, 3u) DREG_ITER(sym.s3, 4u)
     DREG_ITER(sym.s4, 5u) DREG_ITER(sym.s5, 6u) DREG_ITER(sym.s6, 7u) DREG_ITER(sym.s7, 8u)
@@ -128,32 +128,15 @@ done:
 #undef DREG_ITER
 #undef DREG_WINDOW
     t.over = P > Phi;
-    t.ng = ng;
-    t.Pg = Pg;
-    t.fg = fg;
-    t.Pend = Pstart;
-    t.cnt = 0;
-    t.bad = false;
-    if (__any(ng != 0u)) {
-        /* the last iteration that counts again: its codewords begin at Pg, b1, b2, b3 and it ends at b4 */
-        const uint32_t d1 = dreg_bits_at(Pg, lane4);
-        const uint32_t e1 = dreg_entry(lut_addr, d1);
-        const uint32_t d2 = d1 << (e1 & 31u);
-        const uint32_t e2 = dreg_entry(lut_addr, d2);
-        const uint32_t b1 = (Pg - (e1 & 31u)) & 0xff1fu, b2 = (b1 - (e2 & 31u)) & 0xff1fu;
-        const uint32_t d3 = dreg_bits_at(b2, lane4);
-        const uint32_t e3 = dreg_entry(lut_addr, d3);
-        const uint32_t d4 = d3 << (e3 & 31u);
-        const uint32_t e4 = dreg_entry(lut_addr, d4);
-        const uint32_t b3 = (b2 - (e3 & 31u)) & 0xff1fu, b4 = (b3 - (e4 & 31u)) & 0xff1fu;
-        const bool in1 = b1 > Phi, in2 = b2 > Phi, in3 = b3 > Phi;
-        const uint32_t fb = fg | d1 | (in1 ? d2 : 0u) | (in2 ? d3 : 0u) | (in3 ? d4 : 0u);
-        if (ng != 0u) {
-            t.cnt = 4u * ng - 3u + (in1 ? 1u : 0u) + (in2 ? 1u : 0u) + (in3 ? 1u : 0u);
-            t.Pend = !in1 ? b1 : !in2 ? b2 : !in3 ? b3 : b4;
-            t.bad = (fb >> 31) != 0u;
-        }
-    }
+    t.bad = (firsts >> 31) != 0u;
+    /* the last iteration's codewords began at R1 + length 1, R1, R2, R3 and it ended at R4 = where the lane stands: from the
+     * four lengths, no look-up (until round 6b the iteration was looked up again: four dependent table reads a pass) */
+    const uint32_t RPhi = dreg_ungap(Phi);
+    const uint32_t R4 = dreg_ungap(P);
+    const uint32_t R3 = R4 + (L4 >> 24), R2 = R3 + ((L4 >> 16) & 0xffu), R1 = R2 + ((L4 >> 8) & 0xffu);
+    const bool in1 = R1 > RPhi, in2 = R2 > RPhi, in3 = R3 > RPhi;
+    t.cnt = ng != 0u ? 4u * ng - 3u + (in1 ? 1u : 0u) + (in2 ? 1u : 0u) + (in3 ? 1u : 0u) : 0u;
+    t.Rend = !in1 ? R1 : !in2 ? R2 : !in3 ? R3 : R4;
 }
 
 /* the position behind the first n codewords from Pfrom; *first_bits |= their first bits (bit 31).  (One lane a block: the
@@ -403,7 +386,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         const uint32_t hi_eff = dmin<uint32_t>(hi, pay_rel);
         uint32_t Phi = dreg_gap(rbase - (dead ? lo : hi_eff));
         DregTrack t;
-        t.Pend = 0; t.cnt = 0; t.ng = 0; t.Pg = 0; t.fg = 0; t.bad = false; t.over = false;
+        t.Rend = 0; t.cnt = 0; t.bad = false; t.over = false;
         uint32_t end = hi, cnt = 0;
         bool need = !dead;
         int rounds = 0;
@@ -416,7 +399,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
                 /* (a track of more than 64 look-ups - a speculative one through entries that leave the tree, bit by bit; or,
                  *  when the rounds are over, the lane's true one - ends where the share does for now: its neighbour is not
                  *  sent in front of its own column) */
-                end = (dead || t.over) ? hi : rbase - dreg_ungap(t.Pend);
+                end = (dead || t.over) ? hi : rbase - t.Rend;
                 cnt = dead ? 0u : t.cnt;
             }
             if (rounds == 0 && end_bits && trust && !hinted) {
@@ -498,12 +481,14 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         bool lane_ok = true;
         uint32_t qe = end;                                             /* the position behind the lane's last symbol of the block */
         const bool partial = quota != 0u && quota < cnt;               /* the block ends inside this lane's codewords */
-        if (__ballot(partial)) {
-            /* from the last iteration's start when the block's last symbol lies in it, else from the lane's start */
-            const bool tail = partial && quota > 4u * (t.ng - 1u);
-            uint32_t fb = tail ? t.fg : 0u;
-            const uint32_t Pq = dreg_walk(lut_addr, lane4, tail ? t.Pg : dreg_gap(rbase - start), partial ? (tail ? quota - 4u * (t.ng - 1u) : quota) : 0u, &fb);
-            if (partial) {
+        /* such a lane's end, and whether a first bit of 1 that a lane's pass saw belongs to one of ITS codewords (the pass looks at
+         * whole iterations: the last one's may begin behind the share's end - the right neighbour's, who sees them too, or nobody's
+         * behind the block's last symbol): its codewords again, one by one.  A lane or two a block. */
+        const bool again = quota != 0u && (partial || t.bad);
+        if (__ballot(again)) {
+            uint32_t fb = 0;
+            const uint32_t Pq = dreg_walk(lut_addr, lane4, dreg_gap(rbase - start), again ? quota : 0u, &fb);
+            if (again) {
                 qe = rbase - dreg_ungap(Pq);
                 lane_ok = (fb >> 31) == 0u;
             }
@@ -517,7 +502,6 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         }
         DPROF_ADD(8, pt); pt = DPROF_T();
         if (quota != 0u) {
-            if (!partial && t.bad) lane_ok = false;
             if (qe > pay_rel) lane_ok = false;                         /* a codeword of the block needs bits past the payload */
             if (end_bits && ex + quota == take && (uint64_t)take == remaining) sh.qend = qe;
             /* the registers: all of the lane's symbols and the whole last dword still inside this block's output, or

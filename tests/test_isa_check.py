@@ -86,6 +86,21 @@ def test_the_shipped_kernels_are_clean(shipped_table):
     assert all(r["scratch"] <= 32 for n, r in shipped_table.items() if "decode_sub_kernel" in n)
 
 
+def test_the_decoders_keep_four_workgroups_a_cu(shipped_table):
+    """round 6: `__launch_bounds__(512, 8)` is a wish - the compiler drops to 7 waves a SIMD (three workgroups a CU) with a
+    warning, and a kernel's register count is the largest of its own and its out-of-line callees': dec_build_tables, no longer
+    inlined once a third kernel called it, took 70 registers and decode_fast_kernel / probe_kernel with it (1.15 -> 1.4 ms per
+    GiB, unnoticed for a dozen commits).  The kernels whose design is four workgroups of 512 a CU: 64 registers, 39.6 KiB."""
+    for k in ("decode_fast_kernel", "probe_kernelILi512", "decode_kernel", "spec_scan_kernel"):
+        rows = [r for n, r in shipped_table.items() if k in n]
+        assert rows, k
+        for r in rows:
+            assert r["allocated"] <= 64, (k, r)
+            assert r["lds"] <= 40960, (k, r)
+    assert all(r["allocated"] <= 64 for n, r in shipped_table.items() if "decode_sub_kernel" in n)
+    assert all(r["allocated"] <= 80 for n, r in shipped_table.items() if "pack_kernelILi256ELb1" in n)
+
+
 def test_the_seven_wave_pack_build_is_rejected_and_its_slack_build_accepted():
     """round 2's 'faster, and wrong' build: the 64-bit accumulator (-DPACK_ACC64), 72 of 72 VGPRs with code[5] in v71"""
     with pytest.raises(RuntimeError) as e:

@@ -52,6 +52,7 @@ namespace hufgpu {
 #ifndef DREG_TARGET_SYMS
 #define DREG_TARGET_SYMS (DREG_ITERS == 16 ? 40u : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
 #endif
+#define DREG_MAX_BLOCK (1u << 28)              /* symbols of a block this path takes: 12 x 2^28 payload bits are positions of 32 bits */
 #define DREG_SAFE_BITS (8u * DREG_ITERS)       /* a share of so many bits cannot hold more codewords than the registers take: none has fewer than 2 bits */
 
 typedef const __attribute__((address_space(3))) uint32_t *dreg_lds_words;
@@ -172,12 +173,12 @@ struct DregWords {
 };
 typedef uint32_t dreg_dwords4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ DregWords dreg_request(__amdgpu_buffer_rsrc_t rsrc, uint64_t seg0, uint64_t readable, uint32_t word0, bool wanted)
+__device__ __forceinline__ DregWords dreg_request(__amdgpu_buffer_rsrc_t rsrc, uint32_t seg0, uint32_t readable, uint32_t word0, bool wanted)
 {
     DregWords q;
-    const uint64_t first = (seg0 >> 3) + 4ull * word0;                 /* payload byte of the column's word 0 */
-    q.fast = wanted && first + 4ull * (DREG_ROWS + 1u) <= readable && first < 0xffffff00ull;
-    const uint32_t off = q.fast ? (uint32_t)first : 0xffffff00u;       /* (the resource begins at the aligned word that holds payload byte 0) */
+    const uint32_t first = (seg0 >> 3) + 4u * word0;                   /* payload byte of the column's word 0 (positions fit 32 bits: decode_payload_regs) */
+    q.fast = wanted && first + 4u * (DREG_ROWS + 1u) <= readable;
+    const uint32_t off = q.fast ? first : 0xffffff00u;       /* (the resource begins at the aligned word that holds payload byte 0) */
     const dreg_dwords4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     const dreg_dwords4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
     const dreg_dwords4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
@@ -188,7 +189,7 @@ __device__ __forceinline__ DregWords dreg_request(__amdgpu_buffer_rsrc_t rsrc, u
     return q;
 }
 
-__device__ __forceinline__ void dreg_commit(uint32_t *col, const DregWords &q, uint32_t sel, const uint8_t *pay, uint64_t seg0, uint64_t readable, uint32_t word0, bool wanted)
+__device__ __forceinline__ void dreg_commit(uint32_t *col, const DregWords &q, uint32_t sel, const uint8_t *pay, uint32_t seg0, uint32_t readable, uint32_t word0, bool wanted)
 {
     /* (word by word: twelve results held for one block of stores are twelve registers more at the kernel's fullest point) */
     if (q.fast) {
@@ -197,9 +198,9 @@ __device__ __forceinline__ void dreg_commit(uint32_t *col, const DregWords &q, u
     }
     if (__builtin_expect(__ballot(wanted && !q.fast) != 0ull, 0)) {
         if (wanted && !q.fast) {
-            const uint64_t first = (seg0 >> 3) + 4ull * word0;
+            const uint32_t first = (seg0 >> 3) + 4u * word0;
 #pragma unroll 1
-            for (uint32_t r = 0; r < DREG_ROWS; r++) col[64u * (DREG_ROWS - 1u - r)] = load_be32(pay, first + 4ull * r, readable);
+            for (uint32_t r = 0; r < DREG_ROWS; r++) col[64u * (DREG_ROWS - 1u - r)] = load_be32(pay, first + 4u * r, readable);
         }
     }
 }
@@ -261,28 +262,49 @@ __device__ __forceinline__ uint4 dreg_run_jump(uint32_t lut_addr, uint32_t lane4
 
 #define DREG_MAX_ROUNDS 64
 
-/* a segment: where it begins (bit seg0 of the payload, a multiple of 32; its first codeword at seg0 + first) and the bits of a share */
-struct DregSeg { uint64_t seg0; uint32_t sb, first; bool hinted; };
+/* block_excl_scan_u32 (util.hpp) without the barrier behind the reads: for partial words that nobody writes again before another
+ * barrier has passed (the segment's sums: the next segment's rounds lie in between; the probe's extra sum has words of its own). */
 template <int THREADS>
-__device__ __forceinline__ DregSeg dreg_plan(uint64_t ts, bool trust, uint32_t shrink, uint32_t cap, bool probing, uint64_t hint_bytes, uint64_t pay_bytes)
+__device__ __forceinline__ uint32_t dreg_excl_scan(uint32_t v, uint32_t *s_part, uint32_t &total)
+{
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane_id() == 63) s_part[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) {
+        const uint32_t x = s_part[i];
+        if (i < (int)(threadIdx.x >> 6)) base += x;
+        tot += x;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+/* a segment: where it begins (bit seg0 of the payload, a multiple of 32; its first codeword at seg0 + first) and the bits of a share */
+struct DregSeg { uint32_t seg0, sb, first; bool hinted; };
+template <int THREADS>
+__device__ __forceinline__ DregSeg dreg_plan(uint32_t ts, bool trust, uint32_t shrink, uint32_t cap, bool probing, uint32_t hint_bytes, uint32_t pay_bytes)
 {
     DregSeg g;
-    const uint64_t pay_bits = pay_bytes * 8ull;
-    g.seg0 = ts & ~31ull;
+    const uint32_t pay_bits = pay_bytes * 8u;
+    g.seg0 = ts & ~31u;
     g.first = (uint32_t)(ts - g.seg0);
     const uint32_t SUB = dmax<uint32_t>(cap >> shrink, 64u);
     uint32_t sb = SUB;
-    g.hinted = uni32((probing && trust && hint_bytes * 8ull > g.seg0 && hint_bytes <= pay_bytes) ? 1u : 0u) != 0u;
+    g.hinted = uni32((probing && trust && hint_bytes * 8u > g.seg0) ? 1u : 0u) != 0u;      /* (a hint beyond the payload is 0 here) */
     if ((!probing || g.hinted) && pay_bits > g.seg0) {
         /* equal shares of what is left (decode_fast.hpp: the block's last segment as full as the others) */
-        const uint64_t rem = (g.hinted ? hint_bytes * 8ull : pay_bits) - g.seg0;
-        if (rem < (1ull << 31)) {
-            /* (in floats: two integer divisions are some eighty vector instructions a segment, and nothing depends on the
-             *  quotients being exact - shares a bit off the even ones are shares all the same; the uniform-bytes case,
-             *  589 824 bits = 4 x 512 x 288, is exact in 24 bits) */
-            const float r = (float)(uint32_t)rem;
-            const float nseg = ceilf(r / (float)((uint32_t)THREADS * SUB));
-            const float even = ceilf(r / (nseg * (float)THREADS));
+        const uint32_t rem = (g.hinted ? hint_bytes * 8u : pay_bits) - g.seg0;
+        if (rem < (1u << 31)) {
+            /* (in floats, and by the reciprocal instruction: two integer divisions are some eighty vector instructions a segment, two
+             *  IEEE float divisions twenty, and nothing depends on the quotients being exact - shares a bit off the even ones are
+             *  shares all the same.  A quotient that IS a whole number must not be rounded up past it: the uniform-bytes case,
+             *  589 824 bits = 4 x 512 x 288, is four segments, not five of 231 bits - hence the factor just below one; the shares
+             *  themselves err upwards.) */
+            const float r = (float)rem;
+            const float nseg = ceilf(r * __builtin_amdgcn_rcpf((float)((uint32_t)THREADS * SUB)) * 0.99999f);
+            const float even = ceilf(r * __builtin_amdgcn_rcpf(nseg * (float)THREADS) * 1.000001f);     /* (never short: bits left over are a segment more) */
             /* (not below 192 bits while the registers allow: a speculative track needs a hundred bits or so to fall into step,
              *  and a short payload spread thin over all the lanes - 4 KiB: 60 bits a lane - is put right one lane a round) */
             sb = dmin<uint32_t>(dmax<uint32_t>((uint32_t)even, 192u), SUB);
@@ -300,9 +322,18 @@ __device__ __forceinline__ DregSeg dreg_plan(uint64_t ts, bool trust, uint32_t s
  * probe: pay_bytes = the rest of the stream) and wants to be told, hint_bytes = where it probably ends. */
 enum { DREG_NO_TABLES = 0, DREG_OK = 1, DREG_FAILED = 2 };
 template <int THREADS, class BuildTables>
-__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
-                                                   uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, BuildTables build_tables)
+__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes64, uint64_t readable64, uint64_t block_len64,
+                                                   uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes64, BuildTables build_tables)
 {
+    /* Positions in 32 bits (round 6b: the 64-bit ones were two scalar registers each in a kernel that has eighty, and what did
+     * not fit went through v_readlane - a vector instruction - every time it was needed): no code of this path is longer than
+     * 12 bits, so a block of up to 2^28 symbols ends within 12 x 2^28 < 2^32 bits of its payload's start and nothing behind
+     * that is anyone's business (the probe's "rest of the stream", an index entry with slack behind the block). */
+    if (block_len64 > DREG_MAX_BLOCK) return DREG_NO_TABLES;                     /* (uniform) */
+    const uint32_t block_len = (uint32_t)block_len64;
+    const uint32_t pay_bytes = (uint32_t)dmin<uint64_t>(pay_bytes64, (uint64_t)(block_len / 2u) * 3u + 16u);
+    const uint32_t readable = (uint32_t)dmin<uint64_t>(readable64, 0xfffffe00ull);
+    const uint32_t hint_bytes = hint_bytes64 <= (uint64_t)pay_bytes ? (uint32_t)hint_bytes64 : 0u;      /* (a hint beyond the payload is none) */
     constexpr int WAVES = THREADS / 64;
     static_assert(offsetof(DecShared<THREADS>, pay) % 256 == 0, "a row of a column is 256 bytes at a multiple of 256: its number is a bit field of an LDS address");
     static_assert((uint32_t)THREADS * DREG_ROWS <= DfastLds<THREADS>::AREA_WORDS, "the columns fit pay + marks");
@@ -314,19 +345,18 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     const uint32_t lane4 = 4u * (uint32_t)lane;
     const uint32_t r_top = 32u * ((slice_a >> 8) + DREG_ROWS - 1u);         /* R of the first bit of a column's word 0 */
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(dreg_lds_halves)sh.lut;
-    const uint64_t pay_bits = pay_bytes * 8ull;
+    const uint32_t pay_bits = pay_bytes * 8u;
     /* the payload through a buffer resource from the aligned word that holds its first byte to the end of what may be read */
     const uintptr_t pay_a = (uintptr_t)uni64((uint64_t)(uintptr_t)pay);
     const uint32_t mis = (uint32_t)(pay_a & 3u);
     const uint32_t sel = (mis << 24) | ((mis + 1u) << 16) | ((mis + 2u) << 8) | (mis + 3u);
-    const uint64_t span = readable + mis;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(pay_a - mis), (short)0, (int)(uint32_t)dmin<uint64_t>(span, 0xffffff00ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(pay_a - mis), (short)0, (int)(readable + mis), 0x00020000);
     /* shares cut for DREG_TARGET_SYMS symbols at the block's bits per symbol (the probe: at the hint's; without one, whole) */
     uint32_t cap = DREG_SUB_BITS;
     {
-        const uint64_t known = end_bits ? ((hint_bytes && hint_bytes <= pay_bytes) ? hint_bytes * 8ull : 0ull) : pay_bits;
-        if (known != 0ull && known < (1ull << 32)) {
-            const float est = (float)DREG_TARGET_SYMS * ((float)(uint32_t)known / (float)block_len);
+        const uint32_t known = end_bits ? hint_bytes * 8u : pay_bits;
+        if (known != 0u) {
+            const float est = (float)DREG_TARGET_SYMS * ((float)known / (float)block_len);
             cap = est >= (float)DREG_SUB_BITS ? DREG_SUB_BITS : dmax<uint32_t>((uint32_t)est, 64u);
         }
     }
@@ -334,12 +364,14 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     /* (plain functions of plain values, no closures: a closure over a dozen locals is an object the compiler keeps whole -
      *  sixteen registers in a row, spilled and reloaded as one) */
 #define DREG_PLAN(TS, TRUST, SHRINK) dreg_plan<THREADS>((TS), (TRUST), (SHRINK), cap, end_bits != nullptr, hint_bytes, pay_bytes)
-#define DREG_REL(G) (pay_bits > (G).seg0 ? (uint32_t)dmin<uint64_t>(pay_bits - (G).seg0, 0xfffffff0ull) : 0u)       /* payload bits from seg0 on */
+#define DREG_REL(G) (pay_bits > (G).seg0 ? pay_bits - (G).seg0 : 0u)       /* payload bits from seg0 on */
 #define DREG_WORD0(G) ((tid == 0 ? (G).first : (uint32_t)tid * (G).sb) >> 5)
 #define DREG_WANTED(G) ((uint32_t)tid * (G).sb < DREG_REL(G))
     uint32_t shrink = 0;                                               /* (uniform) halvings of the shares after a lane ran out of registers */
-    uint64_t true_start = 0, produced = 0;
+    uint32_t true_start = 0, produced = 0;
+    uint32_t seg0_last = 0;
     bool ok = true;
+    bool lanes_ok = true;                                              /* (per lane) every segment's lane_ok so far */
     bool trust = true;
     unsigned long long pt0 = DPROF_T();
     DregSeg g = DREG_PLAN(0, true, 0);
@@ -360,7 +392,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             dreg_commit(slice + lane, q2, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
         }
         have = false;
-        const uint64_t seg0 = g.seg0;
+        const uint32_t seg0 = g.seg0;
         const uint32_t sb = g.sb, first = g.first;
         const bool hinted = g.hinted;
         const uint32_t pay_rel = DREG_REL(g);
@@ -369,10 +401,10 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         const uint32_t rbase = r_top + 32u * (lo >> 5);               /* R = rbase - position */
         uint32_t start = lo;
         bool dead = hi - sb >= pay_rel;
-        const uint64_t remaining = block_len - produced;
+        const uint32_t remaining = block_len - produced;
         bool guessed = false;
         if (hinted) {
-            const uint32_t bound = (uint32_t)dmin<uint64_t>(hint_bytes * 8ull - seg0, 0xfffffff0ull);
+            const uint32_t bound = hint_bytes * 8u - seg0;
             if (!dead && hi - sb >= bound) dead = true;
             guessed = (uint32_t)(THREADS - 1) * sb >= bound;
         } else if (end_bits && trust && produced != 0) {
@@ -406,14 +438,14 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
                 /* (the probe without a hint) the speculative counts are right to a few symbols either way: a lane in front of
                  * which they already hold the rest of the block and a margin is taken for dead */
                 uint32_t spec_total;
-                const uint32_t exs = block_excl_scan_u32<THREADS>(cnt, sh.part, spec_total);
-                if (!dead && (uint64_t)exs >= remaining + 128u + ((uint32_t)tid >> 2)) {
+                const uint32_t exs = dreg_excl_scan<THREADS>(cnt, sh.wtile + 2 * WAVES, spec_total);
+                if (!dead && exs >= remaining + 128u + ((uint32_t)tid >> 2)) {
                     dead = true;
                     end = hi;
                     cnt = 0;
                     Phi = dreg_gap(rbase - lo);
                 }
-                guessed = guessed || (uint64_t)uni32(spec_total) >= remaining + 128u;
+                guessed = guessed || uni32(spec_total) >= remaining + 128u;
             }
             if (lane == 63) sh.wend[wave] = end;
             __syncthreads();
@@ -449,15 +481,15 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
          * and stores come back in the order they went out, and behind the stores the words would wait for every one of
          * them - and arrive under the sums */
         const uint32_t last_end = uni32(sh.wend[WAVES - 1]);
-        const uint64_t next_start = seg0 + last_end;
+        const uint32_t next_start = seg0 + last_end;
         const DregSeg gn = DREG_PLAN(next_start, true, shrink);
         /* (behind the payload's last byte there is no next segment: its lanes ask beyond the resource and nothing is fetched -
          *  one request in five was for the first kilobytes of the NEXT block, which that block's workgroup reads again) */
-        const bool more = uni32(next_start + 7ull < (gn.hinted ? hint_bytes * 8ull : pay_bits) ? 1u : 0u) != 0u;
+        const bool more = uni32(next_start + 7u < (gn.hinted ? hint_bytes * 8u : pay_bits) ? 1u : 0u) != 0u;
         const DregWords qn = dreg_request(rsrc, gn.seg0, readable, DREG_WORD0(gn), more && DREG_WANTED(gn));
         /* the counts' sum; above it the lanes whose true track ran out of registers (counts: at most 64 a lane, 2^15 a segment) */
         uint32_t seg_total;
-        const uint32_t ex = block_excl_scan_u32<THREADS>(cnt | ((uint32_t)(t.over && !dead) << 16), sh.part, seg_total) & 0xffffu;
+        const uint32_t ex = dreg_excl_scan<THREADS>(cnt | ((uint32_t)(t.over && !dead) << 16), sh.part, seg_total) & 0xffffu;
         seg_total = uni32(seg_total);
         if ((seg_total >> 16) != 0u) {                                 /* a share of more than 64 codewords: the segment again, shares of half the bits */
             DFAST_DBG(9, 1);
@@ -465,13 +497,13 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             continue;
         }
         if (guessed) DFAST_DBG(12, 1);
-        if (guessed && (uint64_t)seg_total < remaining) {             /* a guess that did not hold: the segment again, without */
+        if (guessed && seg_total < remaining) {             /* a guess that did not hold: the segment again, without */
             DFAST_DBG(13, 1);
             trust = false;
             continue;
         }
         trust = true;
-        const uint32_t take = (uint32_t)dmin<uint64_t>(seg_total, remaining);
+        const uint32_t take = dmin<uint32_t>(seg_total, remaining);
         uint32_t quota = 0;
         if (ex < take) {
             quota = take - ex;
@@ -503,10 +535,10 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         DPROF_ADD(8, pt); pt = DPROF_T();
         if (quota != 0u) {
             if (qe > pay_rel) lane_ok = false;                         /* a codeword of the block needs bits past the payload */
-            if (end_bits && ex + quota == take && (uint64_t)take == remaining) sh.qend = qe;
+            if (end_bits && ex + quota == take && take == remaining) sh.qend = qe;
             /* the registers: all of the lane's symbols and the whole last dword still inside this block's output, or
              * whole dwords and the rest byte by byte */
-            uint8_t *gp = gout + produced + ex;
+            uint8_t *gp = gout + (produced + ex);
             const bool whole = !partial && produced + ex + ((quota + 3u) & ~3u) <= block_len;
             const uint32_t nd = whole ? (quota + 3u) >> 2 : quota >> 2;
             typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
@@ -542,24 +574,28 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             }
         }
         DPROF_ADD(9, pt); pt = DPROF_T();
-        {
-            /* is every lane content?  (The waves' words lie behind the rounds': this barrier also ends the segment.) */
-            const uint32_t wave_bad = __ballot(!lane_ok) != 0ull ? 1u : 0u;
-            if (lane == 0) sh.wtile[WAVES + wave] = wave_bad;
-            __syncthreads();
-            uint32_t bad_any = 0;
-#pragma unroll
-            for (int i = 0; i < WAVES; i++) bad_any |= sh.wtile[WAVES + i];
-            if (uni32(bad_any) != 0u) { ok = false; DFAST_DBG(2, 1); break; }
-        }
-        DPROF_ADD(5, pt);
+        /* (is every lane content?  Asked once, behind the block's last segment - round 6b; until then a vote and a barrier a
+         *  segment, and a second barrier in the sums.  Neither is needed: the columns are their lanes' own, sh.wend was read for
+         *  the last time in front of the sums' barrier, the sums' partial words are written again only behind the next rounds'
+         *  barriers - the probe's extra sum in round 0 has words of its own for that reason.) */
+        lanes_ok = lanes_ok && lane_ok;
         DFAST_DBG(11, 1);
         produced += take;
         if (take == 0) { ok = false; DFAST_DBG(3, 1); break; }
-        if (end_bits && produced == block_len) *end_bits = seg0 + (uint64_t)uni32(sh.qend);
+        if (produced == block_len) seg0_last = seg0;
         true_start = next_start;
         g = gn;
     }
+    {
+        const uint32_t wave_bad = __ballot(!lanes_ok) != 0ull ? 1u : 0u;
+        if (lane == 0) sh.wtile[WAVES + wave] = wave_bad;
+        __syncthreads();                                               /* (also: sh.qend is everyone's) */
+        uint32_t bad_any = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) bad_any |= sh.wtile[WAVES + i];
+        if (uni32(bad_any) != 0u) { ok = false; DFAST_DBG(2, 1); }
+    }
+    if (ok && end_bits) *end_bits = (uint64_t)seg0_last + (uint64_t)uni32(sh.qend);
     return ok ? DREG_OK : DREG_FAILED;
 #undef DREG_PLAN
 #undef DREG_REL

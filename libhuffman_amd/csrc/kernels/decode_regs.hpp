@@ -267,18 +267,29 @@ __device__ __forceinline__ uint4 dreg_run_jump(uint32_t lut_addr, uint32_t lane4
 template <int THREADS>
 __device__ __forceinline__ uint32_t dreg_excl_scan(uint32_t v, uint32_t *s_part, uint32_t &total)
 {
+    constexpr int WAVES = THREADS / 64;
+    static_assert(WAVES == 8 || WAVES == 4, "the waves' words are summed by the first lanes of a row of sixteen");
+    const uint32_t wave = uni32(threadIdx.x >> 6);
     const uint32_t inc = wave_incl_scan_u32(v);
-    if (lane_id() == 63) s_part[threadIdx.x >> 6] = inc;
+    if (lane_id() == 63) s_part[wave] = inc;
     __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < THREADS / 64; i++) {
-        const uint32_t x = s_part[i];
-        if (i < (int)(threadIdx.x >> 6)) base += x;
-        tot += x;
-    }
-    total = tot;
+    /* (the waves' words summed by the lanes - lane j reads word j mod WAVES, three DPP steps, two v_readlane: eight words read by
+     *  every lane and added under eight comparisons of the wave's number were thirty instructions, half of them the comparisons'
+     *  masks coming back from where the compiler had put them) */
+    uint32_t x = s_part[lane_id() & (WAVES - 1)];
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+    if (WAVES == 8) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    /* row_shr:4 */
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, WAVES - 1);
+    const uint32_t base = wave != 0u ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wave - 1) : 0u;
     return base + inc - v;
+}
+
+/* do the waves' words (one a wave, written in front of the last barrier) hold anything but zeros? */
+template <int WAVES>
+__device__ __forceinline__ bool dreg_any_word(const uint32_t *words)
+{
+    return __ballot(words[lane_id() & (WAVES - 1)] != 0u) != 0ull;
 }
 
 /* a segment: where it begins (bit seg0 of the payload, a multiple of 32; its first codeword at seg0 + first) and the bits of a share */
@@ -466,12 +477,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             const uint32_t wave_needs = __ballot(need) != 0ull ? 1u : 0u;   /* (the vote of the whole wave: outside the lane's branch) */
             if (lane == 0) sh.wtile[wave] = wave_needs;
             __syncthreads();
-            {
-                uint32_t any = 0;
-#pragma unroll
-                for (int i = 0; i < WAVES; i++) any |= sh.wtile[i];
-                if (uni32(any) == 0u) break;
-            }
+            if (!dreg_any_word<WAVES>(sh.wtile)) break;
             DFAST_DBG(10, 1);
             if (++rounds > DREG_MAX_ROUNDS) { ok = false; DFAST_DBG(1, 1); break; }
         }
@@ -590,10 +596,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         const uint32_t wave_bad = __ballot(!lanes_ok) != 0ull ? 1u : 0u;
         if (lane == 0) sh.wtile[WAVES + wave] = wave_bad;
         __syncthreads();                                               /* (also: sh.qend is everyone's) */
-        uint32_t bad_any = 0;
-#pragma unroll
-        for (int i = 0; i < WAVES; i++) bad_any |= sh.wtile[WAVES + i];
-        if (uni32(bad_any) != 0u) { ok = false; DFAST_DBG(2, 1); }
+        if (dreg_any_word<WAVES>(sh.wtile + WAVES)) { ok = false; DFAST_DBG(2, 1); }
     }
     if (ok && end_bits) *end_bits = (uint64_t)seg0_last + (uint64_t)uni32(sh.qend);
     return ok ? DREG_OK : DREG_FAILED;

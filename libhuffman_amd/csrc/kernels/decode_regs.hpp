@@ -44,13 +44,18 @@ namespace hufgpu {
  * A share that holds more than 64 codewords (codes far shorter than the block's average) has the segment done again
  * with shares of half the bits; 128 bits cannot hold more than 64 codewords (no code of these trees has fewer than 2).
  * ==================================================================================== */
-#define DREG_ROWS 12u                          /* words of a lane's column: the word with its first bit, 288 bits, the last iteration's windows */
-#define DREG_SUB_BITS 288u
+#ifndef DREG_ROWS
+#define DREG_ROWS 15u                          /* words of a lane's column: up to 31 bits in front of the share, the share, the 48 bits the last iteration's
+                                                  other three codewords may take behind it (32 x rows >= 31 + share + 48 - 1) */
+#endif
+#define DREG_SUB_BITS (32u * DREG_ROWS - 96u)  /* 15 rows: 384 (round 6b; 12 rows and 288 bits until then: a 64 KiB block of zipf255 was four segments
+                                                  of 240 bits, now three of 320 - what a segment costs beside its passes a quarter less often, and the
+                                                  wave's slowest lane closer to its average one) */
 #ifndef DREG_ITERS
 #define DREG_ITERS 16                          /* iterations of four symbols a pass can take: 12 or 16 */
 #endif
 #ifndef DREG_TARGET_SYMS
-#define DREG_TARGET_SYMS (DREG_ITERS == 16 ? 40u : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
+#define DREG_TARGET_SYMS (DREG_ITERS == 16 ? (DREG_ROWS >= 15u ? 48u : 40u) : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
 #endif
 #define DREG_MAX_BLOCK (1u << 28)              /* symbols of a block this path takes: 12 x 2^28 payload bits are positions of 32 bits */
 #define DREG_SAFE_BITS (8u * DREG_ITERS)       /* a share of so many bits cannot hold more codewords than the registers take: none has fewer than 2 bits */
@@ -179,13 +184,19 @@ __device__ __forceinline__ DregWords dreg_request(__amdgpu_buffer_rsrc_t rsrc, u
     const uint32_t first = (seg0 >> 3) + 4u * word0;                   /* payload byte of the column's word 0 (positions fit 32 bits: decode_payload_regs) */
     q.fast = wanted && first + 4u * (DREG_ROWS + 1u) <= readable;
     const uint32_t off = q.fast ? first : 0xffffff00u;       /* (the resource begins at the aligned word that holds payload byte 0) */
+    static_assert(DREG_ROWS == 12u || DREG_ROWS == 15u, "thirteen or sixteen dwords");
     const dreg_dwords4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     const dreg_dwords4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
     const dreg_dwords4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
-    q.d[12] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 48u, 0, 0);
     q.d[0] = v0.x; q.d[1] = v0.y; q.d[2] = v0.z; q.d[3] = v0.w;
     q.d[4] = v1.x; q.d[5] = v1.y; q.d[6] = v1.z; q.d[7] = v1.w;
     q.d[8] = v2.x; q.d[9] = v2.y; q.d[10] = v2.z; q.d[11] = v2.w;
+#if DREG_ROWS == 15u
+    const dreg_dwords4 v3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48u, 0, 0);
+    q.d[12] = v3.x; q.d[13] = v3.y; q.d[14] = v3.z; q.d[15] = v3.w;
+#else
+    q.d[12] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 48u, 0, 0);
+#endif
     return q;
 }
 
@@ -215,7 +226,7 @@ __device__ __forceinline__ uint32_t dreg_run_at(uint32_t lut_addr, uint32_t lane
     if ((w >> 31) != 0u || L == 0u) return 0u;
     bool same = true;
 #pragma unroll 1
-    for (uint32_t k = 0; k < 10; k++) {
+    for (uint32_t k = 0; k < (DREG_SUB_BITS + 31u) / 32u + 1u; k++) {
         const uint32_t wn = dreg_bits_at(P0 - ((k + 1u) << 8), lane4);       /* (32 bits on: one row down) */
         const bool counts = pos + 32u * k < hi;
         if (counts && __builtin_amdgcn_alignbit(w, wn, 32u - L) != w) same = false;
@@ -292,10 +303,20 @@ __device__ __forceinline__ bool dreg_any_word(const uint32_t *words)
     return __ballot(words[lane_id() & (WAVES - 1)] != 0u) != 0ull;
 }
 
+/* ceil(n / d) for n < 2^31, d >= 1, a quotient below 2^18: v_rcp's estimate (off by a few units in the seventh digit) cut off and
+ * put right by two comparisons - uniform values, five instructions where the division proper takes forty */
+__device__ __forceinline__ uint32_t dreg_ceil_div(uint32_t n, uint32_t d)
+{
+    uint32_t q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d) * 0.999999f);
+    q += q * d < n ? 1u : 0u;
+    q += q * d < n ? 1u : 0u;
+    return q;
+}
+
 /* a segment: where it begins (bit seg0 of the payload, a multiple of 32; its first codeword at seg0 + first) and the bits of a share */
 struct DregSeg { uint32_t seg0, sb, first; bool hinted; };
 template <int THREADS>
-__device__ __forceinline__ DregSeg dreg_plan(uint32_t ts, bool trust, uint32_t shrink, uint32_t cap, bool probing, uint32_t hint_bytes, uint32_t pay_bytes)
+__device__ __forceinline__ DregSeg dreg_plan(uint32_t ts, bool trust, uint32_t shrink, uint32_t cap, uint32_t fixlen, bool probing, uint32_t hint_bytes, uint32_t pay_bytes)
 {
     DregSeg g;
     const uint32_t pay_bits = pay_bytes * 8u;
@@ -308,17 +329,16 @@ __device__ __forceinline__ DregSeg dreg_plan(uint32_t ts, bool trust, uint32_t s
         /* equal shares of what is left (decode_fast.hpp: the block's last segment as full as the others) */
         const uint32_t rem = (g.hinted ? hint_bytes * 8u : pay_bits) - g.seg0;
         if (rem < (1u << 31)) {
-            /* (in floats, and by the reciprocal instruction: two integer divisions are some eighty vector instructions a segment, two
-             *  IEEE float divisions twenty, and nothing depends on the quotients being exact - shares a bit off the even ones are
-             *  shares all the same.  A quotient that IS a whole number must not be rounded up past it: the uniform-bytes case,
-             *  589 824 bits = 4 x 512 x 288, is four segments, not five of 231 bits - hence the factor just below one; the shares
-             *  themselves err upwards.) */
-            const float r = (float)rem;
-            const float nseg = ceilf(r * __builtin_amdgcn_rcpf((float)((uint32_t)THREADS * SUB)) * 0.99999f);
-            const float even = ceilf(r * __builtin_amdgcn_rcpf(nseg * (float)THREADS) * 1.000001f);     /* (never short: bits left over are a segment more) */
+            /* (two integer divisions are some eighty vector instructions a segment: dreg_ceil_div.  Exact, because a quotient that
+             *  IS a whole number must stay one: uniform bytes, 589 824 bits = 4 x 512 x 288, are four segments of 288 bits - not
+             *  five of 231, and not four of 289 and a fifth for the crumbs) */
+            const uint32_t nseg = dreg_ceil_div(rem, (uint32_t)THREADS * SUB);
+            uint32_t even = dreg_ceil_div(rem, nseg * (uint32_t)THREADS);
+            /* (a block whose codes all have one length - decode_payload_regs: shares of whole codewords) */
+            if (fixlen != 0u) even = fixlen * dreg_ceil_div(even, fixlen);
             /* (not below 192 bits while the registers allow: a speculative track needs a hundred bits or so to fall into step,
              *  and a short payload spread thin over all the lanes - 4 KiB: 60 bits a lane - is put right one lane a round) */
-            sb = dmin<uint32_t>(dmax<uint32_t>((uint32_t)even, 192u), SUB);
+            sb = dmin<uint32_t>(dmax<uint32_t>(even, 192u), SUB);
         }
     }
     g.sb = uni32(sb);
@@ -347,7 +367,12 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     const uint32_t hint_bytes = hint_bytes64 <= (uint64_t)pay_bytes ? (uint32_t)hint_bytes64 : 0u;      /* (a hint beyond the payload is none) */
     constexpr int WAVES = THREADS / 64;
     static_assert(offsetof(DecShared<THREADS>, pay) % 256 == 0, "a row of a column is 256 bytes at a multiple of 256: its number is a bit field of an LDS address");
-    static_assert((uint32_t)THREADS * DREG_ROWS <= DfastLds<THREADS>::AREA_WORDS, "the columns fit pay + marks");
+    /* (the columns run on from pay + marks into ent and lr: the tree's entries are not this path's, and what the table build keeps
+     *  in lr - the leaves' codes - it is done with before the first column is written) */
+    static_assert((uint32_t)THREADS * DREG_ROWS * 4u <= sizeof(DecShared<THREADS>::pay) + sizeof(DecShared<THREADS>::mark) + sizeof(DecShared<THREADS>::ent) + sizeof(DecShared<THREADS>::lr),
+                  "the columns fit pay + marks + ent + lr");
+    static_assert(offsetof(DecShared<THREADS>, lr) == offsetof(DecShared<THREADS>, ent) + sizeof(DecShared<THREADS>::ent) &&
+                  offsetof(DecShared<THREADS>, ent) == offsetof(DecShared<THREADS>, mark) + sizeof(DecShared<THREADS>::mark), "one area");
     static_assert(sizeof(DecShared<THREADS>) <= 65536 - 256, "rows are numbered in eight bits");
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = (int)uni32((uint32_t)tid >> 6);
@@ -363,18 +388,29 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     const uint32_t sel = (mis << 24) | ((mis + 1u) << 16) | ((mis + 2u) << 8) | (mis + 3u);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(pay_a - mis), (short)0, (int)(readable + mis), 0x00020000);
     /* shares cut for DREG_TARGET_SYMS symbols at the block's bits per symbol (the probe: at the hint's; without one, whole) */
-    uint32_t cap = DREG_SUB_BITS;
+    uint32_t cap = DREG_SUB_BITS, fixlen = 0;
     {
         const uint32_t known = end_bits ? hint_bytes * 8u : pay_bits;
         if (known != 0u) {
-            const float est = (float)DREG_TARGET_SYMS * ((float)known / (float)block_len);
+            const float per_sym = (float)known / (float)block_len;
+            const float est = (float)DREG_TARGET_SYMS * per_sym;
             cap = est >= (float)DREG_SUB_BITS ? DREG_SUB_BITS : dmax<uint32_t>((uint32_t)est, 64u);
+            /* Incompressible bytes: every code 9 bits (8 and the root's 0), the payload block_len x 9 bits and a byte's padding.
+             * Shares of whole codewords then - a lane's own first bit IS a codeword's and the speculative pass the only one,
+             * where codes of one length never fall into step by themselves (1 GiB of uniform bytes: 0.78 ms against 1.06 with
+             * shares of 384 bits).  A block that only looks like it loses nothing. */
+            const uint32_t L = (uint32_t)(per_sym + 0.001f);
+            if (L >= 2u && L <= DEC_LUT_BITS && known - L * block_len < 8u) {
+                fixlen = L;
+                cap = L * (uint32_t)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)L));
+            }
         }
     }
     cap = uni32(cap);
+    fixlen = uni32(fixlen);
     /* (plain functions of plain values, no closures: a closure over a dozen locals is an object the compiler keeps whole -
      *  sixteen registers in a row, spilled and reloaded as one) */
-#define DREG_PLAN(TS, TRUST, SHRINK) dreg_plan<THREADS>((TS), (TRUST), (SHRINK), cap, end_bits != nullptr, hint_bytes, pay_bytes)
+#define DREG_PLAN(TS, TRUST, SHRINK) dreg_plan<THREADS>((TS), (TRUST), (SHRINK), cap, fixlen, end_bits != nullptr, hint_bytes, pay_bytes)
 #define DREG_REL(G) (pay_bits > (G).seg0 ? pay_bits - (G).seg0 : 0u)       /* payload bits from seg0 on */
 #define DREG_WORD0(G) ((tid == 0 ? (G).first : (uint32_t)tid * (G).sb) >> 5)
 #define DREG_WANTED(G) ((uint32_t)tid * (G).sb < DREG_REL(G))

@@ -187,6 +187,8 @@ struct DecShared {
     uint32_t badsym;                     /* segment symbol index of the first walk that left the tree */
     uint32_t firstone;                   /* single-leaf trees: first set payload bit */
     uint32_t qend;                       /* segment bit right after the block's last symbol */
+    uint32_t leaves[320];                /* decode_regs.hpp: the leaves' codes in preorder (256 words) and their bytes (64), kept for the block's codes
+                                            beyond the table (the struct with them: 40 880 of the 40 960 bytes a workgroup has at four a CU) */
 };
 
 /* big-endian 32-bit word of payload bytes [off, off+4), zero beyond nbytes */

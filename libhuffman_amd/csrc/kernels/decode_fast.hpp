@@ -60,8 +60,11 @@ namespace hufgpu {
 #ifndef DFAST_PAIRS_FROM
 #define DFAST_PAIRS_FROM 32768u                      /* symbols of a block from which its scans read the table of pairs (dfast_pair_table) */
 #endif
+#define DREG_E_LONG 0u                                /* decode_regs.hpp's table: twelve bits that are the beginning of a longer code (a length of 0) */
 #ifndef DREG_MIN_BLOCK
-#define DREG_MIN_BLOCK 32768u                        /* symbols of a block from which decode_regs.hpp's path takes it (below: the tables' chain of leaves is most of a block's time) */
+#define DREG_MIN_BLOCK 8192u                         /* symbols of a block from which decode_regs.hpp's path takes it.  (32 768 until round 6b: smaller blocks have codes
+                                                        beyond 12 bits, which the path then declined - with the tables built twice for it.  Now, zipf255 with the block
+                                                        index alone: 16 KiB blocks 3.15 -> 2.46 ms per GiB, 8 KiB blocks 5.74 -> 4.99; a 16 KiB huf_decode 81 -> 73 us.) */
 #endif
 #ifndef DFAST_JUMP_FROM_ROUND
 #define DFAST_JUMP_FROM_ROUND 1                      /* the round loop's pass from which runs of one byte value are looked for (dfast_run_jump) */
@@ -869,10 +872,23 @@ __device__ __forceinline__ bool decode_payload_dfast(DecShared<THREADS> &sh, con
  * is to be used then, the caller walks the tree - for any other shape of tree and for blocks with codes of more than
  * DEC_LUT_BITS bits (their `long` entries need the child links only the walk builds).
  * ==================================================================================== */
+/* where decode_regs.hpp's table build keeps the leaves in preorder: codes (left-aligned) and bytes in sh.leaves - they stay, behind
+ * everything the columns overwrite (pay, marks, ent and most of lr), for the block's codes beyond the table's 12 bits
+ * (dreg_long_entry); the lengths, which only the build needs, where FastLdsOf has them. */
+template <class SH>
+struct DregLeafLdsOf {
+    static_assert(sizeof(SH::leaves) >= 320u * 4u && sizeof(SH) <= 40960u, "the leaves fit, and four workgroups a CU");
+    __device__ static __forceinline__ uint32_t *code(SH &sh) { return sh.leaves; }
+    __device__ static __forceinline__ uint8_t *len(SH &sh) { return reinterpret_cast<uint8_t *>(sh.lr + 256); }
+    __device__ static __forceinline__ uint8_t *sym(SH &sh) { return reinterpret_cast<uint8_t *>(sh.leaves + 256); }
+};
+template <class SH, bool REGS> struct DfastLeafLds : FastLdsOf<SH> {};
+template <class SH> struct DfastLeafLds<SH, true> : DregLeafLdsOf<SH> {};
+
 template <int THREADS, bool SPEC, bool REGS = false>
 __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tree, int tree_len)
 {
-    typedef DsubFastLds<THREADS> F;
+    typedef DfastLeafLds<DecShared<THREADS>, REGS> F;
     constexpr int WAVES = THREADS / 64;
     static_assert(THREADS * 2 >= HUF_TREE_MAX - 1 && THREADS >= 256 && WAVES <= 8, "two entries per thread");
     const int tid = (int)threadIdx.x;
@@ -1013,14 +1029,17 @@ __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tr
             if (dn + t < d || (uint32_t)s_pos[k + 1] != pos + 3u + (dn + t - d)) ok = false;
         } else if (pos + 4u != (uint32_t)tree_len) ok = false;
     }
-    if (anylong) ok = false;                                                    /* (uniform: codes beyond the table take the walk's child links) */
+    if (anylong && !REGS) ok = false;                                           /* (uniform: codes beyond the table take the walk's child links; decode_regs.hpp
+                                                                                    finds such a code among the leaves kept here: sh.l2n, sh.fastk) */
+    if (REGS && tid == 0) { sh.l2n = anylong ? 1u : 0u; sh.fastk = K; }
     if (!__syncthreads_and(ok ? 1 : 0)) return false;
     if constexpr (REGS) {
         /* Round 6, decode_regs.hpp's table: decode_sub's entry format (byte << 8 | length) over the 12 bits at a position.  A
-         * first bit of 0: a leaf - every node below the root's only child has two children and no code is longer than the
-         * table.  A first bit of 1 leaves the tree: length = the run of ones (at most 12), byte 0 - on a speculative track
-         * that is what puts it into step (tracks in a run of ones all land on the 0 behind it), on the block's true track the
-         * first bits are checked (decode_regs.hpp). */
+         * first bit of 0: a leaf - every node below the root's only child has two children -, or DREG_E_LONG when the twelve
+         * bits are not a whole code: a length of 0, to the pass "stand still" (round 6b; until then blocks with such codes
+         * were not this path's).  A first bit of 1 leaves the tree: length = the run of ones (at most 12),
+         * byte 0 - on a speculative track that is what puts it into step (tracks in a run of ones all land on the 0 behind
+         * it), on the block's true track the first bits are checked (decode_regs.hpp). */
         static_assert((1 << DEC_LUT_BITS) == THREADS * 8, "eight entries per thread");
         const uint32_t *code = F::code(sh);
         const uint32_t x0 = (uint32_t)tid * 8u;
@@ -1031,7 +1050,8 @@ __device__ bool dfast_tables_from_tree(DecShared<THREADS> &sh, const uint8_t *tr
             for (uint32_t j = 0; j < 8; j++) {
                 const uint32_t v = (x0 + j) << (32 - DEC_LUT_BITS);
                 while (k + 1u < K && code[k + 1u] <= v) k++;
-                e[j] = ((uint32_t)F::sym(sh)[k] << 8) | (uint32_t)F::len(sh)[k];
+                const uint32_t lk = (uint32_t)F::len(sh)[k];
+                e[j] = lk > (uint32_t)DEC_LUT_BITS ? DREG_E_LONG : ((uint32_t)F::sym(sh)[k] << 8) | lk;
             }
         } else {
 #pragma unroll
@@ -1127,7 +1147,7 @@ __device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64
 #ifndef DFAST_NO_REGS
     if (leaf < 0 && m.block_len >= DREG_MIN_BLOCK)
         regs = decode_payload_regs<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase, nullptr, 0,
-                                            [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len); });
+                                            [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len) ? (uni32(sh.l2n) != 0u ? 2 : 1) : 0; });
     if (leaf < 0 && regs == 0)
         rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
 #else

@@ -57,7 +57,7 @@ namespace hufgpu {
 #ifndef DREG_TARGET_SYMS
 #define DREG_TARGET_SYMS (DREG_ITERS == 16 ? (DREG_ROWS >= 15u ? 48u : 40u) : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
 #endif
-#define DREG_MAX_BLOCK (1u << 28)              /* symbols of a block this path takes: 12 x 2^28 payload bits are positions of 32 bits */
+#define DREG_MAX_BLOCK (1u << 26)              /* symbols of a block this path takes: 32 x 2^26 payload bits are positions of 32 bits */
 #define DREG_SAFE_BITS (8u * DREG_ITERS)       /* a share of so many bits cannot hold more codewords than the registers take: none has fewer than 2 bits */
 
 typedef const __attribute__((address_space(3))) uint32_t *dreg_lds_words;
@@ -80,6 +80,68 @@ __device__ __forceinline__ uint32_t dreg_entry(uint32_t lut_addr, uint32_t d)
     return *(dreg_lds_halves)(uintptr_t)(lut_addr + ((d >> 19) & 0x1ffeu));
 }
 
+/* Codes beyond the table's twelve bits (round 6b).  Their table entry is DREG_E_LONG = 0: a length of 0 - a lane that meets one
+ * stands still, every further look-up of its iteration is the same entry (the window is shifted by 0), and the iteration's
+ * LAST length byte says so: no other entry has a length of 0.  The pass then decodes what the lane is short of one codeword at a
+ * time (dreg_repair), the long ones by a binary search over the leaves' codes which dfast_tables_from_tree left in sh.leaves
+ * (the walk's child links are not built) - a byte seen once in 5 000 costs a wave some hundred instructions in every third
+ * pass.  Blocks without such codes run a pass that does not ask (dreg_pass<false>). */
+typedef const __attribute__((address_space(3))) uint8_t *dreg_lds_bytes;
+struct DregLeaves {
+    uint32_t code_a;            /* LDS address of [K] the leaves' codes in preorder = ascending, left-aligned in 32 bits; leaf k's length (2 .. 32)
+                                   from the distance to the next code: the codes of a full tree lie 2^(32 - length) apart, the last one ends
+                                   at 2^31 (every code begins with the root's 0) */
+    uint32_t sym_a;             /* LDS address of [K] their bytes */
+    uint32_t K;
+    bool any;                   /* (uniform) the block has codes beyond the table */
+};
+/* byte << 8 | length of the codeword whose (first) 32 bits are d */
+__device__ __forceinline__ uint32_t dreg_long_entry(uint32_t code_a, uint32_t sym_a, uint32_t K, uint32_t d)
+{
+    dreg_lds_words code = (dreg_lds_words)(uintptr_t)code_a;
+    uint32_t lo = 0, hi = K;                             /* largest k < K with code[k] <= d (code[0] = 0): dsub_leaf_of on LDS addresses */
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) {                     /* K <= 256 */
+        const uint32_t mid = (lo + hi) >> 1;
+        if (hi - lo > 1u) {
+            if (code[mid] <= d) lo = mid; else hi = mid;
+        }
+    }
+    const uint32_t next = lo + 1u < K ? code[lo + 1u] : 0x80000000u;
+    const uint32_t byte = ((dreg_lds_bytes)(uintptr_t)sym_a)[lo];
+    return (byte << 8) | ((uint32_t)__clz((int)(next - code[lo])) + 1u);
+}
+/* An iteration in which a lane (`hit`) met a long code: its first codewords stand - their bytes in S, their lengths in L4 - and P
+ * stands at the long one; the rest of its four one by one.  Called under the iteration's EXEC (the wave's active lanes).  Loops,
+ * not unrolled: there are sixteen copies of this in a pass.  (Out of line - one copy - it cost more than it saved: the sixteen
+ * registers of symbols around a call are sixteen registers saved and restored, zipf255 1.01 -> 1.33 ms with it.) */
+__device__ __forceinline__ void dreg_repair(uint32_t lut_addr, uint32_t lane4, const DregLeaves &lv, bool hit, uint32_t &P, uint32_t &S, uint32_t &L4, uint32_t &firsts)
+{
+    /* (lengths that stand are not 0: bit 7 of a byte of nz says "not zero") */
+    const uint32_t nz = (((L4 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | L4) & 0x80808080u;
+    const uint32_t nv = hit ? (uint32_t)__builtin_popcount(nz) : 4u;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; j++) {
+        const bool go = j >= nv;
+        if (__any(go)) {
+            const uint32_t d = dreg_bits_at(P, lane4);
+            uint32_t e = dreg_entry(lut_addr, d);
+            const bool lg = go && (e & 0xffu) == 0u;
+            if (__any(lg)) {
+                const uint32_t e2 = dreg_long_entry(lv.code_a, lv.sym_a, lv.K, d);
+                e = lg ? e2 : e;
+            }
+            if (go) {
+                const uint32_t len = e & 0xffu;                        /* (at most 32: one borrow) */
+                firsts |= d;
+                S = (S & ~(0xffu << (8u * j))) | ((e >> 8) << (8u * j));
+                L4 = (L4 & ~(0xffu << (8u * j))) | (len << (8u * j));
+                P = (P - len) & 0xff1fu;
+            }
+        }
+    }
+}
+
 /* what a pass leaves in a lane besides the sixteen registers */
 struct DregTrack {
     uint32_t Rend;       /* (as R, not gapped) the first codeword start at or behind the share's end (the start, for a lane that holds nothing) */
@@ -93,7 +155,8 @@ struct DregTrack {
 /* (the sixteen registers are sixteen variables, DregSyms' members: an array of them the compiler turns into ONE value of sixteen
  *  registers in a row, moved, spilled and reloaded whole) */
 struct DregSyms { uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15; };
-__device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uint32_t Pstart, uint32_t Phi, DregSyms &sym, DregTrack &t)
+template <bool LONG>
+__device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, const DregLeaves &lv, uint32_t Rfloor, uint32_t Pstart, uint32_t Phi, DregSyms &sym, DregTrack &t)
 {
     uint32_t P = Pstart, ng = 0, firsts = 0, L4 = 0;
 #define DREG_WINDOW(PAIR)                                                                                      \
@@ -122,6 +185,10 @@ __device__ __forceinline__ void dreg_pass(uint32_t lut_addr, uint32_t lane4, uin
             S = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                                 \
             L4 = __builtin_amdgcn_perm(p23, p01, 0x07060302u);     /* lengths 1 .. 4 */                       \
             ng = (K);                            /* (positions only grow: the active iterations are the first ng) */ \
+            if (LONG) {                                                                                       \
+                const bool hit_ = p23 < 0x01000000u; /* the iteration's last look-up was DREG_E_LONG */        \
+                if (__builtin_expect(__any(hit_), 0)) dreg_repair(lut_addr, lane4, lv, hit_, P, S, L4, firsts); \
+            }                                                                                                 \
         }                                                                                                     \
     }
     DREG_ITER(sym.s0, 1u) DREG_ITER(sym.s1, 2u) DREG_ITER(sym.s2, 3u) DREG_ITER(sym.s3, 4u)
@@ -135,6 +202,12 @@ done:
 #undef DREG_WINDOW
     t.over = P > Phi;
     t.bad = (firsts >> 31) != 0u;
+    /* (a long code in the last iteration can carry it past the column's last row - three more codewords of up to 32 bits where
+     *  the rows allow for 48 bits: what was looked up there is not the payload's, and the lane's last dword, whose bytes behind its
+     *  own symbols go to the right neighbour's place, must not be stored.  Such a lane ran out of rows as another runs out of
+     *  registers: the segment again, with shares of half the bits.  Every codeword that ENDS inside the column was decoded from
+     *  its own bits alone - no code is the beginning of another.) */
+    if (LONG && dreg_ungap(P) < Rfloor) t.over = true;
     /* the last iteration's codewords began at R1 + length 1, R1, R2, R3 and it ended at R4 = where the lane stands: from the
      * four lengths, no look-up (until round 6b the iteration was looked up again: four dependent table reads a pass) */
     const uint32_t RPhi = dreg_ungap(Phi);
@@ -147,16 +220,23 @@ done:
 
 /* the position behind the first n codewords from Pfrom; *first_bits |= their first bits (bit 31).  (One lane a block: the
  * one that holds the block's last symbol and codewords behind it.) */
-__device__ __forceinline__ uint32_t dreg_walk(uint32_t lut_addr, uint32_t lane4, uint32_t Pfrom, uint32_t n, uint32_t *first_bits)
+__device__ __forceinline__ uint32_t dreg_walk(uint32_t lut_addr, uint32_t lane4, const DregLeaves &lv, uint32_t Pfrom, uint32_t n, uint32_t *first_bits)
 {
     uint32_t P = Pfrom, f = 0;
 #pragma unroll 1
     while (__any(n != 0u)) {
         const uint32_t d = dreg_bits_at(P, lane4);
-        const uint32_t e = dreg_entry(lut_addr, d);
+        uint32_t e = dreg_entry(lut_addr, d);
+        if (lv.any) {
+            const bool lg = n != 0u && (e & 0xffu) == 0u;
+            if (__any(lg)) {
+                const uint32_t e2 = dreg_long_entry(lv.code_a, lv.sym_a, lv.K, d);
+                e = lg ? e2 : e;
+            }
+        }
         if (n != 0u) {
             f |= d;
-            P = (P - (e & 31u)) & 0xff1fu;
+            P = (P - (e & 0xffu)) & 0xff1fu;
             n--;
         }
     }
@@ -351,18 +431,18 @@ __device__ __forceinline__ DregSeg dreg_plan(uint32_t ts, bool trust, uint32_t s
  * symbols were written and everything the in-order decoder would have checked held, DREG_FAILED otherwise.  Arguments as
  * decode_payload_fast_impl (decode_fast.hpp): end_bits = the caller does not know where the payload ends (the raw-stream
  * probe: pay_bytes = the rest of the stream) and wants to be told, hint_bytes = where it probably ends. */
-enum { DREG_NO_TABLES = 0, DREG_OK = 1, DREG_FAILED = 2 };
-template <int THREADS, class BuildTables>
-__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes64, uint64_t readable64, uint64_t block_len64,
+enum { DREG_NO_TABLES = 0, DREG_OK = 1, DREG_FAILED = 2, DREG_LONG = 3 };
+template <int THREADS, bool LONG, class BuildTables>
+__device__ __forceinline__ int decode_payload_regs_as(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes64, uint64_t readable64, uint64_t block_len64,
                                                    uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes64, BuildTables build_tables)
 {
     /* Positions in 32 bits (round 6b: the 64-bit ones were two scalar registers each in a kernel that has eighty, and what did
      * not fit went through v_readlane - a vector instruction - every time it was needed): no code of this path is longer than
-     * 12 bits, so a block of up to 2^28 symbols ends within 12 x 2^28 < 2^32 bits of its payload's start and nothing behind
-     * that is anyone's business (the probe's "rest of the stream", an index entry with slack behind the block). */
+     * 32 bits, so a block of up to 2^26 symbols ends within 2^31 bits of its payload's start and nothing behind that is
+     * anyone's business (the probe's "rest of the stream", an index entry with slack behind the block). */
     if (block_len64 > DREG_MAX_BLOCK) return DREG_NO_TABLES;                     /* (uniform) */
     const uint32_t block_len = (uint32_t)block_len64;
-    const uint32_t pay_bytes = (uint32_t)dmin<uint64_t>(pay_bytes64, (uint64_t)(block_len / 2u) * 3u + 16u);
+    const uint32_t pay_bytes = (uint32_t)dmin<uint64_t>(pay_bytes64, (uint64_t)block_len * 4u + 16u);
     const uint32_t readable = (uint32_t)dmin<uint64_t>(readable64, 0xfffffe00ull);
     const uint32_t hint_bytes = hint_bytes64 <= (uint64_t)pay_bytes ? (uint32_t)hint_bytes64 : 0u;      /* (a hint beyond the payload is none) */
     constexpr int WAVES = THREADS / 64;
@@ -394,6 +474,11 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         if (known != 0u) {
             const float per_sym = (float)known / (float)block_len;
             const float est = (float)DREG_TARGET_SYMS * per_sym;
+            /* (a block of fewer than four bits a symbol is not this path's: the sixteen registers hold its shares down to a
+             *  hundred bits and less, in which a speculative track does not fall into step - the rounds then put the lanes right
+             *  one at a time.  Geometric bytes, two bits a symbol, 1 MiB blocks: 2.8 ms here, 2.4 with decode_fast.hpp's scans,
+             *  which count a share of 288 bits whatever it holds.) */
+            if (est < 192.0f) return DREG_NO_TABLES;
             cap = est >= (float)DREG_SUB_BITS ? DREG_SUB_BITS : dmax<uint32_t>((uint32_t)est, 64u);
             /* Incompressible bytes: every code 9 bits (8 and the root's 0), the payload block_len x 9 bits and a byte's padding.
              * Shares of whole codewords then - a lane's own first bit IS a codeword's and the speculative pass the only one,
@@ -424,7 +509,18 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
     DregSeg g = DREG_PLAN(0, true, 0);
     const DregWords q = dreg_request(rsrc, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
     DPROF_ADD(10, pt0); pt0 = DPROF_T();
-    if (!build_tables()) return DREG_NO_TABLES;
+    {
+        const int built = build_tables();                              /* (uniform) 0: declined, 1: the table stands, 2: and the block has codes beyond it */
+        if (built == 0) return DREG_NO_TABLES;
+        if (!LONG && built == 2) return DREG_LONG;                     /* nothing was decoded; the table stands */
+    }
+    typedef DregLeafLdsOf<DecShared<THREADS>> LF;
+    DregLeaves lv;
+    lv.code_a = (uint32_t)(uintptr_t)(dreg_lds_words)LF::code(sh);
+    lv.sym_a = (uint32_t)(uintptr_t)(dreg_lds_bytes)LF::sym(sh);
+    lv.K = uni32(sh.fastk);
+    lv.any = LONG;
+    const uint32_t Rfloor = r_top - 32u * (DREG_ROWS - 1u) - 32u;      /* R behind the column's last bit */
     DPROF_ADD(11, pt0); pt0 = DPROF_T();
     dreg_commit(slice + lane, q, sel, pay, g.seg0, readable, DREG_WORD0(g), DREG_WANTED(g));
     DPROF_ADD(12, pt0);
@@ -474,7 +570,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
             if (__ballot(need)) {
                 DFAST_DBGW(8, 1);
                 DFAST_DBGW(rounds == 0 ? 6 : rounds == 1 ? 7 : 14, 1);
-                dreg_pass(lut_addr, lane4, dreg_gap(rbase - (dead ? lo : start)), Phi, sym, t);
+                dreg_pass<LONG>(lut_addr, lane4, lv, Rfloor, dreg_gap(rbase - (dead ? lo : start)), Phi, sym, t);
                 /* (a track of more than 64 look-ups - a speculative one through entries that leave the tree, bit by bit; or,
                  *  when the rounds are over, the lane's true one - ends where the share does for now: its neighbour is not
                  *  sent in front of its own column) */
@@ -535,6 +631,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         seg_total = uni32(seg_total);
         if ((seg_total >> 16) != 0u) {                                 /* a share of more than 64 codewords: the segment again, shares of half the bits */
             DFAST_DBG(9, 1);
+            if ((cap >> shrink) <= 64u) { ok = false; break; }         /* (shares of 64 bits hold what a lane can take: this is not a payload of this tree - the exact decoder says what it is) */
             shrink++;
             continue;
         }
@@ -561,7 +658,7 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
         const bool again = quota != 0u && (partial || t.bad);
         if (__ballot(again)) {
             uint32_t fb = 0;
-            const uint32_t Pq = dreg_walk(lut_addr, lane4, dreg_gap(rbase - start), again ? quota : 0u, &fb);
+            const uint32_t Pq = dreg_walk(lut_addr, lane4, lv, dreg_gap(rbase - start), again ? quota : 0u, &fb);
             if (again) {
                 qe = rbase - dreg_ungap(Pq);
                 lane_ok = (fb >> 31) == 0u;
@@ -642,6 +739,19 @@ __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const
 #undef DREG_WANTED
 }
 
+/* A block's payload: by the pass that does not ask for codes beyond the table, and - when the table build says the block has some -
+ * by the one that does (two instances of everything above: one pass with the question in it was 3 % slower on blocks that have
+ * none, two passes chosen from inside the round loop 30 % - the sixteen registers came out of the choice as copies).
+ * build_tables() -> 0: declined, 1: the table stands, 2: and the block has codes beyond it. */
+template <int THREADS, class BuildTables>
+__device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
+                                                   uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, BuildTables build_tables)
+{
+    int r = decode_payload_regs_as<THREADS, false>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, build_tables);
+    if (r == DREG_LONG) r = decode_payload_regs_as<THREADS, true>(sh, pay, pay_bytes, readable, block_len, gout, end_bits, hint_bytes, []() { return 2; });
+    return r;
+}
+
 /* The in-order chain of decode.hpp (decode_chain_kernel: the block loop of src/decoder.c:218-276, one workgroup) with the
  * lean decoder in front of the exact one: a block with an encoder-shaped tree goes through decode_payload_regs first - told
  * where the stream ends as a hint at where its payload does, which is right for the stream of one block that a small call
@@ -685,7 +795,7 @@ __global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_
              *  declines them: decode_fast.hpp's lean decoder walks such codes, with the tables of the tree's walk) */
             const int lean = block_len < DREG_MIN_BLOCK ? DREG_NO_TABLES :
                 decode_payload_regs<THREADS>(sh, stream + rd, avail - rd, avail - rd, block_len, out + wr, &end_bits, hint,
-                                             [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, tl); });
+                                             [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, tl) ? (uni32(sh.l2n) != 0u ? 2 : 1) : 0; });
             bool done = lean == DREG_OK;
             if (lean == DREG_NO_TABLES) {
                 int leaf = -1;

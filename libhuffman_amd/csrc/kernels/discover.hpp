@@ -383,7 +383,7 @@ __global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void probe_kernel(cons
 #ifndef DFAST_NO_REGS
         const int shaped = !(block_len >= DREG_MIN_BLOCK && tl <= HUF_TREE_MAX) ? 0 :
             decode_payload_regs<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint,
-                                         [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, stream + c + HUF_HEADER_FIXED, tl); });
+                                         [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, stream + c + HUF_HEADER_FIXED, tl) ? (uni32(sh.l2n) != 0u ? 2 : 1) : 0; });
         if (shaped != 0 ? shaped == 1 /* DREG_OK */
                         : (dec_build_tables<THREADS, true>(sh, stream + c + HUF_HEADER_FIXED, tl, &leaf) == HUFE_OK && leaf < 0 &&
                            decode_payload_dfast<THREADS>(sh, stream + pay0, avail - pay0, avail - pay0, block_len, out + uni64(spec_off[blockIdx.x]), &end_bits, hint))) {

@@ -1033,3 +1033,45 @@ def test_many_blocks_of_deep_codes(torch_mod, codec, oracle, top):
             pytest.fail(f"launch {rep}: {len(bad)} blocks differ from the oracle, first {bad[:8]}")
     out = torch.zeros(nb * bs, dtype=torch.uint8, device="cuda")
     assert codec.decode(stream, length, offs, nb, out) == nb * bs and torch.equal(out, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [32768, 65536, 262144])
+def test_codes_beyond_the_table_with_the_block_index_alone(torch_mod, codec, oracle, bs):
+    """round 6b: decode_regs.hpp takes blocks whose trees have codes of more than 12 bits (its table marks the twelve bits,
+    the pass decodes the lane's iteration again codeword by codeword, the long one by a search over the leaves' codes).
+    Rare bytes in skewed data, a geometric distribution (a long code every few hundred symbols), Fibonacci weights (codes up
+    to 22 bits, one lane's last iteration can run far behind its share): encoded by the oracle, decoded with the block index
+    alone and as a raw stream, both against the input."""
+    torch = torch_mod
+    rng = np.random.default_rng(bs)
+    n = 6 * bs + 777
+    sets = []
+    z = rng.zipf(1.3, size=n)
+    a = (z % 200).astype(np.uint8)
+    rare = rng.integers(0, n, size=3 * 56)
+    a[rare] = np.repeat(np.arange(200, 256, dtype=np.uint8), 3)             # 56 bytes seen three times each
+    sets.append(("zipf + rare bytes", a))
+    w = 0.5 ** np.arange(1, 21)
+    sets.append(("geometric over 20 bytes", rng.choice(20, size=n, p=w / w.sum()).astype(np.uint8)))
+    f, parts, total, sym = [1, 1], [], 0, 0
+    while total + f[-2] <= n and sym < 250:
+        parts.append(np.full(f[-2], sym, np.uint8)); total += f[-2]; f.append(f[-1] + f[-2]); sym += 1
+    fib = np.concatenate(parts + [np.full(n - total, sym - 1, np.uint8)])
+    rng.shuffle(fib)
+    sets.append(("fibonacci weights", fib))
+    text = np.frombuffer((b"GET /index.html HTTP/1.1 200 1234 \"Mozilla/5.0\" " * (n // 48 + 1))[:n], dtype=np.uint8).copy()
+    text[rng.integers(0, n, size=40)] = rng.integers(128, 256, size=40).astype(np.uint8)
+    sets.append(("text with stray bytes", text))
+    for name, data in sets:
+        want = oracle.encode(data, bs)
+        out, offs = gpu_encode(torch, codec, data, bs)
+        assert np.array_equal(out, want), (name, first_diff(out, want))
+        back = gpu_decode_indexed(torch, codec, out, offs, data.size)
+        assert np.array_equal(back, data), (name, "block index alone", first_diff(back, data))
+        assert codec.decode_counters()[0] == 0, (name, "blocks handed to the exact decoder", codec.decode_counters())
+        s = to_dev(torch, out)
+        dst = torch.empty(data.size, dtype=torch.uint8, device="cuda")
+        res = codec.decode_stream(s, out.size, out.size, dst)
+        assert res[0] == 0 and res[1] == data.size, (name, res)
+        assert np.array_equal(dst.cpu().numpy(), data), (name, "raw stream")

@@ -471,3 +471,68 @@ def test_raw_stream_of_blocks_whose_bit_rate_changes(torch_mod, codec, blocksize
     ref = torch.zeros_like(out)
     assert codec.decode_stream(stream, length, length, ref, relaxed=True, sequential=True) == (0, n, length)
     assert torch.equal(ref, out)
+
+
+@pytest.mark.gpu
+def test_small_and_full_size_streams_with_codes_beyond_the_table(torch_mod):
+    """round 6b.  (a) huf_decode of small memory streams (hufgpu_decode_small: the in-order chain with decode_regs in front) whose
+    one block has codes of more than 12 bits: 9 000 ... 100 000 bytes of skewed bytes with rare ones, stream and round trip against
+    the oracle.  (b) 256 MiB of the same kind in 64 KiB blocks with the block index alone and as a raw stream: the round trip, and
+    the first and last blocks of the stream against the oracle's."""
+    import ctypes as C
+    torch = torch_mod
+    from libhuffman_amd import _native as N
+    from libhuffman_amd.codec import GpuCodec
+    from oracle.oracle import Oracle
+    L = N.load()
+    orc = Oracle()
+    rng = np.random.default_rng(66)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def skewed(n):
+        a = (rng.zipf(1.35, size=n) % 180).astype(np.uint8)
+        k = max(3, n // 3000)
+        a[rng.integers(0, n, size=k)] = rng.integers(180, 255, size=k).astype(np.uint8)
+        return a
+
+    for n in (9000, 20000, 40001, 65536, 100000):
+        data = skewed(n)
+        bs = 65536
+        want = orc.encode(data, bs)
+        rin, rout, rback = C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)(), C.POINTER(N.ReadWriter)()
+        bin_, bout, bback = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for r, b in ((rin, bin_), (rout, bout), (rback, bback)):
+            assert L.huf_memopen(C.byref(r), C.byref(b), 64) == 0
+        assert rin.contents.write(rin.contents.stream, data.ctypes.data_as(C.c_void_p), n) == 0
+        cfg = N.Config(n, bs, 0, 0, rin, rout)
+        assert L.huf_encode(C.byref(cfg)) == 0
+        m = C.c_size_t()
+        L.huf_memlen(rout, C.byref(m))
+        enc = np.frombuffer(C.string_at(bout.value, m.value), np.uint8)
+        assert np.array_equal(enc, want), n
+        dcfg = N.Config(m.value, bs, 0, 0, rout, rback)
+        assert L.huf_decode(C.byref(dcfg)) == 0, n
+        L.huf_memlen(rback, C.byref(m))
+        assert m.value == n and np.array_equal(np.frombuffer(C.string_at(bback.value, n), np.uint8), data), n
+        for r in (rin, rout, rback):
+            L.huf_memclose(C.byref(r))
+        for b in (bin_, bout, bback):
+            libc.free(b)
+
+    c = GpuCodec(0)
+    tile, n, bs = 8 << 20, 256 << 20, 65536
+    host = skewed(tile)
+    data = torch.from_numpy(host).cuda().repeat(n // tile)
+    nb = c.block_count(n, bs)
+    stream, offs, length = c.encode(data, bs)
+    oh = offs.cpu().numpy()
+    want_tile = orc.encode(host, bs)                                 # the stream of one tile: the first 128 blocks of the whole
+    assert np.array_equal(stream[:want_tile.size].cpu().numpy(), want_tile)
+    assert np.array_equal(stream[int(oh[nb - 128]):length].cpu().numpy(), want_tile)      # and the last 128
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert c.decode(stream, length, offs, nb, back) == n and torch.equal(back, data)
+    assert c.decode_counters()[0] == 0
+    back.zero_()
+    res = c.decode_stream(stream, length, length, back)
+    assert res[0] == 0 and res[1] == n and torch.equal(back, data)

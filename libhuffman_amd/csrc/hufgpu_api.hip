@@ -770,7 +770,10 @@ static int decode_impl(hufgpu_ctx_t *ctx, const void *d_stream, uint64_t stream_
             fix.blocks = ctx->d_fix_blocks;
             fix.flag = ctx->d_fix_flag;
             const unsigned fix_grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
-            decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, ctx->d_out_offsets, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
+            DecodeFastArgs fa;
+            fa.stream = st; fa.stream_len = stream_len; fa.offsets = d_block_offsets; fa.dmeta = ctx->d_dmeta; fa.out_offsets = ctx->d_out_offsets;
+            fa.lens = lens; fa.out = (uint8_t *)d_out; fa.out_cap = out_cap; fa.status = ctx->d_status; fa.result = res; fa.fix = fix;
+            decode_fast_kernel<DEC_THREADS><<<dim3((unsigned)nblocks), dim3(DEC_THREADS), 0, s>>>(fa);
             decode_fix_kernel<DEC_THREADS><<<dim3(fix_grid), dim3(DEC_THREADS), 0, s>>>(st, stream_len, d_block_offsets, ctx->d_dmeta, lens, (uint8_t *)d_out, out_cap, ctx->d_status, res, fix);
         }
     }

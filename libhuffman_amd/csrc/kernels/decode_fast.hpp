@@ -1108,78 +1108,116 @@ template <int THREADS, class BuildTables>
 __device__ __forceinline__ int decode_payload_regs(DecShared<THREADS> &sh, const uint8_t *pay, uint64_t pay_bytes, uint64_t readable, uint64_t block_len,
                                                    uint8_t *gout, uint64_t *end_bits, uint64_t hint_bytes, BuildTables build_tables);      /* decode_regs.hpp */
 
+/* decode_fast_kernel's arguments: ONE struct, so that the code behind decode_payload_regs can read them again from where they lie
+ * (the kernel argument segment) instead of holding them in scalar registers through the whole decode - round 6b: at eight waves a
+ * SIMD a wave has 80 of those, the register path's loop needs most, and what does not fit is brought back by v_readlane, a vector
+ * instruction.  Only the fall-back paths and the list of blocks for the exact decoder need anything after the payload. */
+struct DecodeFastArgs {
+    const uint8_t *stream;
+    uint64_t stream_len;
+    const uint64_t *offsets;
+    const HufDecodeMeta *dmeta;
+    uint64_t *out_offsets;
+    TwoLevel lens;
+    uint8_t *out;
+    uint64_t out_cap;
+    int32_t *status;
+    unsigned long long *result;
+    DecFixList fix;
+};
+
+/* where block blk's tree and payload lie and where its bytes go */
+struct DfastBlock {
+    HufDecodeMeta m;
+    uint64_t obase, pay_bytes, readable;
+    const uint8_t *tree, *pay;
+};
+__device__ __forceinline__ DfastBlock dfast_locate(const DecodeFastArgs &a, uint64_t blk)
+{
+    DfastBlock b;
+    b.m = a.dmeta[blk];
+    b.m.block_len = uni64(b.m.block_len);
+    b.m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)b.m.tree_len);
+    b.m.leaf = (int16_t)uni32((uint32_t)(uint16_t)b.m.leaf);
+    b.m.status = (int32_t)uni32((uint32_t)b.m.status);
+    b.obase = uni64(a.lens.gprefix[blk / SCAN_GROUP] + a.lens.local[blk]);
+    const uint64_t o0 = uni64(a.offsets[blk]);
+    const uint64_t o1 = dmin<uint64_t>(uni64(a.offsets[blk + 1]), a.stream_len);
+    b.pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)b.m.tree_len);
+    b.tree = a.stream + o0 + HUF_HEADER_FIXED;
+    b.pay = b.tree + 2 * (int)b.m.tree_len;
+    b.readable = a.stream_len - (uint64_t)(b.pay - a.stream);
+    return b;
+}
+
 /* One indexed block (the body of decode_fast_kernel). */
 template <int THREADS>
-__device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, uint64_t blk,
-    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
-    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
-    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ result, DecFixList fix)
+__device__ __forceinline__ void decode_fast_block(DecShared<THREADS> &sh, const DecodeFastArgs &a)
 {
     const int tid = (int)threadIdx.x;
-    HufDecodeMeta m = dmeta[blk];
-    m.block_len = uni64(m.block_len);
-    m.tree_len = (int16_t)uni32((uint32_t)(uint16_t)m.tree_len);
-    m.leaf = (int16_t)uni32((uint32_t)(uint16_t)m.leaf);
-    m.status = (int32_t)uni32((uint32_t)m.status);
-    const uint64_t obase = uni64(lens.gprefix[blk / SCAN_GROUP] + lens.local[blk]);
-    if (tid == 0) out_offsets[blk] = obase;
-    if (m.status != HUFE_OK || m.block_len == 0) return;             /* header errors were recorded by decode_prepare */
-    if (obase + m.block_len > out_cap) {
-        if (tid == 0) {
-            status[blk] = HUFE_MEMORY;
-            atomicMin(&result[2], (unsigned long long)blk);
+    int regs = 0;                                       /* (uniform) what decode_regs.hpp made of the block: 0 = it declined (another shape of tree, a short or a dull block) */
+    {
+        const uint64_t blk = blockIdx.x;
+        const DfastBlock b = dfast_locate(a, blk);
+        if (tid == 0) a.out_offsets[blk] = b.obase;
+        if (b.m.status != HUFE_OK || b.m.block_len == 0) return;         /* header errors were recorded by decode_prepare */
+        if (b.obase + b.m.block_len > a.out_cap) {
+            if (tid == 0) {
+                a.status[blk] = HUFE_MEMORY;
+                atomicMin(&a.result[2], (unsigned long long)blk);
+            }
+            return;
         }
-        return;
-    }
-    const uint64_t o0 = uni64(offsets[blk]);
-    const uint64_t o1 = dmin<uint64_t>(uni64(offsets[blk + 1]), stream_len);
-    const uint64_t pay_bytes = o1 - (o0 + HUF_HEADER_FIXED + 2ull * (uint64_t)m.tree_len);
-    const uint8_t *tree = stream + o0 + HUF_HEADER_FIXED;
-    const uint8_t *pay = tree + 2 * (int)m.tree_len;
-    int leaf = m.leaf;
-    int rc = HUFE_OK;
-    unsigned long long kt = DPROF_T();
-    /* (from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide next to a long
-     *  payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05, log text
-     *  1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
-    int regs = 0;                                       /* (uniform) what decode_regs.hpp made of the block: 0 = it declined (another shape of tree, long codes) */
 #ifndef DFAST_NO_REGS
-    if (leaf < 0 && m.block_len >= DREG_MIN_BLOCK)
-        regs = decode_payload_regs<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase, nullptr, 0,
-                                            [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, tree, m.tree_len) ? (uni32(sh.l2n) != 0u ? 2 : 1) : 0; });
-    if (leaf < 0 && regs == 0)
-        rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
-#else
-    if (leaf < 0 && !(m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, tree, m.tree_len)))
-        rc = dec_build_tables<THREADS, true>(sh, tree, m.tree_len, &leaf);
+        if (b.m.leaf < 0 && b.m.block_len >= DREG_MIN_BLOCK)
+            regs = decode_payload_regs<THREADS>(sh, b.pay, b.pay_bytes, b.readable, b.m.block_len, a.out + b.obase, nullptr, 0,
+                                                [&]() { return dfast_tables_from_tree<THREADS, true, true>(sh, b.tree, b.m.tree_len) ? (uni32(sh.l2n) != 0u ? 2 : 1) : 0; });
+        if (regs == 1) return;                          /* (DREG_OK: most blocks of most streams end here) */
 #endif
-    DPROF_ADD(6, kt);
+    }
+    /* Everything from here on reads the arguments AGAIN, through a pointer the compiler cannot see through: nothing of the above
+     * is held in registers across the payload for it. */
+    const DecodeFastArgs *again = (const DecodeFastArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(again));
+    const DecodeFastArgs &r = *again;
+    const uint64_t blk = blockIdx.x;
     bool good;
-    if (rc != HUFE_OK) {
-        good = false;
-    } else if (regs != 0) {
-        good = regs == 1;                               /* (DREG_OK) */
-    } else if (leaf >= 0) {
-        uint64_t eb = 0, produced = 0;
-        good = decode_single_leaf<THREADS, true>(sh, (uint32_t)leaf, pay, m.block_len, pay_bytes, out + obase, &eb, &produced) == HUFE_OK;
+    if (regs != 0) {
+        good = false;                                   /* (DREG_FAILED) */
     } else {
-        good = decode_payload_dfast<THREADS>(sh, pay, pay_bytes, stream_len - (uint64_t)(pay - stream), m.block_len, out + obase);
+        const DfastBlock b = dfast_locate(r, blk);
+        int leaf = b.m.leaf;
+        int rc = HUFE_OK;
+        unsigned long long kt = DPROF_T();
+        /* (dfast_tables_from_tree from 32 KiB of symbols on: the chain is a latency - 3 us a block - that four workgroups per CU hide
+         *  next to a long payload and not next to a short one.  1 GiB in 64 KiB blocks: zipf255 1.72 -> 1.70 ms, uniform bytes 1.11 -> 1.05,
+         *  log text 1.75 -> 1.68; in 16 KiB blocks 3.2 -> 3.6, in 4 KiB blocks 12.7 -> 15.2 with it) */
+#ifndef DFAST_NO_REGS
+        if (leaf < 0) rc = dec_build_tables<THREADS, true>(sh, b.tree, b.m.tree_len, &leaf);
+#else
+        if (leaf < 0 && !(b.m.block_len >= 32768u && dfast_tables_from_tree<THREADS, true>(sh, b.tree, b.m.tree_len)))
+            rc = dec_build_tables<THREADS, true>(sh, b.tree, b.m.tree_len, &leaf);
+#endif
+        DPROF_ADD(6, kt);
+        if (rc != HUFE_OK) {
+            good = false;
+        } else if (leaf >= 0) {
+            uint64_t eb = 0, produced = 0;
+            good = decode_single_leaf<THREADS, true>(sh, (uint32_t)leaf, b.pay, b.m.block_len, b.pay_bytes, r.out + b.obase, &eb, &produced) == HUFE_OK;
+        } else {
+            good = decode_payload_dfast<THREADS>(sh, b.pay, b.pay_bytes, b.readable, b.m.block_len, r.out + b.obase);
+        }
     }
     if (!good && tid == 0) {
-        if (atomicExch(&fix.flag[blk], 1u) == 0u) fix.blocks[atomicAdd(fix.count, 1u)] = (uint32_t)blk;
+        if (atomicExch(&r.fix.flag[blk], 1u) == 0u) r.fix.blocks[atomicAdd(r.fix.count, 1u)] = (uint32_t)blk;
     }
 }
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kernel(
-    const uint8_t *__restrict__ stream, uint64_t stream_len, const uint64_t *__restrict__ offsets,
-    const HufDecodeMeta *__restrict__ dmeta, uint64_t *__restrict__ out_offsets, TwoLevel lens,
-    uint8_t *__restrict__ out, uint64_t out_cap, int32_t *__restrict__ status,
-    unsigned long long *__restrict__ result, DecFixList fix)
+__global__ __launch_bounds__(THREADS, DEC_WAVES_PER_SIMD) void decode_fast_kernel(DecodeFastArgs a)
 {
     __shared__ DecShared<THREADS> sh;
-    decode_fast_block<THREADS>(sh, blockIdx.x, stream, stream_len, offsets, dmeta, out_offsets, lens, out, out_cap, status, result, fix);
+    decode_fast_block<THREADS>(sh, a);
 }
 
 }  // namespace hufgpu

@@ -768,7 +768,9 @@ __global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_
     uint64_t rd = 0, wr = 0, nblk = 0;
     uint64_t good_rd = 0, good_wr = 0;
     int err = HUFE_OK;
+    unsigned long long pk = DPROF_T();                                /* (tools/phase_fast.py small: slots 13 = the kernel, 14 = a block's header, 15 = its payload) */
     while (length > rd) {                                             /* decoder.c:218 */
+        unsigned long long ph = DPROF_T();
         good_rd = rd;
         good_wr = wr;
         if (avail - rd < 8) { err = HUFE_RW; break; }                 /* decoder.c:220-224 */
@@ -791,6 +793,7 @@ __global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_
         if (want == block_len && tl >= 9 && tl <= HUF_TREE_MAX && block_len >= 256u) {
             const uint64_t hint = length > rd ? length - rd : 0;
             __syncthreads();
+            DPROF_ADD(14, ph); ph = DPROF_T();
             /* (blocks of a few KiB have codes beyond the table's 12 bits - a byte seen once in 4 096 - and the path of this file
              *  declines them: decode_fast.hpp's lean decoder walks such codes, with the tables of the tree's walk) */
             const int lean = block_len < DREG_MIN_BLOCK ? DREG_NO_TABLES :
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_
                 done = dec_build_tables<THREADS, true>(sh, tree, tl, &leaf) == HUFE_OK && leaf < 0 &&
                        decode_payload_dfast<THREADS>(sh, stream + rd, avail - rd, avail - rd, block_len, out + wr, &end_bits, hint);
             }
+            DPROF_ADD(15, ph);
             if (done) {
                 rd += (end_bits + 7) >> 3;
                 wr += block_len;
@@ -820,6 +824,7 @@ __global__ __launch_bounds__(THREADS) void decode_chain_lean_kernel(const uint8_
         wr += block_len;
         nblk++;
     }
+    DPROF_ADD(13, pk);
     if (threadIdx.x == 0) {
         result[0] = (uint64_t)err;
         result[1] = wr;

@@ -226,8 +226,30 @@ __global__ __launch_bounds__(DISC_THREADS) void discover_kernel(const uint8_t *_
     uint32_t tot_lo, tot_hi;
     const uint32_t c_lo = (uint32_t)__popc((uint32_t)mask & 0xffffu) | ((uint32_t)__popc((uint32_t)(mask >> 16) & 0xffffu) << 16);
     const uint32_t c_hi = (uint32_t)__popc((uint32_t)(mask >> 32) & 0xffffu) | ((uint32_t)__popc((uint32_t)(mask >> 48)) << 16);
-    const uint32_t ex_lo = block_excl_scan_u32<DISC_THREADS>(c_lo, s_part, tot_lo);
-    const uint32_t ex_hi = block_excl_scan_u32<DISC_THREADS>(c_hi, s_part2, tot_hi);
+    /* (both sums behind ONE barrier - the partial words are written once a launch -, the waves' words summed by the lanes as in
+     *  decode_regs.hpp's dreg_excl_scan: 0.211 -> 0.207 ms.  Measured beside it and not kept: workgroups of 512 / 1 024 threads
+     *  0.27 / 0.45 ms, a launched workgroup scanning 2 / 4 / 8 pieces one after the other 0.227 / 0.232 / 0.237 - a wave lives one memory
+     *  round trip, and many short waves hide it better than few long ones) */
+    uint32_t ex_lo, ex_hi;
+    {
+        constexpr int WAVES = DISC_THREADS / 64;
+        static_assert(WAVES == 4, "four waves' words summed by the first four lanes of a row");
+        const uint32_t wv = uni32(threadIdx.x >> 6);
+        const uint32_t i_lo = wave_incl_scan_u32(c_lo), i_hi = wave_incl_scan_u32(c_hi);
+        if (lane_id() == 63) { s_part[wv] = i_lo; s_part2[wv] = i_hi; }
+        __syncthreads();
+        uint32_t x = s_part[lane_id() & (WAVES - 1)], y = s_part2[lane_id() & (WAVES - 1)];
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+        y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xf, 0xf, true);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+        y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xf, 0xf, true);
+        tot_lo = (uint32_t)__builtin_amdgcn_readlane((int)x, WAVES - 1);
+        tot_hi = (uint32_t)__builtin_amdgcn_readlane((int)y, WAVES - 1);
+        const uint32_t b_lo = wv != 0u ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wv - 1) : 0u;
+        const uint32_t b_hi = wv != 0u ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wv - 1) : 0u;
+        ex_lo = b_lo + i_lo - c_lo;
+        ex_hi = b_hi + i_hi - c_hi;
+    }
     const uint32_t tot[4] = {tot_lo & 0xffffu, tot_lo >> 16, tot_hi & 0xffffu, tot_hi >> 16};
     const uint32_t total = tot[0] + tot[1] + tot[2] + tot[3];
     if (total <= DISC_SLOTS) {                                     /* (uniform) */

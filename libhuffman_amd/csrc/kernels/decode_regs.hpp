@@ -21,11 +21,11 @@ namespace hufgpu {
  * scans could not keep their symbols because a lane does not know where its bytes go before every lane in front of it
  * has counted.  Here they are kept all the same - in registers:
  *
- *   - a lane's share of a segment is at most 288 payload bits and (the shares are cut to the block's bits per
- *     symbol) about 40 symbols, at most 64: sixteen registers of four bytes (DREG_ITERS);
+ *   - a lane's share of a segment is at most 384 payload bits and (the shares are cut to the block's bits per
+ *     symbol) about 48 symbols, at most 64: sixteen registers of four bytes (DREG_ITERS);
  *   - ONE pass form: from the lane's start, four symbols an iteration with decode_sub's loop (entries byte << 8 | length
  *     over the 12 bits at a position, a position register that counts down with a gap, both lengths of a window
- *     subtracted by one v_dot4c) - 28 vector instructions per four symbols, the iteration's four bytes into register k;
+ *     subtracted by one v_dot4c) - 27 vector instructions per four symbols, the iteration's four bytes into register k;
  *     a lane whose position has passed its share's end is switched off; the four lengths of its last iteration give
  *     the end (the first codeword start at or behind the share's end) and the count;
  *   - the rounds are decode_fast's: lane 0 starts at the segment's true first codeword, every other lane at its own
@@ -41,6 +41,8 @@ namespace hufgpu {
  * what puts a speculative track into step), no codeword of the block needs bits past the payload,
  * the symbols add up to block_len.  A block that fails any of it goes to the exact decoder (decode_fix_kernel /
  * probe_exact_kernel), which has the reference's error code and byte count.
+ * Codes beyond the table's 12 bits (up to 32): DregLeaves below.  Blocks of fewer than 8 192 symbols, of fewer than four bits a
+ * symbol, with a code beyond 32 bits or a tree of another shape are decode_fast.hpp's.
  * A share that holds more than 64 codewords (codes far shorter than the block's average) has the segment done again
  * with shares of half the bits; 128 bits cannot hold more than 64 codewords (no code of these trees has fewer than 2).
  * ==================================================================================== */

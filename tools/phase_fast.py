@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from libhuffman_amd.codec import GpuCodec
 c = GpuCodec(0)
-names = {6: "tables+all", 1: "stage", 2: "first pass", 3: "rounds", 4: "request+sums", 7: "partial walk", 8: "commit", 9: "stores", 5: "last barrier", 10: "plan+request", 11: "tables", 12: "first commit"}
+names = {6: "tables+all", 1: "stage", 2: "first pass", 3: "rounds", 4: "request+sums", 7: "partial walk", 8: "commit", 9: "stores", 10: "plan+request", 11: "tables", 12: "first commit"}
 for wl in sys.argv[1:] or ["zipf255"]:
     n, bs = 1 << 28, 65536
     d = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(d, wl)

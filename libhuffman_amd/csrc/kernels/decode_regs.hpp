@@ -41,8 +41,8 @@ namespace hufgpu {
  * what puts a speculative track into step), no codeword of the block needs bits past the payload,
  * the symbols add up to block_len.  A block that fails any of it goes to the exact decoder (decode_fix_kernel /
  * probe_exact_kernel), which has the reference's error code and byte count.
- * Codes beyond the table's 12 bits (up to 32): DregLeaves below.  Blocks of fewer than 8 192 symbols, of fewer than four bits a
- * symbol, with a code beyond 32 bits or a tree of another shape are decode_fast.hpp's.
+ * Codes beyond the table's 12 bits (up to 32): DregLeaves below.  Blocks of fewer than 8 192 symbols, with a code beyond 32 bits
+ * or a tree of another shape are decode_fast.hpp's, and so are - for the raw-stream probe - blocks of fewer than four bits a symbol.
  * A share that holds more than 64 codewords (codes far shorter than the block's average) has the segment done again
  * with shares of half the bits; 128 bits cannot hold more than 64 codewords (no code of these trees has fewer than 2).
  * ==================================================================================== */
@@ -58,6 +58,10 @@ namespace hufgpu {
 #endif
 #ifndef DREG_TARGET_SYMS
 #define DREG_TARGET_SYMS (DREG_ITERS == 16 ? (DREG_ROWS >= 15u ? 48u : 40u) : 30u)   /* symbols a share is cut for (of 4 x DREG_ITERS it may hold) */
+#endif
+#ifndef DREG_MIN_SHARE_BITS
+#define DREG_MIN_SHARE_BITS 64u                 /* a block whose shares (DREG_TARGET_SYMS symbols at its bits a symbol) would be shorter is not this path's ... */
+#define DREG_MIN_SHARE_BITS_PROBE 192u          /* ... and for the raw-stream probe, whose failures cost more, one of fewer than four bits a symbol: decode_payload_regs */
 #endif
 #define DREG_MAX_BLOCK (1u << 26)              /* symbols of a block this path takes: 32 x 2^26 payload bits are positions of 32 bits */
 #define DREG_SAFE_BITS (8u * DREG_ITERS)       /* a share of so many bits cannot hold more codewords than the registers take: none has fewer than 2 bits */
@@ -476,20 +480,25 @@ __device__ __forceinline__ int decode_payload_regs_as(DecShared<THREADS> &sh, co
         if (known != 0u) {
             const float per_sym = (float)known / (float)block_len;
             const float est = (float)DREG_TARGET_SYMS * per_sym;
-            /* (a block of fewer than four bits a symbol is not this path's: the sixteen registers hold its shares down to a
-             *  hundred bits and less, in which a speculative track does not fall into step - the rounds then put the lanes right
-             *  one at a time.  Geometric bytes, two bits a symbol, 1 MiB blocks: 2.8 ms here, 2.4 with decode_fast.hpp's scans,
-             *  which count a share of 288 bits whatever it holds.) */
-            if (est < 192.0f) return DREG_NO_TABLES;
+            /* Blocks of few bits a symbol: the sixteen registers hold their shares down to a hundred bits and less, in which a
+             * speculative track falls into step late.  With the block index they are still this path's down to shares of 64 bits
+             * (`tools/time_lowentropy.py`, ms per GiB in 64 KiB / 1 MiB blocks, this path against decode_fast.hpp's scans: two byte
+             * values 0.68 / 0.56 against 1.23 / 1.33, zeros with 1 % of random bytes 0.92 / 0.74 against 1.40 / 1.00, geometric bytes
+             * 2.55 / 1.66 against 4.28 / 2.02).  The PROBE of a raw stream keeps them away unless all their codes have one length
+             * (two byte values 0.90 against 1.39 ms a call, four 0.87 against 1.14): what the rounds do not settle there goes to the
+             * exact decoder, and geometric bytes in 64 KiB blocks hold blocks that take THAT milliseconds (11.4 against 4.5 ms a
+             * call with them through here; round 6 did not get to the bottom of either figure). */
+            const uint32_t Lfix = (uint32_t)(per_sym + 0.001f);
+            const bool one_length = Lfix >= 2u && Lfix <= DEC_LUT_BITS && known - Lfix * block_len < 8u;
+            if (est < (float)((end_bits && !one_length) ? DREG_MIN_SHARE_BITS_PROBE : DREG_MIN_SHARE_BITS)) return DREG_NO_TABLES;
             cap = est >= (float)DREG_SUB_BITS ? DREG_SUB_BITS : dmax<uint32_t>((uint32_t)est, 64u);
             /* Incompressible bytes: every code 9 bits (8 and the root's 0), the payload block_len x 9 bits and a byte's padding.
              * Shares of whole codewords then - a lane's own first bit IS a codeword's and the speculative pass the only one,
              * where codes of one length never fall into step by themselves (1 GiB of uniform bytes: 0.78 ms against 1.06 with
              * shares of 384 bits).  A block that only looks like it loses nothing. */
-            const uint32_t L = (uint32_t)(per_sym + 0.001f);
-            if (L >= 2u && L <= DEC_LUT_BITS && known - L * block_len < 8u) {
-                fixlen = L;
-                cap = L * (uint32_t)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)L));
+            if (one_length) {
+                fixlen = Lfix;
+                cap = Lfix * (uint32_t)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)Lfix));
             }
         }
     }

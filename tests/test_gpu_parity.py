@@ -1075,3 +1075,35 @@ def test_codes_beyond_the_table_with_the_block_index_alone(torch_mod, codec, ora
         res = codec.decode_stream(s, out.size, out.size, dst)
         assert res[0] == 0 and res[1] == data.size, (name, res)
         assert np.array_equal(dst.cpu().numpy(), data), (name, "raw stream")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [16384, 65536])
+def test_blocks_of_few_bits_a_symbol_with_the_block_index_alone(torch_mod, codec, oracle, bs):
+    """round 6b: with the block index decode_regs.hpp takes blocks down to shares of 64 bits - two or four byte values (all codes
+    one length: shares of whole codewords), zeros with a few random bytes, geometric bytes (shares of a hundred bits, the segment done
+    again when one holds more than 64 codewords).  The oracle's stream, decoded with the block index alone and as a raw stream."""
+    torch = torch_mod
+    rng = np.random.default_rng(bs + 1)
+    n = 5 * bs + 333
+    sets = [("two byte values", rng.integers(0, 2, size=n).astype(np.uint8) * 77),
+            ("four byte values", (rng.integers(0, 4, size=n) * 50).astype(np.uint8))]
+    sp = np.zeros(n, np.uint8)
+    k = n // 100
+    sp[rng.integers(0, n, size=k)] = rng.integers(1, 256, size=k).astype(np.uint8)
+    sets.append(("zeros, 1 % random bytes", sp))
+    w = 0.5 ** np.arange(1, 21)
+    sets.append(("geometric", rng.choice(20, size=n, p=w / w.sum()).astype(np.uint8)))
+    runs = np.repeat(rng.integers(0, 3, size=n // 500 + 1).astype(np.uint8), 500)[:n]
+    sets.append(("runs of three byte values", runs))
+    for name, data in sets:
+        want = oracle.encode(data, bs)
+        out, offs = gpu_encode(torch, codec, data, bs)
+        assert np.array_equal(out, want), (name, first_diff(out, want))
+        back = gpu_decode_indexed(torch, codec, out, offs, data.size, relaxed=True)
+        assert np.array_equal(back, data), (name, "block index alone", first_diff(back, data))
+        s = to_dev(torch, out)
+        dst = torch.empty(data.size, dtype=torch.uint8, device="cuda")
+        res = codec.decode_stream(s, out.size, out.size, dst, relaxed=True)
+        assert res[0] == 0 and res[1] == data.size, (name, res)
+        assert np.array_equal(dst.cpu().numpy(), data), (name, "raw stream")

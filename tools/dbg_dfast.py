@@ -22,6 +22,13 @@ for wl in [a for a in sys.argv[1:] if a != "--raw"] or ["zipf255", "uniform256"]
         pos = np.arange(n) % bs
         first = (np.arange(n) // bs) % 2 == 0
         data = torch.from_numpy(np.where((pos < bs // 2) == first, cheap, dear)).cuda()
+    elif wl == "geometric":         # three bits a symbol; in 64 KiB blocks a block in 256 that the raw-stream probe cannot vouch for
+        import numpy as np
+        rng = np.random.default_rng(9)
+        tile = 16 << 20
+        rng.integers(0, 2, size=tile); rng.integers(0, 4, size=tile); rng.integers(0, 16, size=tile); k = tile // 100; rng.integers(0, tile, size=k); rng.integers(1, 256, size=k)
+        w = 0.5 ** np.arange(1, 21)
+        data = torch.from_numpy(rng.choice(20, size=tile, p=w / w.sum()).astype(np.uint8)).cuda().repeat(n // tile)
     else:
         data = torch.empty(n, dtype=torch.uint8, device="cuda"); c.fill(data, wl)
     out, offs, length = c.encode(data, bs)
